@@ -1,0 +1,240 @@
+"""Golden-vector generator (runs ONLY in the build container, where
+/root/reference exists).  Imports the real reference on CPU following the
+recipe in SURVEY.md 8c, feeds it deterministic numpy weights + synthetic
+batches, and writes small fixtures under tests/golden/.  Only data (inputs and
+expected outputs) is written -- no reference source.
+
+Usage:  python oracle/gen_golden.py [--time]
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import seqpan_ref as R  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    tk = types.ModuleType("tkinter"); tk.Y = None; sys.modules["tkinter"] = tk
+    pkg = types.ModuleType("models"); pkg.__path__ = ["/root/reference/models"]; sys.modules["models"] = pkg
+    torch.cuda.synchronize = lambda *a, **k: None
+    seqpan = importlib.import_module("models.SeqPAN")
+    loss = importlib.import_module("models.loss")
+    engine = importlib.import_module("utils.engine")
+    return seqpan, loss, engine
+
+
+def build_reference(seqpan_mod, cfg, weights):
+    glove = weights["text_encoder.word_emb.glove_vec"]
+    model = seqpan_mod.SeqPAN(cfg, glove)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(weights.keys()), "state_dict key order differs from oracle.param_shapes"
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(weights[k].shape), (k, v.shape, weights[k].shape)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    return model
+
+
+class GumbelPatch:
+    """Make the Gumbel noise an explicit stored input."""
+
+    def __init__(self, g):
+        self.g = g
+
+    def __enter__(self):
+        self.orig = torch.nn.functional.gumbel_softmax
+        g = self.g
+        torch.nn.functional.gumbel_softmax = lambda logits, tau=1, hard=False, eps=1e-10, dim=-1: \
+            torch.softmax((logits + g) / tau, dim)
+        return self
+
+    def __exit__(self, *a):
+        torch.nn.functional.gumbel_softmax = self.orig
+
+
+def run_reference(mods, cfg, weights, batch, g, train_mode_grads=True, hooks=False):
+    seqpan_mod, loss_mod, engine_mod = mods
+    model = build_reference(seqpan_mod, cfg, weights)
+    model.eval()  # dropout off; grads still flow (SURVEY.md 7 "Randomness")
+    inter = {}
+    handles = []
+    if hooks:
+        calls = {}
+
+        def mk(name):
+            def hook(_m, _i, o):
+                n = calls.get(name, 0); calls[name] = n + 1
+                inter[f"{name}#{n}"] = (o[0] if isinstance(o, tuple) else o).detach().numpy().copy()
+            return hook
+        for name in ("text_encoder", "video_affine", "vfeat_encoder", "dual_attention_block_1",
+                     "dual_attention_block_2", "q2v_attn", "v2q_attn", "cq_cat", "match_conv1d",
+                     "predictor.feature_encoder"):
+            mod = model
+            for part in name.split("."):
+                mod = getattr(mod, part)
+            handles.append(mod.register_forward_hook(mk(name)))
+    with GumbelPatch(g):
+        cfg.device = "cpu"
+        loss, out = seqpan_mod.train_engine_SeqPAN(model, batch, cfg, "train")
+    for h in handles:
+        h.remove()
+    res = {"slogits": out["slogits"].detach().numpy(), "elogits": out["elogits"].detach().numpy(),
+           "match_score": out["match_score"].detach().numpy(), "loss": np.float32(loss.item())}
+    lab = batch["label1ds"]
+    res["loss_loc"] = np.float32(loss_mod.lossfun_loc(out["slogits"], out["elogits"], lab[:, 0], lab[:, 1],
+                                                      batch["vmasks"]).item())
+    res["loss_match"] = np.float32(loss_mod.lossfun_match(out["match_score"], out["label_embs"],
+                                                          batch["NER_labels"], batch["vmasks"]).item())
+    res["infer"] = seqpan_mod.infer_SeqPAN(out, cfg).astype(np.float32)
+    grads = {}
+    if train_mode_grads:
+        loss.backward()
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                grads[n] = p.grad.detach().numpy().copy()
+        res["nograd_keys"] = np.array(sorted(n for n, p in model.named_parameters()
+                                             if p.requires_grad and p.grad is None))
+    return res, inter, grads, model
+
+
+def run_oracle(cfg, weights, batch, g):
+    P = R.to_params(weights, requires_grad=True)
+    loss, out, (loc, mat) = R.train_loss(P, cfg, batch, g)
+    loss.backward()
+    grads = {k: v.grad.numpy() for k, v in P.items() if v.grad is not None}
+    return loss, out, grads
+
+
+def maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def case(mods, name, B, T, L, D, V, num_words, num_chars, C, seed, store_weights, hooks, mutate=None):
+    cfg = R.make_cfg(dim=D, vlen=T, vdim=V, num_words=num_words, num_chars=num_chars)
+    weights = R.make_weights(cfg, seed)
+    batch = R.synth_batch(B, T, L, V, num_words, num_chars, C=C, seed=seed)
+    if mutate:
+        mutate(batch)
+    g = R.gumbel_noise(B, T, seed)
+    res, inter, grads, _ = run_reference(mods, cfg, weights, batch, g, hooks=hooks)
+    # validate the restatement against the real reference right here
+    loss_o, out_o, grads_o = run_oracle(cfg, weights, batch, g)
+    d = {k: maxdiff(res[k], out_o[k].detach().numpy()) for k in ("slogits", "elogits", "match_score")}
+    d["loss"] = abs(float(res["loss"]) - float(loss_o.item()))
+    gmax = max(float(np.max(np.abs(v))) for v in grads.values())
+    # analytically-zero grads (key biases, logit shifts) are fp32 noise: floor the scale
+    # (two fp32 implementations differ by accumulation order: compare in relative L2 per tensor)
+    gd = max(float(np.linalg.norm(grads[k].astype(np.float64) - grads_o[k])) /
+             (1e-4 * gmax * np.sqrt(grads[k].size) + float(np.linalg.norm(grads[k]))) for k in grads)
+    assert set(grads) == set(grads_o), set(grads) ^ set(grads_o)
+    print(f"[{name}] oracle-vs-reference max abs diff {d}  worst rel grad diff {gd:.2e}")
+    assert max(d.values()) < 2e-4 and gd < 2e-3, "oracle restatement disagrees with the reference"
+    save = {"meta": np.array([B, T, L, D, V, num_words, num_chars, C, seed], np.int64)}
+    for k, v in batch.items():
+        save["in." + k] = v.numpy()
+    save["in.gumbel"] = g.numpy()
+    for k, v in res.items():
+        save["out." + k] = v
+    for k, v in inter.items():
+        save["mid." + k] = v
+    if store_weights:
+        for k, v in weights.items():
+            save["w." + k] = v
+        for k, v in grads.items():
+            save["g." + k] = v
+    else:  # only norms + a few small grads (weights are regenerated from the recipe)
+        save["gnorm"] = np.float32(np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in grads.values())))
+        for k in ("label_embs", "match_conv1d.conv1d.bias", "predictor.start_dense.conv1d.weight",
+                  "q2v_attn.w4mlu", "video_affine.v_layer_norm.weight",
+                  "dual_attention_block_1.dual_multihead_attention.bilinear_1.bias_value"):
+            save["g." + k] = grads[k]
+        save["gnorms.keys"] = np.array(sorted(grads))
+        save["gnorms.vals"] = np.array([np.sqrt((grads[k].astype(np.float64) ** 2).sum()) for k in sorted(grads)],
+                                       np.float32)
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **save)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def adversarial(batch):
+    """g_masks: vlen=1, text length 1, equal start/end labels."""
+    B, T = batch["vmasks"].shape
+    L = batch["tmasks"].shape[1]
+    batch["vmasks"][1] = 0; batch["vmasks"][1, 0] = 1
+    batch["vfeats"][1, 1:] = 0
+    batch["tmasks"][2] = 0; batch["tmasks"][2, 0] = 1
+    batch["words_ids"][2, 1:] = 0; batch["char_ids"][2, 1:] = 0
+    lab = R.soft_boundary_labels(0, 0, T)
+    batch["label1ds"][1] = torch.from_numpy(lab)
+    batch["NER_labels"][1] = torch.from_numpy(R.ner_labels(0, 0, 1, T))
+
+
+def time_both(mods):
+    """Show the restatement is a fair CPU stand-in for the reference (+-10%)."""
+    cfg = R.make_cfg(dim=512, vlen=64, vdim=1024, num_words=4002, num_chars=60)
+    weights = R.make_weights(cfg, 7)
+    batch = R.synth_batch(4, 64, 10, 1024, 4002, 60, seed=7)
+    g = R.gumbel_noise(4, 64, 7)
+    model = build_reference(mods[0], cfg, weights); model.eval()
+    P = R.to_params(weights, requires_grad=True)
+
+    def ref_step():
+        with GumbelPatch(g):
+            loss, _ = mods[0].train_engine_SeqPAN(model, batch, cfg, "train")
+        model.zero_grad(); loss.backward()
+
+    def ora_step():
+        loss, _, _ = R.train_loss(P, cfg, batch, g)
+        for p in P.values():
+            p.grad = None
+        loss.backward()
+    for fn, nm in ((ref_step, "reference"), (ora_step, "oracle")):
+        fn()
+        t0 = time.time()
+        for _ in range(5):
+            fn()
+        print(f"cfg1 fwd+bwd {nm}: {(time.time() - t0) / 5 * 1e3:.1f} ms/step ({torch.get_num_threads()} threads)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--time", action="store_true")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    mods = import_reference()
+    # g_tiny: everything stored (weights, intermediates, per-parameter grads)
+    case(mods, "g_tiny", B=3, T=16, L=6, D=32, V=24, num_words=30, num_chars=12, C=5, seed=11,
+         store_weights=True, hooks=True)
+    # g_masks: adversarial masks on the tiny config
+    case(mods, "g_masks", B=3, T=16, L=6, D=32, V=24, num_words=30, num_chars=12, C=5, seed=12,
+         store_weights=True, hooks=False, mutate=adversarial)
+    # g_small: D=128 (the reference's real width, config/anet/SeqPAN_c3d.yaml:34), odd V
+    case(mods, "g_small", B=5, T=48, L=9, D=128, V=500, num_words=200, num_chars=40, C=8, seed=13,
+         store_weights=False, hooks=False)
+    # g_cfg1: BASELINE cfg1 end-to-end
+    case(mods, "g_cfg1", B=4, T=64, L=10, D=512, V=1024, num_words=4002, num_chars=60, C=8, seed=14,
+         store_weights=False, hooks=False)
+    # g_cfg2_small_B: cfg2 shapes at a DP-shard-sized batch
+    case(mods, "g_cfg2_small_B", B=8, T=128, L=20, D=1024, V=500, num_words=4002, num_chars=60, C=8, seed=15,
+         store_weights=False, hooks=False)
+    if args.time:
+        time_both(mods)
+
+
+if __name__ == "__main__":
+    main()

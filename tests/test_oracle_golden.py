@@ -1,0 +1,98 @@
+"""CPU: the oracle restatement (oracle/seqpan_ref.py) against the golden
+vectors produced by the real reference (oracle/gen_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import seqpan_ref as R
+from tests.helpers import load_golden
+
+TOL = 2e-4  # fp32 vs fp32, different accumulation order
+
+
+def _md(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def test_param_inventory_matches_survey():
+    cfg = R.make_cfg(dim=32, vlen=16, vdim=24, num_words=30, num_chars=12)
+    S = R.param_shapes(cfg)
+    assert len(S) == 192
+    unused = [k for k in S if R.is_unused(k)]
+    assert len(unused) == 20
+
+
+@pytest.mark.parametrize("name", ["g_tiny", "g_masks", "g_small", "g_cfg1"])
+def test_oracle_forward_loss_infer(name):
+    z, cfg, batch, g, weights = load_golden(name)
+    P = R.to_params(weights)
+    with torch.no_grad():
+        loss, out, (loc, mat) = R.train_loss(P, cfg, batch, g)
+    assert _md(out["slogits"], z["out.slogits"]) < TOL
+    assert _md(out["elogits"], z["out.elogits"]) < TOL
+    assert _md(out["match_score"], z["out.match_score"]) < TOL
+    assert abs(float(loss) - float(z["out.loss"])) < TOL
+    assert abs(float(loc) - float(z["out.loss_loc"])) < TOL
+    assert abs(float(mat) - float(z["out.loss_match"])) < TOL
+    inf = R.infer_basic(out["slogits"], out["elogits"], batch["vmasks"])
+    np.testing.assert_allclose(inf, z["out.infer"], atol=1e-6)
+    assert np.isfinite(out["slogits"].numpy()).all()
+
+
+def test_oracle_intermediates_tiny():
+    z, cfg, batch, g, weights = load_golden("g_tiny")
+    P = R.to_params(weights)
+    with torch.no_grad():
+        out, I = R.seqpan_forward(P, cfg, batch["words_ids"], batch["char_ids"], batch["vfeats"],
+                                  batch["vmasks"], batch["tmasks"], g, return_intermediates=True)
+    pairs = {"text_emb": "text_encoder#0", "video_proj": "video_affine#0", "venc": "vfeat_encoder#0",
+             "tenc": "vfeat_encoder#1", "dab1_v": "dual_attention_block_1#0", "dab1_t": "dual_attention_block_1#1",
+             "dab2_v": "dual_attention_block_2#0", "dab2_t": "dual_attention_block_2#1", "t2v": "q2v_attn#0",
+             "v2t": "v2q_attn#0", "fuse": "cq_cat#0", "match_logits": "match_conv1d#0",
+             "pred_sfeat": "predictor.feature_encoder#0", "pred_efeat": "predictor.feature_encoder#1"}
+    for mine, ref in pairs.items():
+        assert _md(I[mine], z["mid." + ref]) < TOL, mine
+
+
+@pytest.mark.parametrize("name", ["g_tiny", "g_masks"])
+def test_oracle_gradients(name):
+    z, cfg, batch, g, weights = load_golden(name)
+    P = R.to_params(weights, requires_grad=True)
+    loss, _, _ = R.train_loss(P, cfg, batch, g)
+    loss.backward()
+    gkeys = {k[2:] for k in z.files if k.startswith("g.")}
+    mine = {k for k, v in P.items() if v.grad is not None}
+    assert mine == gkeys
+    assert sorted(k for k in P if R.is_unused(k)) == sorted(z["out.nograd_keys"].tolist())
+    gmax = max(float(np.abs(z["g." + k]).max()) for k in gkeys)
+    for k in gkeys:
+        ref = z["g." + k].astype(np.float64)
+        rel = np.linalg.norm(P[k].grad.numpy() - ref) / (1e-4 * gmax * np.sqrt(ref.size) + np.linalg.norm(ref))
+        assert rel < 2e-3, (k, rel)
+
+
+def test_oracle_gradnorms_cfg1():
+    z, cfg, batch, g, weights = load_golden("g_cfg1")
+    P = R.to_params(weights, requires_grad=True)
+    loss, _, _ = R.train_loss(P, cfg, batch, g)
+    loss.backward()
+    keys = z["gnorms.keys"].tolist()
+    vals = z["gnorms.vals"]
+    tot = float(z["gnorm"])
+    for k, v in zip(keys, vals):
+        mine = float(P[k].grad.norm())
+        assert abs(mine - float(v)) <= 2e-3 * float(v) + 1e-5 * tot, k
+    mine_tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in P.values() if p.grad is not None)))
+    assert abs(mine_tot - tot) < 1e-3 * tot
+
+
+def test_fully_masked_rows_are_finite():
+    """-1e30 additive masks on fully padded query rows give a uniform softmax, not NaN."""
+    z, cfg, batch, g, weights = load_golden("g_masks")
+    assert float(batch["vmasks"][1].sum()) == 1.0 and float(batch["tmasks"][2].sum()) == 1.0
+    P = R.to_params(weights)
+    with torch.no_grad():
+        out = R.seqpan_forward(P, cfg, batch["words_ids"], batch["char_ids"], batch["vfeats"],
+                               batch["vmasks"], batch["tmasks"], g)
+    for k in ("slogits", "elogits", "match_score"):
+        assert torch.isfinite(out[k]).all()
