@@ -1,0 +1,176 @@
+/* vmr_hip.h -- C ABI of libvmr_hip.so: the MI355X (gfx950) kernels behind the
+ * SeqPAN cross-modal matching path.
+ *
+ * The reference (renjie-liang/VMRFrame) has NO FFI / operator registry: its
+ * boundary is the Python naming convention of main.py:21,87,99.
+ * Each entry point below therefore cites the reference *function* whose
+ * arithmetic it replaces (file:line relative to the reference tree); the
+ * Python host layer (vmrframe_amd/) binds them with ctypes and mirrors the
+ * reference's module/engine interface.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     stated; the caller owns all memory, the library never retains pointers.
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and
+ *     returns without synchronising: 0 on success, negative on error
+ *     (vmr_last_error() gives a thread-local message).
+ *   - tensors are row-major, last dim contiguous. `dtype` is VMR_F32 or
+ *     VMR_BF16 for activations; statistics, biases, LayerNorm affine
+ *     parameters, losses and weight gradients are always fp32.
+ */
+#ifndef VMR_HIP_H
+#define VMR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMR_F32 0
+#define VMR_BF16 1
+
+#define VMR_NEG_INF_MASK (-1e30f) /* models/layers.py:9 mask_value */
+
+int vmr_version(void);
+const char* vmr_last_error(void);
+
+/* ------------------------------------------------------------------ GEMM
+ * C[z] = epilogue(alpha * opA(A[z]) . opB(B[z]))
+ *   transA=0: A is [M,K] (k contiguous, leading dim lda); 1: A is [K,M]
+ *   transB=0: B is [N,K] (k contiguous -- the layout of a Conv1D/Linear
+ *             weight [out,in]);                           1: B is [K,N]
+ * Replaces every pointwise Conv1D (models/layers.py:15-26 == x.W^T+b), the
+ * nn.MultiheadAttention in/out projections (layers.py:570) and, batched, the
+ * QK^T / P.V contractions of DualMultiAttention (layers.py:349-366) and
+ * TopSelfAttention2 (layers.py:567-574), plus all their backward products.
+ * bf16 runs on v_mfma_f32_16x16x32_bf16, f32 on v_mfma_f32_16x16x4_f32.
+ */
+#define VMR_EPI_BIAS 1      /* + bias[n] (fp32)                               */
+#define VMR_EPI_RELU 2      /* max(.,0)                                        */
+#define VMR_EPI_DROPOUT 4   /* inverted dropout, counter-based mask            */
+#define VMR_EPI_RESIDUAL 8  /* + residual[m,n] (dtype, leading dim ldr)        */
+#define VMR_EPI_AUX 16      /* also store the pre-residual value to aux        */
+#define VMR_EPI_OUT_F32 32  /* C is fp32 regardless of dtype                   */
+#define VMR_EPI_ACCUM 64    /* C (fp32) += result, via atomics (split-K safe)  */
+#define VMR_EPI_ROWSCALE 128 /* multiply row m by rowscale[m] (fp32) at the end */
+
+typedef struct {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;
+  const void* residual;
+  void* aux;
+  const float* rowscale;
+  int64_t lda, ldb, ldc, ldr;
+  int32_t M, N, K;
+  int32_t transA, transB;
+  int32_t dtype;
+  int32_t flags;
+  float alpha;
+  /* batching: z in [0, Z1*Z2); z1 = z / Z2, z2 = z % Z2; element strides */
+  int32_t Z1, Z2;
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+  int32_t splitk; /* >1 requires VMR_EPI_ACCUM */
+  float drop_p;
+  uint32_t drop_seed;
+  uint32_t _pad;
+  const uint32_t* drop_step; /* nullable device counter mixed into the seed (hipGraph replay) */
+} vmr_gemm_t;
+
+int vmr_gemm(const vmr_gemm_t* g, void* stream);
+
+/* ------------------------------------------------------------- LayerNorm
+ * y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim D, optional
+ * "+ pos[row % S]" (PositionalEmbedding add of FeatureEncoder,
+ * layers.py:96-107,397) and optional dropout on the result.
+ * nn.LayerNorm call sites: layers.py:85,116,136,271-273,619-620,650-651. */
+int vmr_layernorm_fwd(const void* x, const float* gamma, const float* beta, float eps,
+                      const void* pos, int S, void* y, float* mean, float* rstd,
+                      int64_t rows, int D, int dtype, float drop_p, uint32_t drop_seed,
+                      const uint32_t* drop_step, void* stream);
+/* dx = LN backward of dy (dropout mask regenerated from the seed), optionally
+ * dx += dres (gradient arriving through a residual branch); dgamma/dbeta are
+ * ACCUMULATED (fp32 atomics) and must be zeroed by the caller when needed.
+ * dpos (optional, fp32 [S,D]) accumulates the positional-table gradient. */
+int vmr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                      const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                      float* dpos, int S, int64_t rows, int D, int dtype, float drop_p,
+                      uint32_t drop_seed, const uint32_t* drop_step, void* stream);
+
+/* ------------------------------------------ fused LayerNorm + depthwise conv
+ * u[b,s,:] = sum_k w[:,k] * LN(x)[b,s+k-3,:]   (k=7, zero padded, UNMASKED)
+ * = layer_norms[l] + depthwise Conv1d(groups=D) of DepthwiseSeparableConvBlock
+ * (layers.py:139-148).  x,u: [B,S,D]; w: fp32 [D,7]; mean/rstd: fp32 [B*S]. */
+int vmr_ln_dwconv_fwd(const void* x, const float* gamma, const float* beta, float eps,
+                      const float* w, void* u, float* mean, float* rstd,
+                      int B, int S, int D, int dtype, void* stream);
+/* backward of the depthwise conv alone: dn = conv^T(du); dw += sum du*n where
+ * n = LN(x) is recomputed from x, mean, rstd.  dn then goes to
+ * vmr_layernorm_bwd. dw is accumulated with fp32 atomics. */
+int vmr_dwconv_bwd(const void* du, const void* x, const float* gamma, const float* beta,
+                   const float* mean, const float* rstd, const float* w, void* dn, float* dw,
+                   int B, int S, int D, int dtype, void* stream);
+
+/* ----------------------------------------------------------- masked softmax
+ * P[z,r,:] = softmax_c( scale*S[z,r,c] + term ) with dropout on P.
+ *   mode 0 (DualMultiAttention, layers.py:346-357): z=(b,h);
+ *          term = (1 - rmask[b,r]*cmask[b,c]) * -1e30
+ *   mode 1 (TopSelfAttention2 float key_padding_mask, layers.py:573): z=(t,h);
+ *          term = cmask[c*cm_stride + t]   (ADDED, +1 for valid keys)
+ * S: fp32 [Z,R,ldS]; P: dtype [Z,R,ldP] (columns >= C are zero filled up to ldP). */
+int vmr_softmax_fwd(const float* S, void* P, void* Pkeep /*nullable: pre-dropout probs*/,
+                    const float* rmask, const float* cmask,
+                    int mode, int Z, int H, int R, int C, int ldS, int ldP, int cm_stride,
+                    float scale, int dtype, float drop_p, uint32_t drop_seed,
+                    const uint32_t* drop_step, void* stream);
+/* dS = scale * Pk*(dP' - sum_c dP'*Pk) with dP' = dropout-mask(dP) regenerated
+ * from the seed; P here is the PRE-dropout probability (Pkeep of the forward,
+ * or its P when drop_p == 0). dP: fp32 [Z,R,ldS]; dS: dtype [Z,R,ldP] (pad columns zeroed). */
+int vmr_softmax_bwd(const float* dP, const void* P, void* dS /*dtype, ld = ldP*/, int Z, int R, int C, int ldS,
+                    int ldP, float scale, int dtype, float drop_p, uint32_t drop_seed,
+                    const uint32_t* drop_step, void* stream);
+
+/* ------------------------------------------------------------------ losses
+ * lossfun_loc (models/loss.py:43-54): mean_b( -sum_t y[b,t]*log_softmax(z[b,:])[t] ),
+ * start + end in one launch. loss: fp32[1] (accumulated, caller zeroes). */
+int vmr_soft_ce_fwd(const float* zs, const float* ze, const float* ys, const float* ye,
+                    float* loss, float* lse /*[2,B]*/, int B, int T, void* stream);
+int vmr_soft_ce_bwd(const float* zs, const float* ze, const float* ys, const float* ye,
+                    const float* lse, const float* dloss, float* dzs, float* dze, int B, int T,
+                    void* stream);
+/* ------------------------------------------------------------- elementwise */
+/* dst[r,0:cols] = dropout(cast(src[r,0:cols])), dst[r,cols:ld_dst] = 0.  Used for
+ * the fp32 -> compute-dtype copy of the [B,T,V] video features (with the input
+ * dropout of VisualProjection, layers.py:120) and of weights whose K is padded
+ * to a multiple of 8 (V=500 -> 504) so the GEMM keeps 16-byte loads. */
+int vmr_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t rows, int cols,
+             int64_t ld_src, int64_t ld_dst, float drop_p, uint32_t drop_seed,
+             const uint32_t* drop_step, void* stream);
+/* Backward of the pointwise-conv epilogue (layers.py:133-146, 288-296):
+ *  mode 0: db[c] += sum_rows dy[r,c]                       (bias gradient only)
+ *  mode 1: dz = dy*scale*(h > 0), db += colsum(dz)         (ReLU [+dropout]; h = saved
+ *          post-dropout ReLU output, scale = 1/(1-p))
+ *  mode 2: dz = dy*scale*keep(seed, r*D+c), db += colsum(dz) (dropout without ReLU; the mask
+ *          is regenerated from the seed the forward GEMM epilogue used)
+ * db may be NULL in modes 1/2. */
+int vmr_relu_bwd_bias(int mode, const void* dy, const void* h, void* dz, float* db, int64_t rows,
+                      int D, int64_t ld, float scale, int dtype, float drop_p, uint32_t drop_seed,
+                      const uint32_t* drop_step, void* stream);
+/* dropout mask materialisation (tests): m[i] = keep(seed,i) ? 1/(1-p) : 0 */
+int vmr_dropout_mask(float* m, int64_t n, float drop_p, uint32_t seed, void* stream);
+
+/* --------------------------------------------------------------- optimizer
+ * fused AdamW over a flat fp32 parameter arena (utils/utils.py:87-97:
+ * AdamW, weight_decay 0.01 except names containing bias/layer_norm) with the
+ * clip_grad_norm_ scale (main.py:95) folded in; also refreshes the bf16
+ * compute copy of the weights.  decay: per-element 0/1 mask as uint8. */
+int vmr_sumsq(const float* g, float* out /*[1], accumulated*/, int64_t n, void* stream);
+int vmr_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay, void* p_bf16,
+              const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
+              float wd, int step, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,451 @@
+"""MI355X-native SeqPAN: the reference's model / engine surface
+(`SeqPAN(configs, word_vectors)`, `forward(word_ids, char_ids, vfeat_in, vmask,
+tmask)`, `train_engine_SeqPAN`, `infer_SeqPAN`; reference models/SeqPAN.py:10-192)
+over hand-written HIP kernels (vmrframe_amd/csrc, C ABI in include/vmr_hip.h).
+
+Design differences from the reference (same numbers, different machine mapping):
+  * parameters live under the reference's 192 state_dict names, but the forward
+    is one flat program over a PACKED token matrix [B*T video rows | B*L query
+    rows]: modules whose weights are shared between the two streams (the
+    feature encoder, models/SeqPAN.py:59-60; both directions of a dual block,
+    :64-70) run ONE GEMM over all tokens instead of two;
+  * projections that share an input are one GEMM over concatenated weights
+    (query|f_key|f_value, t_key|t_value, bilinear_1|bilinear_2);
+  * BiLinear's dense_1(a)+dense_1(b) (models/layers.py:257-263) is dense_1(a+b)
+    with bias 2*b+bias_value;
+  * bias / ReLU / dropout / residual / mask live in the GEMM epilogue; LayerNorm
+    is fused with the depthwise conv; dropout masks are counter-based and
+    regenerated in the backward instead of stored.
+There is NO CPU fallback: tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import math
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
+
+NEG = -1e30  # reference models/layers.py:9
+
+
+def _cfg_get(obj, name, default=None):
+    try:
+        return getattr(obj, name)
+    except (AttributeError, KeyError):
+        try:
+            return obj[name]
+        except (KeyError, TypeError, IndexError):
+            return default
+
+
+# ---------------------------------------------------------------------------
+# parameter inventory: the reference's 192 state_dict entries
+# ---------------------------------------------------------------------------
+def seqpan_param_shapes(D, V, vlen, num_words, num_chars, word_dim=300, char_dim=100):
+    S = OrderedDict()
+
+    def conv1d(p, cin, cout):
+        S[p + ".conv1d.weight"] = (cout, cin, 1)
+        S[p + ".conv1d.bias"] = (cout,)
+
+    def ln(p):
+        S[p + ".weight"] = (D,)
+        S[p + ".bias"] = (D,)
+
+    def conv_block(p):
+        for l in range(4):
+            S[f"{p}.depthwise_separable_conv.{l}.0.weight"] = (D, 1, 7)
+            S[f"{p}.depthwise_separable_conv.{l}.1.weight"] = (D, D, 1)
+            S[f"{p}.depthwise_separable_conv.{l}.1.bias"] = (D,)
+        for l in range(4):
+            ln(f"{p}.layer_norms.{l}")
+
+    S["label_embs"] = (D, 4)
+    S["text_encoder.word_emb.pad_vec"] = (1, word_dim)
+    S["text_encoder.word_emb.unk_vec"] = (1, word_dim)
+    S["text_encoder.word_emb.glove_vec"] = (num_words - 2, word_dim)
+    S["text_encoder.char_emb.char_emb.weight"] = (num_chars, char_dim)
+    for i in range(4):
+        S[f"text_encoder.char_emb.char_convs.{i}.0.weight"] = (10 * (i + 1), char_dim, 1, i + 1)
+        S[f"text_encoder.char_emb.char_convs.{i}.0.bias"] = (10 * (i + 1),)
+    conv1d("text_encoder.query_conv1d", word_dim + 100, D)
+    ln("text_encoder.q_layer_norm")
+    conv1d("video_affine.video_conv1d", V, D)
+    ln("video_affine.v_layer_norm")
+    S["vfeat_encoder.pos_embedding.position_embeddings.weight"] = (vlen, D)
+    conv_block("vfeat_encoder.conv_block")
+    for blk in (1, 2):
+        p = f"dual_attention_block_{blk}"
+        ln(p + ".layer_norm_1"); ln(p + ".layer_norm_2"); ln(p + ".layer_norm_t")
+        conv1d(p + ".dense_1", D, D); conv1d(p + ".dense_2", D, D)
+        m = p + ".dual_multihead_attention"
+        for nm in ("query", "f_key", "f_value", "t_key", "t_value", "s_dense", "x_dense", "s_gate", "x_gate",
+                   "guided_dense"):
+            conv1d(f"{m}.{nm}", D, D)
+        for b in (1, 2):
+            S[f"{m}.bilinear_{b}.bias_value"] = (D,)
+            conv1d(f"{m}.bilinear_{b}.dense_1", D, D)
+            conv1d(f"{m}.bilinear_{b}.dense_2", D, D)
+        ln(m + ".layer_norm1"); ln(m + ".layer_norm2")
+        conv1d(m + ".out_layer", D, D)
+    for p in ("q2v_attn", "v2q_attn"):
+        S[p + ".w4C"] = (D, 1)
+        S[p + ".w4Q"] = (D, 1)
+        S[p + ".w4mlu"] = (1, 1, D)
+        conv1d(p + ".cqa_linear", 4 * D, D)
+    S["cq_cat.weighted_pool.weight"] = (D, 1)
+    conv1d("cq_cat.conv1d", 2 * D, D)
+    conv1d("match_conv1d", D, 4)
+    fe = "predictor.feature_encoder"
+    S[fe + ".pos_embedding.position_embeddings.weight"] = (vlen, D)
+    conv_block(fe + ".conv_block")
+    ln(fe + ".layer_norm_1"); ln(fe + ".layer_norm_2")
+    S[fe + ".top_self_attention.selfattn.in_proj_weight"] = (3 * D, D)
+    S[fe + ".top_self_attention.selfattn.in_proj_bias"] = (3 * D,)
+    S[fe + ".top_self_attention.selfattn.out_proj.weight"] = (D, D)
+    S[fe + ".top_self_attention.selfattn.out_proj.bias"] = (D,)
+    conv1d(fe + ".dense", D, D)
+    ln("predictor.start_layer_norm"); ln("predictor.end_layer_norm")
+    conv1d("predictor.start_hidden", 2 * D, D); conv1d("predictor.end_hidden", 2 * D, D)
+    conv1d("predictor.start_dense", D, 1); conv1d("predictor.end_dense", D, 1)
+    return S
+
+
+FROZEN = ("text_encoder.word_emb.pad_vec", "text_encoder.word_emb.glove_vec")
+
+
+class _Node(nn.Module):
+    """Bare container: the module tree exists only to reproduce the reference's
+    parameter names (state_dict keys, named_parameters for the decay groups)."""
+
+
+def _init_param(name: str, shape, gen: torch.Generator) -> torch.Tensor:
+    """PyTorch-default initialisers of the reference's layers."""
+    t = torch.empty(shape, dtype=torch.float32)
+
+    def kaiming_u(w):  # nn.Conv*/Linear default: kaiming_uniform_(a=sqrt(5)) => U(+-1/sqrt(fan_in))
+        fan_in = int(np.prod(w.shape[1:]))
+        bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+        return w.uniform_(-bound, bound, generator=gen)
+
+    def xavier_u(w, fan_in, fan_out):
+        bound = math.sqrt(6.0 / (fan_in + fan_out))
+        return w.uniform_(-bound, bound, generator=gen)
+
+    if name.endswith("pad_vec") or name.endswith("bias_value"):
+        return t.zero_()
+    if "layer_norm" in name or "layer_norms" in name:
+        return t.fill_(1.0) if name.endswith("weight") else t.zero_()
+    if name.endswith("unk_vec"):
+        return xavier_u(t, shape[1], shape[0])
+    if name.endswith("position_embeddings.weight"):
+        return t.normal_(0, 1, generator=gen)
+    if name.endswith("char_emb.weight"):
+        t.normal_(0, 1, generator=gen)
+        t[0].zero_()
+        return t
+    if name == "label_embs":
+        a = torch.empty(shape).normal_(0, 1, generator=gen)
+        q, r = torch.linalg.qr(a)
+        return (q * torch.sign(torch.diagonal(r))[None, :]).contiguous()
+    if name.endswith("w4C") or name.endswith("w4Q") or name.endswith("weighted_pool.weight"):
+        return xavier_u(t, shape[1], shape[0])
+    if name.endswith("w4mlu"):
+        return xavier_u(t, shape[1] * shape[2], shape[0] * shape[2])
+    if name.endswith("in_proj_weight"):
+        return xavier_u(t, shape[1], shape[0])
+    if name.endswith("in_proj_bias") or name.endswith("out_proj.bias"):
+        return t.zero_()
+    if name.endswith(".bias"):  # conv bias: U(+-1/sqrt(fan_in)); fan_in from the sibling weight
+        return t  # filled by the caller (needs fan_in)
+    return kaiming_u(t)
+
+
+class SeqPAN(nn.Module):
+    """Drop-in for reference models/SeqPAN.py:10-95 (same constructor, forward
+    signature, output dict and state_dict keys)."""
+
+    def __init__(self, configs, word_vectors):
+        super().__init__()
+        self.configs = configs
+        m = configs.model
+        self.dim, self.vdim, self.vlen = int(m.dim), int(m.vdim), int(m.vlen)
+        self.num_heads = int(_cfg_get(m, "num_heads", 4))
+        self.droprate = float(_cfg_get(m, "droprate", 0.0))
+        self.word_dim, self.char_dim = int(_cfg_get(m, "word_dim", 300)), int(_cfg_get(m, "char_dim", 100))
+        cd = _cfg_get(m, "compute_dtype", "bf16")
+        self.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32}[str(cd)]
+        assert self.dim % 8 == 0 and self.dim % self.num_heads == 0
+        shapes = seqpan_param_shapes(self.dim, self.vdim, self.vlen, int(configs.num_words), int(configs.num_chars),
+                                     self.word_dim, self.char_dim)
+        gen = torch.Generator().manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF)
+        self._pnames = []
+        for name, shp in shapes.items():
+            t = _init_param(name, shp, gen)
+            if name.endswith(".bias") and "layer_norm" not in name and not name.endswith("out_proj.bias"):
+                wshape = shapes.get(name[:-4] + "weight")
+                fan_in = int(np.prod(wshape[1:])) if wshape else shp[0]
+                t.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in), generator=gen)
+            if name.endswith("glove_vec"):
+                if word_vectors is None:
+                    raise ValueError("SeqPAN needs pretrained word_vectors (reference layers.py:31-37)")
+                t = torch.as_tensor(np.asarray(word_vectors), dtype=torch.float32).clone()
+                assert tuple(t.shape) == tuple(shp), (t.shape, shp)
+            self._register(name, nn.Parameter(t.contiguous(), requires_grad=name not in FROZEN))
+            self._pnames.append(name)
+        self._cache = ops.WeightCache()
+        self._seed_calls = 0
+        self.gumbel_override = None   # tests: inject F.gumbel_softmax's noise
+        self.drop_step = None         # optional device int32[1] mixed into the dropout seeds
+        self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
+        self.last_drop_sites = []
+
+    # -- plumbing -------------------------------------------------------------
+    def _register(self, dotted, param):
+        mod = self
+        parts = dotted.split(".")
+        for part in parts[:-1]:
+            if part not in mod._modules:
+                mod.add_module(part, _Node())
+            mod = mod._modules[part]
+        mod.register_parameter(parts[-1], param)
+
+    def P(self, name):
+        mod = self
+        parts = name.split(".")
+        for part in parts[:-1]:
+            mod = mod._modules[part]
+        return mod._parameters[parts[-1]]
+
+    def _lin(self, x, prefix, **kw):
+        return ops.linear(x, self.P(prefix + ".conv1d.weight"), self.P(prefix + ".conv1d.bias"), self._cache, **kw)
+
+    def _ln(self, x, prefix, eps, **kw):
+        return ops.layer_norm(x, self.P(prefix + ".weight"), self.P(prefix + ".bias"), eps, self._cache, **kw)
+
+    def _conv_block(self, x, prefix, segs, dc):
+        """DepthwiseSeparableConvBlock (reference layers.py:139-148): 4 x {LN -> dw conv k7 ->
+        pw conv + bias -> ReLU -> dropout -> + residual}; LN+dw is one kernel, the rest is the
+        GEMM epilogue."""
+        for l in range(4):
+            u = ops.ln_dwconv(x, self.P(f"{prefix}.layer_norms.{l}.weight"), self.P(f"{prefix}.layer_norms.{l}.bias"),
+                              self.P(f"{prefix}.depthwise_separable_conv.{l}.0.weight"), 1e-6, segs)
+            x = ops.linear(u, self.P(f"{prefix}.depthwise_separable_conv.{l}.1.weight"),
+                           self.P(f"{prefix}.depthwise_separable_conv.{l}.1.bias"), self._cache,
+                           relu=True, drop=dc.next(f"{prefix}.{l}"), residual=x)
+        return x
+
+    # -- stages ---------------------------------------------------------------
+    def _text_embedding(self, word_ids, char_ids, dc):
+        """Embedding.forward (reference layers.py:87-93): word gather + char CNN are
+        index / window glue in torch; every contraction runs on the HIP GEMM."""
+        cdt = self.compute_dtype
+        B, Lq = word_ids.shape
+        pre = "text_encoder."
+        table = torch.cat([self.P(pre + "word_emb.pad_vec"), self.P(pre + "word_emb.unk_vec"),
+                           self.P(pre + "word_emb.glove_vec")], 0)
+        wemb = F.embedding(word_ids, table, padding_idx=0)
+        cemb = F.embedding(char_ids, self.P(pre + "char_emb.char_emb.weight"), padding_idx=0)   # [B,L,C,cd]
+        if dc.p > 0:
+            wemb = F.dropout(wemb, dc.p, True)
+            cemb = F.dropout(cemb, dc.p, True)
+        C = cemb.shape[2]
+        feats = [ops.to_dtype(wemb.reshape(B * Lq, -1), cdt)]
+        for i in range(4):
+            k = i + 1
+            win = cemb.unfold(2, k, 1).reshape(B * Lq * (C - k + 1), self.char_dim * k)   # (cd, k) order == weight
+            y = ops.linear(ops.to_dtype(win, cdt, pad8=True), self.P(f"{pre}char_emb.char_convs.{i}.0.weight"),
+                           self.P(f"{pre}char_emb.char_convs.{i}.0.bias"), self._cache, relu=True)
+            feats.append(y.reshape(B * Lq, C - k + 1, -1).amax(dim=1))
+        emb = torch.cat(feats, dim=1)                                                    # [B*L, 400]
+        return self._lin(emb, pre + "query_conv1d")
+
+    def _dual_block(self, X, prefix, vmask, tmask, rowmask, B, T, Lq, dc):
+        """DualAttentionBlock for both directions on packed tokens (reference layers.py:281-381)."""
+        D, H, c = self.dim, self.num_heads, self._cache
+        m = prefix + ".dual_multihead_attention"
+        W = lambda n: self.P(f"{m}.{n}.conv1d.weight")
+        Bv = lambda n: self.P(f"{m}.{n}.conv1d.bias")
+        n1 = self._ln(X, prefix + ".layer_norm_1", 1e-6, drop=dc.next(prefix + ".ln1"))
+        nt = self._ln(X, prefix + ".layer_norm_t", 1e-6)
+        qkv = ops.linear(n1, [W("query"), W("f_key"), W("f_value")],
+                         torch.cat([Bv("query"), Bv("f_key"), Bv("f_value")]), c)
+        kv = ops.linear(nt, [W("t_key"), W("t_value")], torch.cat([Bv("t_key"), Bv("t_value")]), c)
+        so, xo = ops.dual_attention(qkv, kv, vmask, tmask, B, T, Lq, H,
+                                    [dc.next(prefix + f".attn{i}") for i in range(4)])
+        sval = ops.linear(so, W("s_dense"), Bv("s_dense"), c)
+        xval = ops.linear(xo, W("x_dense"), Bv("x_dense"), c)
+        sscore = ops.linear(sval, W("s_gate"), Bv("s_gate"), c)
+        xscore = ops.linear(xval, W("x_gate"), Bv("x_gate"), c)
+        gated = sscore * xval + xscore * sval                                   # cross gating (:374)
+        gd = ops.linear(gated, W("guided_dense"), Bv("guided_dense"), c)
+        # BiLinear x2: dense_1(a)+dense_1(b)+bias_value == dense_1(a+b) + 2*b1 + bias_value (:257-263)
+        b1, b2 = m + ".bilinear_1", m + ".bilinear_2"
+        bias = torch.cat([2.0 * self.P(b1 + ".dense_1.conv1d.bias") + self.P(b1 + ".bias_value"),
+                          2.0 * self.P(b2 + ".dense_1.conv1d.bias") + self.P(b2 + ".bias_value")])
+        sv = ops.linear(n1 + gd, [self.P(b1 + ".dense_1.conv1d.weight"), self.P(b2 + ".dense_1.conv1d.weight")],
+                        bias, c)
+        scores, values = sv[:, :D], sv[:, D:]
+        out = torch.sigmoid(scores + NEG * (1.0 - rowmask)) * values            # (:380)
+        o1 = self._lin(out, prefix + ".dense_1", drop=dc.next(prefix + ".d1"), residual=X)
+        o2 = self._ln(o1, prefix + ".layer_norm_2", 1e-6, drop=dc.next(prefix + ".ln2"))
+        return self._lin(o2, prefix + ".dense_2", drop=dc.next(prefix + ".d2"), residual=o1)
+
+    def _cq_attention(self, prefix, ctx, qry, cmask, qmask, dc):
+        """CQAttention.forward (reference layers.py:417-437).  The rank-1 terms of the
+        trilinear score are folded onto the SHORTER stream so the long [B,T,D] tensor is read
+        once by the MFMA GEMM and never by an elementwise pass:
+          S = C.(Q*w4mlu + w4C)^T + (Q.w4Q)^T        (query stream short)
+            = (C*w4mlu + w4Q).Q^T + C.w4C            (context stream short)
+        and q2c is re-associated as S_.(S_t^T.C) (no [Lc,Lc] intermediate)."""
+        B, Lc, D = ctx.shape
+        Lq = qry.shape[1]
+        cdt = ctx.dtype
+        w4C, w4Q, w4mlu = self.P(prefix + ".w4C"), self.P(prefix + ".w4Q"), self.P(prefix + ".w4mlu")
+        cd = ops.dropout(ctx, dc.next(prefix + ".c"))
+        qd = ops.dropout(qry, dc.next(prefix + ".q"))
+        if Lq <= Lc:
+            qf = qd.float()
+            bop = (qf * w4mlu + w4C.view(1, 1, D)).to(cdt)
+            S = ops.bmm(cd, bop, 0, 0, out_f32=True) + (qf @ w4Q).transpose(1, 2)
+        else:
+            cf = cd.float()
+            aop = (cf * w4mlu + w4Q.view(1, 1, D)).to(cdt)
+            S = ops.bmm(aop, qd, 0, 0, out_f32=True) + (cf @ w4C)
+        S_ = torch.softmax(S + NEG * (1.0 - qmask[:, None, :]), dim=2)
+        S_t = torch.softmax(S + NEG * (1.0 - cmask[:, :, None]), dim=1)
+        pad = (-Lq) % 8
+        S_p = F.pad(S_.to(cdt), (0, pad))[..., :Lq]        # 16-byte aligned rows for the GEMM loads
+        S_tp = F.pad(S_t.to(cdt), (0, pad))[..., :Lq]
+        c2q = ops.bmm(S_p, qry, 0, 1)                      # [B,Lc,D]
+        mid = ops.bmm(S_tp, ctx, 1, 1)                     # S_t^T . C   [B,Lq,D]
+        q2c = ops.bmm(S_p, mid, 0, 1)                      # [B,Lc,D]
+        cat4 = torch.cat([ctx, c2q, ctx * c2q, ctx * q2c], dim=2).reshape(B * Lc, 4 * D)
+        return self._lin(cat4, prefix + ".cqa_linear")
+
+    def _predict_encoder(self, x, vmask, B, T, dc, tag):
+        """FeatureEncoderPredict.forward (reference layers.py:626-639)."""
+        fe = "predictor.feature_encoder"
+        D, c = self.dim, self._cache
+        pos = ops.to_dtype(self.P(fe + ".pos_embedding.position_embeddings.weight")[:T], x.dtype)
+        feat = (x.view(B, T, D) + pos[:T].view(1, T, D)).reshape(B * T, D)
+        feat = self._conv_block(feat, fe + ".conv_block", [(B, T)], dc)
+        o = self._ln(feat, fe + ".layer_norm_1", 1e-5, drop=dc.next(tag + ".ln1"))
+        att = fe + ".top_self_attention.selfattn"
+        qkv = ops.linear(o, self.P(att + ".in_proj_weight"), self.P(att + ".in_proj_bias"), c)
+        ctxv = ops.batch_axis_attention(qkv, vmask, B, T, 4, dc.next(tag + ".attn"))
+        res = ops.linear(ctxv, self.P(att + ".out_proj.weight"), self.P(att + ".out_proj.bias"), c,
+                         drop=dc.next(tag + ".att"), residual=feat)
+        o = self._ln(res, fe + ".layer_norm_2", 1e-5, drop=dc.next(tag + ".ln2"))
+        return self._lin(o, fe + ".dense", drop=dc.next(tag + ".dense"), residual=res)
+
+    # -- forward --------------------------------------------------------------
+    def forward(self, word_ids, char_ids, vfeat_in, vmask, tmask):
+        L.require_gpu(word_ids, char_ids, vfeat_in, vmask, tmask)
+        torch.cuda.synchronize()          # reference models/SeqPAN.py:51-52 self-timing
+        start = time.time()
+        cdt, D = self.compute_dtype, self.dim
+        B, T = vmask.shape
+        Lq = tmask.shape[1]
+        Nv, Nt = B * T, B * Lq
+        vmask, tmask = vmask.float().contiguous(), tmask.float().contiguous()
+        self._seed_calls += 1
+        dc = ops.DropCtx(self.droprate, self.training, self.base_seed + 7919 * self._seed_calls, self.drop_step)
+        segs = [(B, T), (B, Lq)]
+        pos_p = self.P("vfeat_encoder.pos_embedding.position_embeddings.weight")
+
+        # text / video projections -> LayerNorm (+ positional table) -> packed tokens
+        tq = self._text_embedding(word_ids, char_ids, dc)
+        vx = ops.cast_pad(vfeat_in.reshape(Nv, -1).float(), cdt, dc.next("video.in"))
+        vq = self._lin(vx, "video_affine.video_conv1d")
+        xv = self._ln(vq, "video_affine.v_layer_norm", 1e-6, pos=pos_p, S=T)
+        xt = self._ln(tq, "text_encoder.q_layer_norm", 1e-6, pos=pos_p, S=Lq)
+        X = torch.cat([xv, xt], 0)
+        # the SAME encoder on both streams (reference models/SeqPAN.py:59-60)
+        X = self._conv_block(X, "vfeat_encoder.conv_block", segs, dc)
+        rowmask = torch.cat([vmask.reshape(-1), tmask.reshape(-1)])[:, None].to(cdt)
+        for blk in (1, 2):
+            X = self._dual_block(X, f"dual_attention_block_{blk}", vmask, tmask, rowmask, B, T, Lq, dc)
+        V3, T3 = X[:Nv].view(B, T, D), X[Nv:].view(B, Lq, D)
+        t2v = self._cq_attention("q2v_attn", V3, T3, vmask, tmask, dc)            # [Nv, D]
+        v2t = self._cq_attention("v2q_attn", T3, V3, tmask, vmask, dc)            # [Nt, D]
+        # CQConcatenate (reference layers.py:462-468)
+        v2t3 = v2t.view(B, Lq, D).float()
+        alpha = torch.softmax(v2t3 @ self.P("cq_cat.weighted_pool.weight") + NEG * (1.0 - tmask[:, :, None]), dim=1)
+        pooled = (v2t3 * alpha).sum(1).to(cdt)                                    # [B, D]
+        cat2 = torch.cat([t2v.view(B, T, D), pooled[:, None, :].expand(B, T, D)], dim=2).reshape(Nv, 2 * D)
+        fuse = self._lin(cat2, "cq_cat.conv1d")
+        # match head (reference models/SeqPAN.py:78-82)
+        mlogits = self._lin(fuse, "match_conv1d").float().reshape(B, T, 4)
+        if self.gumbel_override is not None:
+            g = self.gumbel_override.to(mlogits.device)
+        else:
+            g = -torch.empty_like(mlogits).exponential_().log()
+        match_score = torch.softmax((mlogits + g) / 0.3, dim=-1)
+        ms = F.pad(match_score.reshape(Nv, 4), (0, 4)).to(cdt)                    # K padded 4 -> 8
+        # fuse2 = (fuse + match_score . label_embs^T) * vmask : one GEMM epilogue
+        fuse2 = ops.linear(ms, self.P("label_embs"), None, self._cache, residual=fuse,
+                           rowscale=vmask.reshape(-1))
+        # predictor (reference layers.py:659-671)
+        sfeat = self._predict_encoder(fuse2, vmask, B, T, dc, "pred.s")
+        efeat = self._predict_encoder(sfeat, vmask, B, T, dc, "pred.e")
+        sn = self._ln(sfeat, "predictor.start_layer_norm", 1e-6)
+        en = self._ln(efeat, "predictor.end_layer_norm", 1e-6)
+        sh = self._lin(torch.cat([sn, fuse2], 1), "predictor.start_hidden")
+        eh = self._lin(torch.cat([en, fuse2], 1), "predictor.end_hidden")
+        slogits = self._lin(sh, "predictor.start_dense").float().reshape(B, T)
+        elogits = self._lin(eh, "predictor.end_dense").float().reshape(B, T)
+        self.last_drop_sites = dc.sites
+
+        torch.cuda.synchronize()
+        consume_time = time.time() - start
+        return {"slogits": slogits, "elogits": elogits, "vmask": vmask, "match_score": match_score,
+                "label_embs": self.P("label_embs"), "consume_time": consume_time}
+
+
+# ---------------------------------------------------------------------------
+# losses + engine glue (reference models/loss.py:24-54, models/SeqPAN.py:171-192)
+# ---------------------------------------------------------------------------
+def lossfun_loc(start_logits, end_logits, s_labels, e_labels, vmask=None):
+    """Boundary-label CE on the HIP kernel (reference models/loss.py:43-54)."""
+    return ops.soft_ce(start_logits, end_logits, s_labels, e_labels)
+
+
+def lossfun_match(m_probs, label_embs, m_labels, vmask):
+    """reference models/loss.py:24-41 (tiny: [B,T,4] and a 4x4 Gram matrix)."""
+    onehot = F.one_hot(m_labels, 4).float()
+    per = -(onehot * m_probs).sum(-1)
+    loss = (per * vmask).sum() / (vmask.sum() + 1e-12)
+    gram = label_embs.t() @ label_embs * (1.0 - torch.eye(4, device=label_embs.device))
+    return loss + torch.norm(gram, p=2)
+
+
+def train_engine_SeqPAN(model, data, configs, runtype):
+    data = {k: v.to(configs.device) for k, v in data.items()}
+    output = model(data["words_ids"], data["char_ids"], data["vfeats"], data["vmasks"], data["tmasks"])
+    lab = data["label1ds"]
+    loc_loss = lossfun_loc(output["slogits"], output["elogits"], lab[:, 0, :], lab[:, 1, :], data["vmasks"])
+    m_loss = lossfun_match(output["match_score"], output["label_embs"], data["NER_labels"], data["vmasks"].float())
+    return loc_loss + m_loss, output
+
+
+def infer_basic(start_logits, end_logits, vmask):
+    """reference utils/engine.py:28-44."""
+    sp = torch.softmax(start_logits + NEG * (1.0 - vmask), dim=1)
+    ep = torch.softmax(end_logits + NEG * (1.0 - vmask), dim=1)
+    outer = torch.triu(sp[:, :, None] * ep[:, None, :], diagonal=0)
+    sidx = outer.max(dim=2).values.max(dim=1).indices
+    eidx = outer.max(dim=1).values.max(dim=1).indices
+    n = vmask.sum(dim=1)
+    return np.stack([(sidx / n).cpu().numpy(), (eidx / n).cpu().numpy()]).T
+
+
+def infer_SeqPAN(output, configs):
+    return infer_basic(output["slogits"], output["elogits"], output["vmask"])

@@ -1,0 +1,10 @@
+"""vmrframe_amd -- MI355X-native (gfx950) implementation of the SeqPAN
+cross-modal matching hot path of renjie-liang/VMRFrame.
+
+Exports mirror what the reference's `main.py` resolves by name after
+`from models import *` (reference main.py:21,87,99; utils/DataLoader.py:5-6).
+"""
+from .SeqPAN import (SeqPAN, infer_basic, infer_SeqPAN, lossfun_loc, lossfun_match,  # noqa: F401
+                     train_engine_SeqPAN)
+
+__all__ = ["SeqPAN", "train_engine_SeqPAN", "infer_SeqPAN", "infer_basic", "lossfun_loc", "lossfun_match"]

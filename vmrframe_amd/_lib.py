@@ -1,0 +1,101 @@
+"""ctypes binding of libvmr_hip.so (the C ABI declared in include/vmr_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+fails, a RuntimeError is raised.  torch is imported first so the library binds
+to the HIP runtime already loaded by PyTorch-ROCm (same SONAME), which makes
+torch's streams and device pointers directly usable by the kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL: loads libamdhip64)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvmr_hip.so")
+
+F32, BF16 = 0, 1
+
+EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_AUX, EPI_OUT_F32, EPI_ACCUM, EPI_ROWSCALE = \
+    1, 2, 4, 8, 16, 32, 64, 128
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("bias", C.c_void_p), ("residual", C.c_void_p), ("aux", C.c_void_p),
+                ("rowscale", C.c_void_p),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("transA", C.c_int32), ("transB", C.c_int32),
+                ("dtype", C.c_int32), ("flags", C.c_int32), ("alpha", C.c_float),
+                ("Z1", C.c_int32), ("Z2", C.c_int32),
+                ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64),
+                ("sC1", C.c_int64), ("sC2", C.c_int64),
+                ("splitk", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
+                ("_pad", C.c_uint32), ("drop_step", C.c_void_p)]
+
+
+_lib = None
+
+# name -> argtypes (restype is always int unless noted); mirrors include/vmr_hip.h
+_P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+SIGNATURES = {
+    "vmr_gemm": [C.POINTER(GemmDesc), _P],
+    "vmr_layernorm_fwd": [_P, _P, _P, _F, _P, _I, _P, _P, _P, _L, _I, _I, _F, _U, _P, _P],
+    "vmr_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _U, _P, _P],
+    "vmr_ln_dwconv_fwd": [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vmr_dwconv_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vmr_softmax_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _F, _U, _P, _P],
+    "vmr_softmax_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U, _P, _P],
+    "vmr_soft_ce_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "vmr_soft_ce_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "vmr_cast": [_P, _I, _P, _I, _L, _I, _L, _L, _F, _U, _P, _P],
+    "vmr_relu_bwd_bias": [_I, _P, _P, _P, _P, _L, _I, _L, _F, _I, _F, _U, _P, _P],
+    "vmr_dropout_mask": [_P, _L, _F, _U, _P],
+    "vmr_sumsq": [_P, _P, _L, _P],
+    "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _L, _P],
+}
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). vmrframe_amd has no non-HIP fallback.")
+        h = C.CDLL(LIB_PATH)
+        h.vmr_version.restype = C.c_int
+        h.vmr_last_error.restype = C.c_char_p
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the .so lacks a declared symbol
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().vmr_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("vmrframe_amd ops run only on a HIP device (no CPU fallback); "
+                               "got a tensor on %s" % t.device)

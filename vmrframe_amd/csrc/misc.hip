@@ -1,0 +1,305 @@
+// misc.hip -- streaming helpers of the SeqPAN path: dtype casts with padding and
+// input dropout, ReLU/dropout backward with the fused bias reduction, column
+// sums (bias gradients), the boundary-label cross-entropy (reference
+// models/loss.py:43-54) and the fused AdamW / grad-norm optimizer step
+// (utils/utils.py:87-97, main.py:95).  All HBM-bound: 16-B accesses, grid-stride.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------- cast
+// dst[r, 0:cols] = drop(src[r, 0:cols]); dst[r, cols:ld_dst] = 0
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t rows,
+                                                   int cols, int64_t ld_src, int64_t ld_dst, float drop_p,
+                                                   uint32_t seed0, const uint32_t* __restrict__ step) {
+  const uint32_t seed = vmr_seed(seed0, step);
+  const uint32_t thresh = vmr_drop_thresh(drop_p);
+  const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const int64_t total = rows * ld_dst;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / ld_dst;
+    const int c = (int)(i - r * ld_dst);
+    float v = 0.f;
+    if (c < cols) {
+      v = to_f<TS>(src[r * ld_src + c]);
+      if (drop_p > 0.f) v = vmr_keep(seed, (uint64_t)r * cols + c, thresh) ? v * dscale : 0.f;
+    }
+    dst[i] = from_f<TD>(v);
+  }
+}
+
+// ------------------------------------------------ relu/dropout bwd + bias grad
+// MODE 0: db[c] += sum_r dy[r,c]                                   (plain bias)
+// MODE 1: dz = dy * scale * (h > 0)            ; db += colsum(dz)  (ReLU [+dropout]: h is the
+//         saved post-dropout ReLU output, so h > 0 <=> positive AND kept)
+// MODE 2: dz = dy * scale * keep(seed, r*D+c)  ; db += colsum(dz)  (dropout without ReLU)
+// block = 256 threads = 32 column-groups (8 cols) x 8 row lanes; columns tile = 256
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const T* __restrict__ dy, const T* __restrict__ h,
+                                                            T* __restrict__ dz, float* __restrict__ db, int64_t rows,
+                                                            int D, int64_t ld, float scale, int rows_per_block,
+                                                            float drop_p, uint32_t seed0,
+                                                            const uint32_t* __restrict__ step) {
+  __shared__ float red[8][256];
+  const uint32_t seed = vmr_seed(seed0, step);
+  const uint32_t thresh = vmr_drop_thresh(drop_p);
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + cg * 8;
+  const int64_t rbeg = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t rend = min(rows, rbeg + rows_per_block);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < D) {
+    for (int64_t r = rbeg + rl; r < rend; r += 8) {
+      float g[8];
+      Vec8<T>::load(dy + r * ld + c0, g);
+      if (MODE == 1) {
+        float hv[8];
+        Vec8<T>::load(h + r * ld + c0, hv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = hv[e] > 0.f ? g[e] * scale : 0.f;
+        Vec8<T>::store(dz + r * ld + c0, g);
+      } else if (MODE == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          g[e] = vmr_keep(seed, (uint64_t)r * D + c0 + e, thresh) ? g[e] * scale : 0.f;
+        Vec8<T>::store(dz + r * ld + c0, g);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += g[e];
+    }
+  }
+  if (!db) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < D) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+    atomicAdd(&db[c], s);
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ m, int64_t n, float drop_p,
+                                                           uint32_t seed) {
+  const uint32_t thresh = vmr_drop_thresh(drop_p);
+  const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    m[i] = (drop_p > 0.f ? vmr_keep(seed, (uint64_t)i, thresh) : true) ? dscale : 0.f;
+}
+
+// -------------------------------------------- boundary-label cross-entropy
+// loss = mean_b( -sum_t ys*log_softmax(zs) ) + same for the end logits.
+// grid = 2*B waves (one wave per (which, b) row); T <= 64*16.
+__global__ __launch_bounds__(256) void soft_ce_fwd_kernel(const float* __restrict__ zs, const float* __restrict__ ze,
+                                                          const float* __restrict__ ys, const float* __restrict__ ye,
+                                                          float* __restrict__ loss, float* __restrict__ lse, int B,
+                                                          int T) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= 2 * B) return;
+  const int which = row / B, b = row - which * B;
+  const float* z = (which ? ze : zs) + (int64_t)b * T;
+  const float* y = (which ? ye : ys) + (int64_t)b * T;
+  float mx = -INFINITY;
+  for (int t = lane; t < T; t += 64) mx = fmaxf(mx, z[t]);
+  mx = wave_max(mx);
+  float se = 0.f, sy = 0.f, syz = 0.f;
+  for (int t = lane; t < T; t += 64) {
+    se += __expf(z[t] - mx);
+    sy += y[t];
+    syz += y[t] * z[t];
+  }
+  se = wave_sum(se); sy = wave_sum(sy); syz = wave_sum(syz);
+  const float l = mx + __logf(se);
+  if (lane == 0) {
+    lse[row] = l;
+    atomicAdd(loss, (l * sy - syz) / (float)B);  // -sum y*(z - lse)
+  }
+}
+
+// dz = dloss/B * (softmax(z)*sum(y) - y)
+__global__ __launch_bounds__(256) void soft_ce_bwd_kernel(const float* __restrict__ zs, const float* __restrict__ ze,
+                                                          const float* __restrict__ ys, const float* __restrict__ ye,
+                                                          const float* __restrict__ lse, const float* __restrict__ dloss,
+                                                          float* __restrict__ dzs, float* __restrict__ dze, int B,
+                                                          int T) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= 2 * B) return;
+  const int which = row / B, b = row - which * B;
+  const float* z = (which ? ze : zs) + (int64_t)b * T;
+  const float* y = (which ? ye : ys) + (int64_t)b * T;
+  float* dz = (which ? dze : dzs) + (int64_t)b * T;
+  float sy = 0.f;
+  for (int t = lane; t < T; t += 64) sy += y[t];
+  sy = wave_sum(sy);
+  const float l = lse[row], g = dloss[0] / (float)B;
+  for (int t = lane; t < T; t += 64) dz[t] = g * (__expf(z[t] - l) * sy - y[t]);
+}
+
+// --------------------------------------------------------------- optimizer
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* __restrict__ out, int64_t n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const int64_t n4 = n >> 2;
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = g4[i];
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// torch.optim.AdamW semantics (decoupled decay, bias correction, eps outside sqrt)
+// with clip_grad_norm_'s scale min(1, max_norm/(norm+1e-6)) folded into the read of g.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    const uint8_t* __restrict__ decay, bf16_t* __restrict__ pb,
+                                                    const float* __restrict__ gnorm_sq, float max_norm, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1,
+                                                    float bc2, int64_t n) {
+  float clip = 1.f;
+  if (gnorm_sq && max_norm > 0.f) {
+    const float nrm = sqrtf(gnorm_sq[0]);
+    clip = fminf(1.f, max_norm / (nrm + 1e-6f));
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * clip;
+    float pi = p[i];
+    if (decay[i]) pi *= 1.f - lr * wd;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+    if (pb) pb[i] = f2bf(pi);
+  }
+}
+
+template <typename TS>
+int launch_cast(const void* src, void* dst, int dst_dtype, int64_t rows, int cols, int64_t ld_src, int64_t ld_dst,
+                float drop_p, uint32_t seed, const uint32_t* step, hipStream_t st) {
+  const int64_t total = rows * ld_dst;
+  const int grid = (int)min((int64_t)8192, (total + 255) / 256);
+  if (dst_dtype == VMR_BF16)
+    hipLaunchKernelGGL((cast_kernel<TS, bf16_t>), dim3(grid), dim3(256), 0, st, (const TS*)src, (bf16_t*)dst, rows, cols,
+                       ld_src, ld_dst, drop_p, seed, step);
+  else
+    hipLaunchKernelGGL((cast_kernel<TS, float>), dim3(grid), dim3(256), 0, st, (const TS*)src, (float*)dst, rows, cols,
+                       ld_src, ld_dst, drop_p, seed, step);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vmr_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t rows, int cols,
+                        int64_t ld_src, int64_t ld_dst, float drop_p, uint32_t drop_seed,
+                        const uint32_t* drop_step, void* stream) {
+  VMR_CHECK(src && dst, "vmr_cast: null pointer");
+  VMR_CHECK(ld_src >= cols && ld_dst >= cols, "vmr_cast: leading dim < cols");
+  if (rows == 0 || ld_dst == 0) return 0;
+  if (src_dtype == VMR_BF16) launch_cast<bf16_t>(src, dst, dst_dtype, rows, cols, ld_src, ld_dst, drop_p, drop_seed, drop_step, (hipStream_t)stream);
+  else launch_cast<float>(src, dst, dst_dtype, rows, cols, ld_src, ld_dst, drop_p, drop_seed, drop_step, (hipStream_t)stream);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+static void launch_rbb(int mode, dim3 grid, hipStream_t st, const void* dy, const void* h, void* dz, float* db,
+                       int64_t rows, int D, int64_t ld, float scale, int rpb, float drop_p, uint32_t seed,
+                       const uint32_t* step) {
+  if (mode == 0)
+    hipLaunchKernelGGL((relu_bwd_bias_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)dy, (const T*)h, (T*)dz, db, rows,
+                       D, ld, scale, rpb, drop_p, seed, step);
+  else if (mode == 1)
+    hipLaunchKernelGGL((relu_bwd_bias_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)dy, (const T*)h, (T*)dz, db, rows,
+                       D, ld, scale, rpb, drop_p, seed, step);
+  else
+    hipLaunchKernelGGL((relu_bwd_bias_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)dy, (const T*)h, (T*)dz, db, rows,
+                       D, ld, scale, rpb, drop_p, seed, step);
+}
+
+extern "C" int vmr_relu_bwd_bias(int mode, const void* dy, const void* h, void* dz, float* db, int64_t rows, int D,
+                                 int64_t ld, float scale, int dtype, float drop_p, uint32_t drop_seed,
+                                 const uint32_t* drop_step, void* stream) {
+  VMR_CHECK(mode >= 0 && mode <= 2, "vmr_relu_bwd_bias: bad mode %d", mode);
+  VMR_CHECK(dy && (db || mode != 0), "vmr_relu_bwd_bias: null pointer");
+  VMR_CHECK(D % 8 == 0 && ld % 8 == 0, "vmr_relu_bwd_bias: D and ld must be multiples of 8 (D=%d)", D);
+  VMR_CHECK(mode != 1 || h, "vmr_relu_bwd_bias: mode 1 needs h");
+  VMR_CHECK(mode == 0 || dz, "vmr_relu_bwd_bias: modes 1/2 need dz");
+  if (rows == 0) return 0;
+  const int gx = cdiv(D, 256);
+  int gy = (int)min((int64_t)(1024 / gx > 0 ? 1024 / gx : 1), (rows + 63) / 64);
+  const int rpb = (int)((rows + gy - 1) / gy);
+  gy = (int)((rows + rpb - 1) / rpb);
+  if (dtype == VMR_BF16)
+    launch_rbb<bf16_t>(mode, dim3(gx, gy), (hipStream_t)stream, dy, h, dz, db, rows, D, ld, scale, rpb, drop_p,
+                       drop_seed, drop_step);
+  else
+    launch_rbb<float>(mode, dim3(gx, gy), (hipStream_t)stream, dy, h, dz, db, rows, D, ld, scale, rpb, drop_p,
+                      drop_seed, drop_step);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_dropout_mask(float* m, int64_t n, float drop_p, uint32_t seed, void* stream) {
+  VMR_CHECK(m, "vmr_dropout_mask: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)min((int64_t)4096, (n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, m, n, drop_p, seed);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_soft_ce_fwd(const float* zs, const float* ze, const float* ys, const float* ye, float* loss,
+                               float* lse, int B, int T, void* stream) {
+  VMR_CHECK(zs && ze && ys && ye && loss && lse, "vmr_soft_ce_fwd: null pointer");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(soft_ce_fwd_kernel, dim3(cdiv(2 * B, 4)), dim3(256), 0, (hipStream_t)stream, zs, ze, ys, ye, loss,
+                     lse, B, T);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_soft_ce_bwd(const float* zs, const float* ze, const float* ys, const float* ye, const float* lse,
+                               const float* dloss, float* dzs, float* dze, int B, int T, void* stream) {
+  VMR_CHECK(zs && ze && ys && ye && lse && dloss && dzs && dze, "vmr_soft_ce_bwd: null pointer");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(soft_ce_bwd_kernel, dim3(cdiv(2 * B, 4)), dim3(256), 0, (hipStream_t)stream, zs, ze, ys, ye, lse,
+                     dloss, dzs, dze, B, T);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_sumsq(const float* g, float* out, int64_t n, void* stream) {
+  VMR_CHECK(g && out, "vmr_sumsq: null pointer");
+  VMR_CHECK((reinterpret_cast<uintptr_t>(g) & 15) == 0, "vmr_sumsq: g must be 16-byte aligned");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((int)min((int64_t)2048, (n / 4 + 255) / 256 + 1)), dim3(256), 0,
+                     (hipStream_t)stream, g, out, n);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay, void* p_bf16,
+                         const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
+                         float wd, int step, int64_t n, void* stream) {
+  VMR_CHECK(p && g && m && v && decay, "vmr_adamw: null pointer");
+  VMR_CHECK(step >= 1, "vmr_adamw: step starts at 1");
+  if (n == 0) return 0;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3((int)min((int64_t)4096, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     p, g, m, v, decay, (bf16_t*)p_bf16, gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, n);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}

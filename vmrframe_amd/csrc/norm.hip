@@ -1,0 +1,426 @@
+// norm.hip -- LayerNorm and the fused LayerNorm + depthwise-conv encoder kernels.
+//
+// Reference semantics: nn.LayerNorm over the last dim (biased variance) at
+// models/layers.py:85,116,136,271-273,619-620,650-651; the fused kernel is
+// `layer_norms[l]` followed by the depthwise Conv1d(k=7, pad=3, groups=D, no
+// bias) of DepthwiseSeparableConvBlock (layers.py:126-148).  The convolution is
+// NOT masked: padded frames take part, exactly as in the reference.
+//
+// All of these are HBM-bound row kernels: one 64-lane wave owns one row, 16-B
+// vector loads, fp32 statistics, no re-reads (the row lives in registers).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 4;  // chunks of 8 elements per lane => D <= 64*8*4 = 2048
+
+template <typename T>
+__device__ __forceinline__ void load_row(const T* __restrict__ p, int D, int lane, float (&v)[MAXC][8]) {
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * 64 + lane) * 8;
+    if (i < D) Vec8<T>::load(p + i, v[c]);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void row_stats(const float (&v)[MAXC][8], int D, int lane, float eps, float& mean,
+                                          float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[c][e];
+  mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * 64 + lane) * 8;
+    if (i < D) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
+    }
+  }
+  rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+}
+
+// ------------------------------------------------------------ LayerNorm fwd
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps,
+                                                     const T* __restrict__ pos, int S, T* __restrict__ y,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                     int64_t rows, int D, float drop_p, uint32_t seed0,
+                                                     const uint32_t* __restrict__ step) {
+  const uint32_t seed = vmr_seed(seed0, step);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const uint32_t thresh = vmr_drop_thresh(drop_p);
+  const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+    float v[MAXC][8];
+    load_row<T>(x + row * D, D, lane, v);
+    float mean, rstd;
+    row_stats(v, D, lane, eps, mean, rstd);
+    if (lane == 0) {
+      if (mean_o) mean_o[row] = mean;
+      if (rstd_o) rstd_o[row] = rstd;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = (c * 64 + lane) * 8;
+      if (i >= D) continue;
+      float g[8], b[8], o[8];
+      Vec8<float>::load(gamma + i, g);
+      Vec8<float>::load(beta + i, b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
+      if (pos) {
+        float pv[8];
+        Vec8<T>::load(pos + (int64_t)(row % S) * D + i, pv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += pv[e];
+      }
+      if (drop_p > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o[e] = vmr_keep(seed, (uint64_t)row * D + i + e, thresh) ? o[e] * dscale : 0.f;
+      }
+      Vec8<T>::store(y + row * D + i, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------ LayerNorm bwd
+// dgamma/dbeta partials are kept per lane across the rows a wave visits, combined
+// across the 4 waves through LDS and flushed with contiguous float atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean_i,
+                                                     const float* __restrict__ rstd_i, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, float* __restrict__ dpos, int S,
+                                                     int64_t rows, int D, float drop_p, uint32_t seed0,
+                                                     const uint32_t* __restrict__ step) {
+  const uint32_t seed = vmr_seed(seed0, step);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);  // [2][4][D]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const uint32_t thresh = vmr_drop_thresh(drop_p);
+  const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  float ag[MAXC][8], ab[MAXC][8];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+    float xv[MAXC][8], gv[MAXC][8];
+    load_row<T>(x + row * D, D, lane, xv);
+    load_row<T>(dy + row * D, D, lane, gv);
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = (c * 64 + lane) * 8;
+      if (i >= D) continue;
+      float g[8];
+      Vec8<float>::load(gamma + i, g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float d = gv[c][e];
+        if (drop_p > 0.f) d = vmr_keep(seed, (uint64_t)row * D + i + e, thresh) ? d * dscale : 0.f;
+        const float xh = (xv[c][e] - mean) * rstd;
+        ag[c][e] += d * xh;
+        ab[c][e] += d;
+        if (dpos) atomicAdd(&dpos[(int64_t)(row % S) * D + i + e], d);
+        const float dxh = d * g[e];
+        s1 += dxh;
+        s2 += dxh * xh;
+        xv[c][e] = xh;
+        gv[c][e] = dxh;
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = (c * 64 + lane) * 8;
+      if (i >= D) continue;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[c][e] - s1 - xv[c][e] * s2);
+      if (dres) {
+        float r[8];
+        Vec8<T>::load(dres + row * D + i, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += r[e];
+      }
+      Vec8<T>::store(dx + row * D + i, o);
+    }
+  }
+  if (!dgamma) return;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * 64 + lane) * 8;
+    if (i >= D) continue;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(0 * 4 + wid) * D + i + e] = ag[c][e];
+      red[(1 * 4 + wid) * D + i + e] = ab[c][e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 256) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { sg += red[(0 * 4 + w) * D + i]; sb += red[(1 * 4 + w) * D + i]; }
+    atomicAdd(&dgamma[i], sg);
+    atomicAdd(&dbeta[i], sb);
+  }
+}
+
+// ----------------------------------------------- fused LayerNorm + dwconv fwd
+// Workgroup = (sample b, tile of R output rows).  Phase 1: the 4 waves normalise
+// the R+6 rows (3-row halo each side) into LDS; rows outside [0,S) are the
+// conv's zero padding.  Phase 2: each thread owns 4 channels and produces the
+// R output rows from the LDS tile.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            const float* __restrict__ w, T* __restrict__ u,
+                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                            int S, int D, int R, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* tile = reinterpret_cast<T*>(smem);  // [R+6][D]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.x / tiles, s0 = (blockIdx.x % tiles) * R;
+  const int nrows = R + 6;
+  for (int r = wid; r < nrows; r += 4) {
+    const int s = s0 - 3 + r;
+    float v[MAXC][8];
+    const bool in = s >= 0 && s < S;
+    float mean = 0.f, rstd = 0.f;
+    if (in) {
+      load_row<T>(x + ((int64_t)b * S + s) * D, D, lane, v);
+      row_stats(v, D, lane, eps, mean, rstd);
+      if (lane == 0 && r >= 3 && r < 3 + R) {
+        mean_o[(int64_t)b * S + s] = mean;
+        rstd_o[(int64_t)b * S + s] = rstd;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = (c * 64 + lane) * 8;
+      if (i >= D) continue;
+      float o[8];
+      if (in) {
+        float g[8], bb[8];
+        Vec8<float>::load(gamma + i, g);
+        Vec8<float>::load(beta + i, bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + bb[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+      }
+      Vec8<T>::store(tile + (int64_t)r * D + i, o);
+    }
+  }
+  __syncthreads();
+  for (int cg = threadIdx.x; cg * 4 < D; cg += 256) {
+    const int c0 = cg * 4;
+    float wk[4][7];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+      for (int k = 0; k < 7; ++k) wk[ch][k] = w[(c0 + ch) * 7 + k];
+    for (int r = 0; r < R; ++r) {
+      const int s = s0 + r;
+      if (s >= S) break;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const T* p = tile + (int64_t)(r + k) * D + c0;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) acc[ch] += wk[ch][k] * to_f<T>(p[ch]);
+      }
+      T* q = u + ((int64_t)b * S + s) * D + c0;
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) q[ch] = from_f<T>(acc[ch]);
+    }
+  }
+}
+
+// ------------------------------------------------------------- dwconv bwd
+// Workgroup = (sample b, slice of 256 channels); wave w streams rows
+// [w*S/4, (w+1)*S/4) (+3-row halos) keeping 7-row windows of du and n=LN(x) in
+// registers; each lane owns 4 channels.  dn[s] = sum_k w[k]*du[s-k+3];
+// dw[k] += sum_s du[s]*n[s+k-3].  dw partials of the 4 waves are combined in
+// LDS and flushed with contiguous float atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ du, const T* __restrict__ x,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const float* __restrict__ mean_i,
+                                                         const float* __restrict__ rstd_i,
+                                                         const float* __restrict__ w, T* __restrict__ dn,
+                                                         float* __restrict__ dw, int S, int D, int slices) {
+  __shared__ float red[4][256 * 7];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.x / slices, c0 = (blockIdx.x % slices) * 256 + lane * 4;
+  const bool act = c0 < D;
+  const int seg = (S + 3) / 4;
+  const int sb = wid * seg, se = min(S, sb + seg);
+  float wk[4][7], aw[4][7], g[4], bt[4];
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) {
+    g[ch] = act ? gamma[c0 + ch] : 0.f;
+    bt[ch] = act ? beta[c0 + ch] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { wk[ch][k] = act ? w[(c0 + ch) * 7 + k] : 0.f; aw[ch][k] = 0.f; }
+  }
+  // windows: index j holds row (cur - 3 + j), cur = the row whose dn is produced
+  float wdu[7][4], wn[7][4];
+  auto fetch = [&](int s, float (&odu)[4], float (&on)[4]) {
+    if (act && s >= 0 && s < S) {
+      const int64_t off = ((int64_t)b * S + s) * D + c0;
+      const float mean = mean_i[(int64_t)b * S + s], rstd = rstd_i[(int64_t)b * S + s];
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        odu[ch] = to_f<T>(du[off + ch]);
+        on[ch] = (to_f<T>(x[off + ch]) - mean) * rstd * g[ch] + bt[ch];
+      }
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) { odu[ch] = 0.f; on[ch] = 0.f; }
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < 6; ++j) fetch(sb - 3 + j, wdu[j + 1], wn[j + 1]);
+  for (int s = sb; s < se; ++s) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) { wdu[j][ch] = wdu[j + 1][ch]; wn[j][ch] = wn[j + 1][ch]; }
+    fetch(s + 3, wdu[6], wn[6]);
+    // dn[s] = sum_k w[k] * du[s + 3 - k]  -> window index (3 + 3 - k) = 6 - k
+    float o[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) a += wk[ch][k] * wdu[6 - k][ch];
+      o[ch] = a;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) aw[ch][k] += wdu[3][ch] * wn[k][ch];  // du[s] * n[s+k-3]
+    }
+    if (act) {
+      T* q = dn + ((int64_t)b * S + s) * D + c0;
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) q[ch] = from_f<T>(o[ch]);
+    }
+  }
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) red[wid][(lane * 4 + ch) * 7 + k] = aw[ch][k];
+  __syncthreads();
+  const int cbase = (blockIdx.x % slices) * 256;
+  for (int i = threadIdx.x; i < 256 * 7; i += 256) {
+    if (cbase + i / 7 < D) atomicAdd(&dw[(int64_t)cbase * 7 + i], red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+  }
+}
+
+int ln_check(int D) {
+  if (D % 8 != 0 || D > 64 * 8 * MAXC || D <= 0) return vmr_fail(-22, "LayerNorm kernels need D %% 8 == 0 and D <= %d (got %d)", 64 * 8 * MAXC, D);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vmr_layernorm_fwd(const void* x, const float* gamma, const float* beta, float eps, const void* pos,
+                                 int S, void* y, float* mean, float* rstd, int64_t rows, int D, int dtype,
+                                 float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream) {
+  if (int rc = ln_check(D)) return rc;
+  VMR_CHECK(x && gamma && beta && y, "vmr_layernorm_fwd: null pointer");
+  VMR_CHECK(!pos || S > 0, "vmr_layernorm_fwd: pos needs S > 0");
+  if (rows == 0) return 0;
+  const int grid = (int)min((int64_t)4096, (rows + 3) / 4);
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma,
+                       beta, eps, (const bf16_t*)pos, S, (bf16_t*)y, mean, rstd, rows, D, drop_p, drop_seed, drop_step);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma,
+                       beta, eps, (const float*)pos, S, (float*)y, mean, rstd, rows, D, drop_p, drop_seed, drop_step);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                 const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                 float* dpos, int S, int64_t rows, int D, int dtype, float drop_p,
+                                 uint32_t drop_seed, const uint32_t* drop_step, void* stream) {
+  if (int rc = ln_check(D)) return rc;
+  VMR_CHECK(dy && x && gamma && mean && rstd && dx, "vmr_layernorm_bwd: null pointer");
+  VMR_CHECK((dgamma == nullptr) == (dbeta == nullptr), "vmr_layernorm_bwd: dgamma/dbeta must come together");
+  if (rows == 0) return 0;
+  const int grid = (int)min((int64_t)512, (rows + 3) / 4);
+  const size_t lds = (size_t)2 * 4 * D * sizeof(float);
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy,
+                       (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, dpos, S,
+                       rows, D, drop_p, drop_seed, drop_step);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const float*)dy,
+                       (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, dpos, S, rows,
+                       D, drop_p, drop_seed, drop_step);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_ln_dwconv_fwd(const void* x, const float* gamma, const float* beta, float eps, const float* w,
+                                 void* u, float* mean, float* rstd, int B, int S, int D, int dtype, void* stream) {
+  if (int rc = ln_check(D)) return rc;
+  VMR_CHECK(x && gamma && beta && w && u && mean && rstd, "vmr_ln_dwconv_fwd: null pointer");
+  if (B == 0 || S == 0) return 0;
+  const size_t esz = dtype == VMR_BF16 ? 2 : 4;
+  int nrows = (int)min((size_t)32, (size_t)(128 * 1024) / ((size_t)D * esz));
+  VMR_CHECK(nrows >= 7, "vmr_ln_dwconv_fwd: D too large for the LDS tile");
+  int R = min(nrows - 6, S);
+  const int tiles = cdiv(S, R);
+  R = cdiv(S, tiles);  // balance the tiles
+  const size_t lds = (size_t)(R + 6) * D * esz;
+  const void* fn = dtype == VMR_BF16 ? (const void*)ln_dwconv_fwd_kernel<bf16_t> : (const void*)ln_dwconv_fwd_kernel<float>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return vmr_fail(-5, "vmr_ln_dwconv_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(ln_dwconv_fwd_kernel<bf16_t>, dim3(B * tiles), dim3(256), lds, (hipStream_t)stream,
+                       (const bf16_t*)x, gamma, beta, eps, w, (bf16_t*)u, mean, rstd, S, D, R, tiles);
+  else
+    hipLaunchKernelGGL(ln_dwconv_fwd_kernel<float>, dim3(B * tiles), dim3(256), lds, (hipStream_t)stream,
+                       (const float*)x, gamma, beta, eps, w, (float*)u, mean, rstd, S, D, R, tiles);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_dwconv_bwd(const void* du, const void* x, const float* gamma, const float* beta,
+                              const float* mean, const float* rstd, const float* w, void* dn, float* dw, int B,
+                              int S, int D, int dtype, void* stream) {
+  VMR_CHECK(du && x && gamma && beta && mean && rstd && w && dn && dw, "vmr_dwconv_bwd: null pointer");
+  VMR_CHECK(D % 4 == 0, "vmr_dwconv_bwd: D %% 4 != 0");
+  if (B == 0 || S == 0) return 0;
+  const int slices = cdiv(D, 256);
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(dwconv_bwd_kernel<bf16_t>, dim3(B * slices), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)du, (const bf16_t*)x, gamma, beta, mean, rstd, w, (bf16_t*)dn, dw, S, D, slices);
+  else
+    hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(B * slices), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)du, (const float*)x, gamma, beta, mean, rstd, w, (float*)dn, dw, S, D, slices);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}

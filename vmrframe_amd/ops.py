@@ -1,0 +1,690 @@
+"""Autograd operators of the SeqPAN path, each a thin wrapper that launches the
+hand-written HIP kernels of libvmr_hip.so through the C ABI (include/vmr_hip.h)
+on torch's current HIP stream.  PyTorch supplies device memory, streams and the
+autograd tape only; there is no non-HIP fallback (see _lib.require_gpu).
+
+Dropout never stores a mask: every site gets a (p, seed, step_ptr) triple from
+`DropCtx`; forward and backward kernels regenerate the same counter-based mask.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+NO_DROP = (0.0, 0, None)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class DropCtx:
+    """Per-forward dropout bookkeeping: hands out one seed per call site."""
+
+    def __init__(self, p: float, training: bool, base_seed: int, step: Optional[torch.Tensor] = None):
+        self.p = float(p) if training else 0.0
+        self.base = base_seed & 0xFFFFFFFF
+        self.n = 0
+        self.step = step  # optional device int32[1] mixed into every seed (hipGraph replay)
+        self.sites: List[Tuple[str, int]] = []
+
+    def next(self, name: str = "") -> Tuple[float, int, Optional[torch.Tensor]]:
+        if self.p <= 0.0:
+            return NO_DROP
+        self.n += 1
+        seed = (self.base * 0x9E3779B1 + self.n * 0x85EBCA6B + 0x1234567) & 0xFFFFFFFF
+        self.sites.append((name, seed))
+        return (self.p, seed, self.step)
+
+
+# ---------------------------------------------------------------------------
+# raw GEMM launch
+# ---------------------------------------------------------------------------
+def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=None, residual=None, aux=None,
+         ldr=0, rowscale=None, alpha=1.0, Z1=1, Z2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, drop=NO_DROP):
+    d = L.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cmat.data_ptr()
+    d.bias, d.residual, d.aux, d.rowscale = _ptr(bias), _ptr(residual), _ptr(aux), _ptr(rowscale)
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.M, d.N, d.K, d.transA, d.transB = M, N, K, ta, tb
+    d.dtype, d.flags, d.alpha = dtype, flags, alpha
+    d.Z1, d.Z2 = Z1, Z2
+    d.sA1, d.sA2 = sA
+    d.sB1, d.sB2 = sB
+    d.sC1, d.sC2 = sC
+    d.splitk = splitk
+    d.drop_p, d.drop_seed = drop[0], drop[1]
+    d.drop_step = _ptr(drop[2])
+    L.check(L.lib().vmr_gemm(C.byref(d), L.stream_ptr()), "vmr_gemm")
+
+
+def mm(a: torch.Tensor, b: torch.Tensor, ta: int, tb: int, *, out=None, out_f32=False, **kw) -> torch.Tensor:
+    """2-D product through vmr_gemm; a/b may be row-strided views (last stride 1)."""
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = (a.shape[1], a.shape[0]) if ta else a.shape
+    N = b.shape[1] if tb else b.shape[0]
+    assert (b.shape[0] if tb else b.shape[1]) == K, (a.shape, b.shape, ta, tb)
+    dt = L.dtype_code(a)
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    flags = kw.pop("flags", 0) | (L.EPI_OUT_F32 if (out_f32 and dt != L.F32) else 0)
+    gemm(a, b, out, M, N, K, ta, tb, a.stride(0), b.stride(0), out.stride(0), dtype=dt, flags=flags, **kw)
+    return out
+
+
+def bmm4(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, ta: int, tb: int, *, flags=0, **kw):
+    """Batched product over two leading dims of 4-D strided views:
+    a [Z1,Z2,M,K] (or [..,K,M] if ta), b [Z1,Z2,N,K] (or [..,K,N] if tb), c [Z1,Z2,M,N]."""
+    assert a.stride(3) == 1 and b.stride(3) == 1 and c.stride(3) == 1
+    Z1, Z2 = c.shape[0], c.shape[1]
+    M, N = c.shape[2], c.shape[3]
+    K = a.shape[2] if ta else a.shape[3]
+    dt = L.dtype_code(a)
+    if c.dtype == torch.float32 and dt != L.F32:
+        flags |= L.EPI_OUT_F32
+    gemm(a, b, c, M, N, K, ta, tb, a.stride(2), b.stride(2), c.stride(2), dtype=dt, flags=flags,
+         Z1=Z1, Z2=Z2, sA=(a.stride(0), a.stride(1)), sB=(b.stride(0), b.stride(1)),
+         sC=(c.stride(0), c.stride(1)), **kw)
+
+
+def splitk_for(M: int, N: int, K: int) -> int:
+    """dW products have few output tiles and a long K: split K until ~512 workgroups."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    sk = 1
+    while tiles * sk < 384 and K // (sk * 2) >= 512:
+        sk *= 2
+    return sk
+
+
+# ---------------------------------------------------------------------------
+# compute-dtype weight cache
+# ---------------------------------------------------------------------------
+class WeightCache:
+    """Compute-dtype copies of the fp32 master parameters (cast once per
+    optimizer step; keyed on the parameters' version counters).  A group of
+    weights that share their input (q/k/v, bilinear_1/2) is stored concatenated so
+    one GEMM serves the group; K is zero-padded to a multiple of 8."""
+
+    def __init__(self):
+        self.store = {}
+
+    def clear(self):
+        self.store.clear()
+
+    def get(self, params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+        key = (tuple(id(p) for p in params), dtype)
+        ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            mats = [p.detach().reshape(p.shape[0], -1).contiguous() for p in params]
+            K = mats[0].shape[1]
+            Kp = _rup(K, 8)
+            N = sum(m.shape[0] for m in mats)
+            if len(mats) == 1 and dtype == torch.float32 and Kp == K:
+                w = mats[0]
+            else:
+                w = torch.empty(N, Kp, device=mats[0].device, dtype=dtype)
+                r = 0
+                for m in mats:
+                    L.check(L.lib().vmr_cast(m.data_ptr(), L.F32, w[r:].data_ptr(), L.dtype_code(w), m.shape[0], K,
+                                             m.stride(0), Kp, 0.0, 0, None, L.stream_ptr()), "vmr_cast")
+                    r += m.shape[0]
+        self.store[key] = (ver, w)
+        return w
+
+
+# ---------------------------------------------------------------------------
+# cast (+pad, +input dropout)
+# ---------------------------------------------------------------------------
+def cast_pad(x: torch.Tensor, dtype: torch.dtype, drop=NO_DROP) -> torch.Tensor:
+    """[rows, cols] fp32 -> [rows, roundup(cols, 8)] compute dtype, zero padded, with the
+    VisualProjection input dropout (reference models/layers.py:120).  No gradient."""
+    L.require_gpu(x)
+    x = x.contiguous()
+    rows, cols = x.shape
+    out = torch.empty(rows, _rup(cols, 8), device=x.device, dtype=dtype)
+    L.check(L.lib().vmr_cast(x.data_ptr(), L.dtype_code(x), out.data_ptr(), L.dtype_code(out), rows, cols, cols,
+                             out.shape[1], drop[0], drop[1], _ptr(drop[2]), L.stream_ptr()), "vmr_cast")
+    return out
+
+
+class _ToDtype(torch.autograd.Function):
+    """Differentiable dtype cast through vmr_cast (fp32 glue tensors <-> compute dtype);
+    2-D inputs get their columns zero-padded to a multiple of 8 (16-byte GEMM rows)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype, pad8):
+        ctx.src = x.dtype
+        ctx.shape = tuple(x.shape)
+        x = x.contiguous()
+        pad8 = pad8 and x.dim() == 2
+        if pad8:
+            rows, cols = x.shape
+        else:
+            rows, cols = 1, x.numel()
+        ldd = _rup(cols, 8) if pad8 else cols
+        if x.dtype == dtype and ldd == cols:
+            return x
+        out = torch.empty((rows, ldd) if pad8 else x.shape, device=x.device, dtype=dtype)
+        L.check(L.lib().vmr_cast(x.data_ptr(), L.dtype_code(x), out.data_ptr(), L.dtype_code(out), rows, cols,
+                                 cols, ldd, 0.0, 0, None, L.stream_ptr()), "vmr_cast")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape = ctx.shape
+        if g.dtype == ctx.src and tuple(g.shape) == shape:
+            return g, None, None
+        g = g.contiguous()
+        out = torch.empty(shape, device=g.device, dtype=ctx.src)
+        if tuple(g.shape) != shape:
+            rows, cols, lds = shape[0], shape[1], g.shape[1]
+        else:
+            rows, cols, lds = 1, g.numel(), g.numel()
+        L.check(L.lib().vmr_cast(g.data_ptr(), L.dtype_code(g), out.data_ptr(), L.dtype_code(out), rows, cols,
+                                 lds, cols, 0.0, 0, None, L.stream_ptr()), "vmr_cast")
+        return out, None, None
+
+
+def to_dtype(x, dtype, pad8=False):
+    L.require_gpu(x)
+    return _ToDtype.apply(x, dtype, pad8)
+
+
+# ---------------------------------------------------------------------------
+# Linear / pointwise Conv1D with fused epilogue
+# ---------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = drop(act(x.W^T + b)) + residual   (reference Conv1D, layers.py:15-26).
+    `weights` are the fp32 master parameters (a group is concatenated along N);
+    the compute-dtype copy comes from the WeightCache."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, cache, relu, drop, rowscale, *weights):
+        L.require_gpu(x)
+        assert x.dim() == 2 and x.stride(1) == 1
+        W = cache.get(weights, x.dtype)
+        M, Kp = x.shape
+        N = W.shape[0]
+        assert W.shape[1] == Kp, f"input K {Kp} vs weight K {W.shape[1]} (pad inputs to a multiple of 8)"
+        dt = L.dtype_code(x)
+        Np = _rup(N, 8)                      # keep 16-byte rows even for N = 1 / 4 heads
+        ybuf = (torch.zeros if Np != N else torch.empty)(M, Np, device=x.device, dtype=x.dtype)
+        y = ybuf[:, :N] if Np != N else ybuf
+        flags = 0
+        aux = None
+        if bias is not None:
+            flags |= L.EPI_BIAS
+        if relu:
+            flags |= L.EPI_RELU
+        if drop[0] > 0:
+            flags |= L.EPI_DROPOUT
+        if residual is not None:
+            assert residual.shape == y.shape and residual.is_contiguous()
+            flags |= L.EPI_RESIDUAL
+        if relu and (residual is not None) and any(t.requires_grad for t in (x, *weights)):
+            aux = torch.empty_like(y)   # post-dropout ReLU output: the backward's mask
+            flags |= L.EPI_AUX
+        if rowscale is not None:
+            flags |= L.EPI_ROWSCALE
+        gemm(x, W, ybuf, M, N, Kp, 0, 0, x.stride(0), W.stride(0), Np, dtype=dt, flags=flags, bias=bias,
+             residual=residual, aux=aux, ldr=N, rowscale=rowscale, drop=drop)
+        ctx.save_for_backward(x, W, aux if aux is not None else (ybuf if relu else None), rowscale)
+        ctx.meta = (relu, drop, bias is not None, residual is not None, [tuple(w.shape) for w in weights])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, h, rowscale = ctx.saved_tensors
+        relu, drop, has_bias, has_res, wshapes = ctx.meta
+        M, N = dy.shape
+        Np = _rup(N, 8)
+        if Np != N:                          # narrow heads: work on a zero-padded [M, Np] copy
+            assert drop[0] == 0.0, "narrow outputs carry no dropout in this model"
+            pad = torch.zeros(M, Np, device=dy.device, dtype=dy.dtype)
+            pad[:, :N] = dy
+            dyb = pad
+        else:
+            dyb = dy.contiguous()
+        if rowscale is not None:
+            dyb = dyb * rowscale[:, None].to(dyb.dtype)
+        dres = dyb if has_res else None      # (has_res implies Np == N)
+        Kp = x.shape[1]
+        dt = L.dtype_code(dyb)
+        lib, st = L.lib(), L.stream_ptr()
+        scale = 1.0 / (1.0 - drop[0]) if drop[0] > 0 else 1.0
+        db = torch.zeros(Np, device=dy.device, dtype=torch.float32) if has_bias else None
+        if relu:
+            dzb = torch.empty_like(dyb)
+            L.check(lib.vmr_relu_bwd_bias(1, dyb.data_ptr(), h.data_ptr(), dzb.data_ptr(), _ptr(db), M, Np, Np, scale,
+                                          dt, 0.0, 0, None, st), "vmr_relu_bwd_bias")
+        elif drop[0] > 0:
+            dzb = torch.empty_like(dyb)
+            L.check(lib.vmr_relu_bwd_bias(2, dyb.data_ptr(), None, dzb.data_ptr(), _ptr(db), M, Np, Np, scale, dt,
+                                          drop[0], drop[1], _ptr(drop[2]), st), "vmr_relu_bwd_bias")
+        else:
+            dzb = dyb
+            if has_bias:
+                L.check(lib.vmr_relu_bwd_bias(0, dyb.data_ptr(), None, None, db.data_ptr(), M, Np, Np, 1.0, dt, 0.0, 0,
+                                              None, st), "vmr_relu_bwd_bias")
+        dz = dzb[:, :N] if Np != N else dzb
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = mm(dz, W, 0, 1)                       # [M,N] . [N,Kp]
+        # dW = dz^T . x  -> fp32 [N,Kp], split-K over the M (token) dimension
+        sk = splitk_for(N, Kp, M)
+        if sk > 1:
+            dW = torch.zeros(N, Kp, device=dy.device, dtype=torch.float32)
+            gemm(dz, x, dW, N, Kp, M, 1, 1, dz.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_ACCUM, splitk=sk)
+        else:
+            dW = mm(dz, x, 1, 1, out_f32=True)
+        grads = []
+        r = 0
+        for shp in wshapes:
+            n = shp[0]
+            k = 1
+            for s_ in shp[1:]:
+                k *= s_
+            grads.append(dW[r:r + n, :k].reshape(shp))
+            r += n
+        if db is not None and Np != N:
+            db = db[:N]
+        return (dx, db, dres, None, None, None, None, *grads)
+
+
+def linear(x, weights, bias, cache, *, relu=False, drop=NO_DROP, residual=None, rowscale=None):
+    if isinstance(weights, torch.Tensor):
+        weights = [weights]
+    return _Linear.apply(x, bias, residual, cache, relu, drop, rowscale, *weights)
+
+
+# ---------------------------------------------------------------------------
+# LayerNorm (+pos, +dropout)
+# ---------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, pos, S, drop, cache):
+        L.require_gpu(x)
+        x = x.contiguous()
+        rows, D = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        posc = None
+        if pos is not None:
+            posc = cache.get([pos], x.dtype)
+            assert posc.shape[1] == D and S <= posc.shape[0]
+        L.check(L.lib().vmr_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, _ptr(posc), S,
+                                          y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, D, L.dtype_code(x),
+                                          drop[0], drop[1], _ptr(drop[2]), L.stream_ptr()), "vmr_layernorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.meta = (drop, S, None if pos is None else tuple(pos.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        drop, S, pshape = ctx.meta
+        dy = dy.contiguous()
+        rows, D = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.zeros(D, device=x.device, dtype=torch.float32)
+        db = torch.zeros_like(dg)
+        dpos = torch.zeros(pshape, device=x.device, dtype=torch.float32) if pshape else None
+        L.check(L.lib().vmr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                          _ptr(dpos), S, rows, D, L.dtype_code(x), drop[0], drop[1], _ptr(drop[2]),
+                                          L.stream_ptr()), "vmr_layernorm_bwd")
+        return dx, dg, db, None, dpos, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps, cache, *, pos=None, S=0, drop=NO_DROP):
+    return _LayerNorm.apply(x, gamma, beta, eps, pos, S, drop, cache)
+
+
+# ---------------------------------------------------------------------------
+# fused LayerNorm + depthwise conv (k=7)
+# ---------------------------------------------------------------------------
+class _LnDwConv(torch.autograd.Function):
+    """u = dwconv7(LN(x)) per sequence (reference layers.py:139-145, unmasked).
+    x is a packed token matrix [sum_i B_i*S_i, D]; `segs` lists the (B_i, S_i)
+    sequence groups stored back to back (video clips, then query sentences)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w, eps, segs):
+        L.require_gpu(x)
+        x = x.contiguous()
+        rows, D = x.shape
+        assert rows == sum(b * s for b, s in segs)
+        u = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        w2 = w.detach().reshape(D, 7).contiguous()
+        r = 0
+        for (B, S) in segs:
+            L.check(L.lib().vmr_ln_dwconv_fwd(x[r:].data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, w2.data_ptr(),
+                                              u[r:].data_ptr(), mean[r:].data_ptr(), rstd[r:].data_ptr(), B, S, D,
+                                              L.dtype_code(x), L.stream_ptr()), "vmr_ln_dwconv_fwd")
+            r += B * S
+        ctx.save_for_backward(x, gamma, beta, w2, mean, rstd)
+        ctx.meta = (segs, tuple(w.shape))
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        x, gamma, beta, w2, mean, rstd = ctx.saved_tensors
+        segs, wshape = ctx.meta
+        rows, D = x.shape
+        du = du.contiguous()
+        lib, st, dt = L.lib(), L.stream_ptr(), L.dtype_code(x)
+        dn = torch.empty_like(x)
+        dw = torch.zeros(D, 7, device=x.device, dtype=torch.float32)
+        r = 0
+        for (B, S) in segs:
+            L.check(lib.vmr_dwconv_bwd(du[r:].data_ptr(), x[r:].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                       mean[r:].data_ptr(), rstd[r:].data_ptr(), w2.data_ptr(), dn[r:].data_ptr(),
+                                       dw.data_ptr(), B, S, D, dt, st), "vmr_dwconv_bwd")
+            r += B * S
+        dx = torch.empty_like(x)
+        dg = torch.zeros(D, device=x.device, dtype=torch.float32)
+        db = torch.zeros_like(dg)
+        L.check(lib.vmr_layernorm_bwd(dn.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                      None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, 0, rows, D, dt,
+                                      0.0, 0, None, st), "vmr_layernorm_bwd")
+        return dx, dg, db, dw.reshape(wshape), None, None
+
+
+def ln_dwconv(x, gamma, beta, w, eps, segs):
+    return _LnDwConv.apply(x, gamma, beta, w, eps, tuple(segs))
+
+
+# ---------------------------------------------------------------------------
+# attention cores: batched MFMA GEMMs + the masked softmax kernel
+# ---------------------------------------------------------------------------
+def _softmax_fwd(S, R, Cc, ldP, rmask, cmask, mode, H, cm_stride, scale, dtype, drop):
+    """S: fp32 [Z1,Z2,R,ldS] -> (P dropped, Pkeep) in `dtype` [Z1,Z2,R,ldP]."""
+    Z = S.shape[0] * S.shape[1]
+    P = torch.empty(S.shape[0], S.shape[1], R, ldP, device=S.device, dtype=dtype)
+    Pk = torch.empty_like(P) if drop[0] > 0 else None
+    L.check(L.lib().vmr_softmax_fwd(S.data_ptr(), P.data_ptr(), _ptr(Pk), _ptr(rmask), cmask.data_ptr(), mode, Z, H,
+                                    R, Cc, S.shape[3], ldP, cm_stride, scale, L.dtype_code(P), drop[0], drop[1],
+                                    _ptr(drop[2]), L.stream_ptr()), "vmr_softmax_fwd")
+    return P, (Pk if Pk is not None else P)
+
+
+def _softmax_bwd(dP, Pk, R, Cc, scale, drop):
+    Z = dP.shape[0] * dP.shape[1]
+    dS = torch.empty_like(Pk)
+    L.check(L.lib().vmr_softmax_bwd(dP.data_ptr(), Pk.data_ptr(), dS.data_ptr(), Z, R, Cc, dP.shape[3], Pk.shape[3],
+                                    scale, L.dtype_code(Pk), drop[0], drop[1], _ptr(drop[2]), L.stream_ptr()),
+            "vmr_softmax_bwd")
+    return dS
+
+
+def _attend_fwd(q4, k4, v4, o4, rmask, cmask, mode, H, cm_stride, scale, drop):
+    """o = softmax(q.k^T*scale + mask).v over 4-D strided views [Z1,Z2,rows,hd]."""
+    Z1, Z2, R, _ = q4.shape
+    Ck = k4.shape[2]
+    ld = _rup(Ck, 8)
+    S = torch.empty(Z1, Z2, R, ld, device=q4.device, dtype=torch.float32)
+    bmm4(q4, k4, S[..., :Ck], 0, 0)
+    P, Pk = _softmax_fwd(S, R, Ck, ld, rmask, cmask, mode, H, cm_stride, scale, q4.dtype, drop)
+    bmm4(P[..., :Ck], v4, o4, 0, 1)
+    return P, Pk
+
+
+def _attend_bwd(do4, q4, k4, v4, P, Pk, dq4, dk4, dv4, scale, drop, accumulate_dq):
+    Z1, Z2, R, _ = q4.shape
+    Ck = k4.shape[2]
+    ld = P.shape[3]
+    bmm4(P[..., :Ck], do4, dv4, 1, 1)                                   # dV = P^T . dO
+    dP = torch.empty(Z1, Z2, R, ld, device=q4.device, dtype=torch.float32)
+    bmm4(do4, v4, dP[..., :Ck], 0, 0)                                   # dP = dO . V^T
+    dS = _softmax_bwd(dP, Pk, R, Ck, scale, drop)
+    if accumulate_dq:                                                   # dQ += dS . K (in place)
+        bmm4(dS[..., :Ck], k4, dq4, 0, 1, flags=L.EPI_RESIDUAL, residual=dq4, ldr=dq4.stride(2))
+    else:
+        bmm4(dS[..., :Ck], k4, dq4, 0, 1)
+    bmm4(dS[..., :Ck], q4, dk4, 1, 1)                                   # dK = dS^T . Q
+
+
+class _DualAttention(torch.autograd.Function):
+    """Self + cross attention cores of DualMultiAttention (reference
+    models/layers.py:346-367) for BOTH directions of a DualAttentionBlock at once.
+    Token matrices are packed [B*T video rows | B*L query rows]:
+      qkv [N,3D] = (query | f_key | f_value) of every token as a `from` token,
+      kv  [N,2D] = (t_key | t_value)         of every token as a `to` token.
+    Direction v: from = video rows, to = query rows; direction t: the reverse.
+    Returns the head-merged contexts (self, cross) [N, D] (pre s_dense/x_dense)."""
+
+    @staticmethod
+    def _views(qkv, kv, so, xo, B, T, Lq, H):
+        D = qkv.shape[1] // 3
+        hd = D // H
+        Nv = B * T
+        out = []
+        for (r0, Lf, t0, Lt) in ((0, T, Nv, Lq), (Nv, Lq, 0, T)):
+            f5 = qkv[r0:r0 + B * Lf].view(B, Lf, 3, H, hd)
+            t5 = kv[t0:t0 + B * Lt].view(B, Lt, 2, H, hd)
+            q4, kf4, vf4 = (f5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+            kt4, vt4 = (t5[:, :, i].permute(0, 2, 1, 3) for i in range(2))
+            so4 = so[r0:r0 + B * Lf].view(B, Lf, H, hd).permute(0, 2, 1, 3)
+            xo4 = xo[r0:r0 + B * Lf].view(B, Lf, H, hd).permute(0, 2, 1, 3)
+            out.append((q4, kf4, vf4, kt4, vt4, so4, xo4))
+        return out
+
+    @staticmethod
+    def forward(ctx, qkv, kv, vmask, tmask, B, T, Lq, H, drops):
+        L.require_gpu(qkv, kv)
+        D = qkv.shape[1] // 3
+        scale = 1.0 / math.sqrt(float(D // H))
+        so = torch.empty(qkv.shape[0], D, device=qkv.device, dtype=qkv.dtype)
+        xo = torch.empty_like(so)
+        saved = []
+        masks = ((vmask, tmask), (tmask, vmask))
+        for d, (q4, kf4, vf4, kt4, vt4, so4, xo4) in enumerate(_DualAttention._views(qkv, kv, so, xo, B, T, Lq, H)):
+            fm, tm = masks[d]
+            saved += _attend_fwd(q4, kf4, vf4, so4, fm, fm, 0, H, 0, scale, drops[2 * d])
+            saved += _attend_fwd(q4, kt4, vt4, xo4, fm, tm, 0, H, 0, scale, drops[2 * d + 1])
+        ctx.save_for_backward(qkv, kv, *saved)
+        ctx.meta = (B, T, Lq, H, scale, drops)
+        return so, xo
+
+    @staticmethod
+    def backward(ctx, dso, dxo):
+        qkv, kv, *saved = ctx.saved_tensors
+        B, T, Lq, H, scale, drops = ctx.meta
+        dso, dxo = dso.contiguous(), dxo.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dkv = torch.empty_like(kv)
+        fw = _DualAttention._views(qkv, kv, dso, dxo, B, T, Lq, H)
+        bw = _DualAttention._views(dqkv, dkv, dso, dxo, B, T, Lq, H)
+        for d in range(2):
+            q4, kf4, vf4, kt4, vt4, dso4, dxo4 = fw[d]
+            dq4, dkf4, dvf4, dkt4, dvt4, _, _ = bw[d]
+            Ps, Pks, Px, Pkx = saved[4 * d:4 * d + 4]
+            _attend_bwd(dso4, q4, kf4, vf4, Ps, Pks, dq4, dkf4, dvf4, scale, drops[2 * d], False)
+            _attend_bwd(dxo4, q4, kt4, vt4, Px, Pkx, dq4, dkt4, dvt4, scale, drops[2 * d + 1], True)
+        return dqkv, dkv, None, None, None, None, None, None, None
+
+
+def dual_attention(qkv, kv, vmask, tmask, B, T, Lq, H, drops=(NO_DROP,) * 4):
+    return _DualAttention.apply(qkv, kv, vmask.contiguous(), tmask.contiguous(), B, T, Lq, H, tuple(drops))
+
+
+class _BatchAxisAttention(torch.autograd.Function):
+    """Attention core of TopSelfAttention2 (reference models/layers.py:567-574):
+    nn.MultiheadAttention without batch_first on [B,T,D] => for every time index t
+    and head h, sample b attends over the samples b' of the batch; the float
+    key_padding_mask vmask.T is ADDED to the logits.  qkv: [B*T, 3D] (in_proj
+    output, rows b*T+t); returns the head-merged context [B*T, D] (pre out_proj)."""
+
+    @staticmethod
+    def forward(ctx, qkv, vmask, B, T, H, drop):
+        L.require_gpu(qkv)
+        D = qkv.shape[1] // 3
+        hd = D // H
+        scale = 1.0 / math.sqrt(float(hd))
+        q4, k4, v4 = (qkv.view(B, T, 3, H, hd)[:, :, i].permute(1, 2, 0, 3) for i in range(3))  # [T,H,B,hd]
+        o = torch.empty(B * T, D, device=qkv.device, dtype=qkv.dtype)
+        o4 = o.view(B, T, H, hd).permute(1, 2, 0, 3)
+        P, Pk = _attend_fwd(q4, k4, v4, o4, None, vmask, 1, H, T, scale, drop)
+        ctx.save_for_backward(qkv, P, Pk)
+        ctx.meta = (B, T, H, scale, drop)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, P, Pk = ctx.saved_tensors
+        B, T, H, scale, drop = ctx.meta
+        D = qkv.shape[1] // 3
+        hd = D // H
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        q4, k4, v4 = (qkv.view(B, T, 3, H, hd)[:, :, i].permute(1, 2, 0, 3) for i in range(3))
+        dq4, dk4, dv4 = (dqkv.view(B, T, 3, H, hd)[:, :, i].permute(1, 2, 0, 3) for i in range(3))
+        do4 = do.view(B, T, H, hd).permute(1, 2, 0, 3)
+        _attend_bwd(do4, q4, k4, v4, P, Pk, dq4, dk4, dv4, scale, drop, False)
+        return dqkv, None, None, None, None, None
+
+
+def batch_axis_attention(qkv, vmask, B, T, H, drop=NO_DROP):
+    return _BatchAxisAttention.apply(qkv, vmask.contiguous(), B, T, H, drop)
+
+
+# ---------------------------------------------------------------------------
+# generic differentiable batched product (CQAttention contractions)
+# ---------------------------------------------------------------------------
+_BMM_FORMS = {(0, 0), (0, 1), (1, 1)}
+
+
+def _bmm_raw(a, b, ta, tb, out_f32=False):
+    """a,b: [Z, r, c] contiguous -> [Z, M, N]"""
+    Z = a.shape[0]
+    M = a.shape[2] if ta else a.shape[1]
+    N = b.shape[2] if tb else b.shape[1]
+    Np = _rup(N, 8)
+    cbuf = torch.empty(Z, M, Np, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    c = cbuf[..., :N]
+    bmm4(a.unsqueeze(0), b.unsqueeze(0), c.unsqueeze(0), ta, tb)
+    return c
+
+
+class _Bmm(torch.autograd.Function):
+    """c[z] = op(a[z]) . op(b[z]) on the MFMA GEMM (reference torch.matmul sites of
+    CQAttention, models/layers.py:422-423,435).  Forms: (ta,tb) = (0,0): a[M,K].b[N,K]^T;
+    (0,1): a[M,K].b[K,N]; (1,1): a[K,M]^T.b[K,N]."""
+
+    @staticmethod
+    def forward(ctx, a, b, ta, tb, out_f32):
+        L.require_gpu(a, b)
+        assert (ta, tb) in _BMM_FORMS
+        a = a if a.stride(-1) == 1 else a.contiguous()
+        b = b if b.stride(-1) == 1 else b.contiguous()
+        ctx.save_for_backward(a, b)
+        ctx.meta = (ta, tb)
+        return _bmm_raw(a, b, ta, tb, out_f32)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        ta, tb = ctx.meta
+        dc = dc.to(a.dtype)
+        if dc.stride(-1) != 1 or dc.stride(-2) % 8 or dc.stride(0) % 8:
+            dcp = torch.zeros(dc.shape[0], dc.shape[1], _rup(dc.shape[2], 8), device=dc.device, dtype=dc.dtype)
+            dcp[..., :dc.shape[2]] = dc
+            dc = dcp[..., :dc.shape[2]]
+        if (ta, tb) == (0, 0):
+            da, db = _bmm_raw(dc, b, 0, 1), _bmm_raw(dc, a, 1, 1)
+        elif (ta, tb) == (0, 1):
+            da, db = _bmm_raw(dc, b, 0, 0), _bmm_raw(a, dc, 1, 1)
+        else:
+            da, db = _bmm_raw(b, dc, 0, 0), _bmm_raw(a, dc, 0, 1)
+        return da, db, None, None, None
+
+
+def bmm(a, b, ta, tb, out_f32=False):
+    return _Bmm.apply(a, b, ta, tb, out_f32)
+
+
+class _Dropout(torch.autograd.Function):
+    """Stand-alone inverted dropout (the score-path dropout of CQAttention,
+    reference models/layers.py:431-432); mask regenerated in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, drop):
+        L.require_gpu(x)
+        x = x.contiguous()
+        D = x.shape[-1]
+        rows = x.numel() // D
+        y = torch.empty_like(x)
+        L.check(L.lib().vmr_cast(x.data_ptr(), L.dtype_code(x), y.data_ptr(), L.dtype_code(y), rows, D, D, D,
+                                 drop[0], drop[1], _ptr(drop[2]), L.stream_ptr()), "vmr_cast")
+        ctx.drop = drop
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        drop = ctx.drop
+        dy = dy.contiguous()
+        D = dy.shape[-1]
+        rows = dy.numel() // D
+        dx = torch.empty_like(dy)
+        L.check(L.lib().vmr_relu_bwd_bias(2, dy.data_ptr(), None, dx.data_ptr(), None, rows, D, D,
+                                          1.0 / (1.0 - drop[0]), L.dtype_code(dy), drop[0], drop[1], _ptr(drop[2]),
+                                          L.stream_ptr()), "vmr_relu_bwd_bias")
+        return dx, None
+
+
+def dropout(x, drop):
+    return x if drop[0] <= 0.0 else _Dropout.apply(x, drop)
+
+
+# ---------------------------------------------------------------------------
+# boundary-label cross-entropy (reference models/loss.py:43-54)
+# ---------------------------------------------------------------------------
+class _SoftCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, zs, ze, ys, ye):
+        L.require_gpu(zs, ze, ys, ye)
+        zs, ze, ys, ye = (t.contiguous().float() for t in (zs, ze, ys, ye))
+        B, T = zs.shape
+        loss = torch.zeros(1, device=zs.device, dtype=torch.float32)
+        lse = torch.empty(2 * B, device=zs.device, dtype=torch.float32)
+        L.check(L.lib().vmr_soft_ce_fwd(zs.data_ptr(), ze.data_ptr(), ys.data_ptr(), ye.data_ptr(), loss.data_ptr(),
+                                        lse.data_ptr(), B, T, L.stream_ptr()), "vmr_soft_ce_fwd")
+        ctx.save_for_backward(zs, ze, ys, ye, lse)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        zs, ze, ys, ye, lse = ctx.saved_tensors
+        B, T = zs.shape
+        g = g.reshape(1).contiguous().float()
+        dzs, dze = torch.empty_like(zs), torch.empty_like(ze)
+        L.check(L.lib().vmr_soft_ce_bwd(zs.data_ptr(), ze.data_ptr(), ys.data_ptr(), ye.data_ptr(), lse.data_ptr(),
+                                        g.data_ptr(), dzs.data_ptr(), dze.data_ptr(), B, T, L.stream_ptr()),
+                "vmr_soft_ce_bwd")
+        return dzs, dze, None, None
+
+
+def soft_ce(zs, ze, ys, ye):
+    return _SoftCE.apply(zs, ze, ys, ye)
+
+
+def dropout_mask(n: int, p: float, seed: int, device) -> torch.Tensor:
+    """Materialise the counter-based dropout multiplier (tests / oracle injection)."""
+    m = torch.empty(n, device=device, dtype=torch.float32)
+    L.check(L.lib().vmr_dropout_mask(m.data_ptr(), n, p, seed, L.stream_ptr()), "vmr_dropout_mask")
+    return m
