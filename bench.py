@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- SeqPAN train-step throughput on MI355X (BASELINE.json metric:
+clips/sec of a train step at B x T = 64 x 128, D = 1024, bf16).
+
+One "step" = the reference loop body main.py:88-97 on one synthetic batch that is
+already resident in HBM: forward, both losses, backward, gradient all-reduce
+(N > 1), clip_grad_norm_(1.0), AdamW (two decay groups), linear-warmup schedule.
+Dropout is ON (droprate 0.2, the reference's configs); weights are random-init.
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); per-GPU
+batch is fixed at 64 clips (weak scaling).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CFG2 = dict(B=64, T=128, L=20, D=1024, V=500, num_words=4002, num_chars=60, C=8, droprate=0.2)
+TRAIN_GFLOP_PER_CLIP = 58.0      # 19.34 GFLOP fwd (FlopCounter on the reference) x 3
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def make_cfg(a, dtype):
+    from oracle import seqpan_ref as R   # only for the attribute-dict helper + synthetic batch recipe
+    cfg = R.make_cfg(dim=a["D"], vlen=a["T"], vdim=a["V"], num_words=a["num_words"], num_chars=a["num_chars"],
+                     droprate=a["droprate"])
+    cfg.model.compute_dtype = dtype
+    return cfg
+
+
+def synth(a, seed):
+    from oracle import seqpan_ref as R
+    return R.synth_batch(a["B"], a["T"], a["L"], a["V"], a["num_words"], a["num_chars"], C=a["C"], seed=seed)
+
+
+class GemmTimer:
+    """HIP events around every launch of the dominant kernel (the NT bf16 MFMA GEMM) on the
+    stream it is launched on; achieved TFLOP/s = sum(flops) / sum(event time)."""
+
+    def __init__(self):
+        self.records = []
+
+    def __call__(self, launch, M, N, K, ta, tb, Z, dtype):
+        if ta or tb or dtype != 1:
+            return launch()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        launch()
+        e.record()
+        self.records.append((s, e, 2.0 * M * N * K * Z))
+
+    def summary(self):
+        if not self.records:
+            return None
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return {"launches": len(self.records), "ms_total": ms, "tflops": fl / (ms * 1e-3) / 1e12,
+                "avg_us": ms * 1e3 / len(self.records), "flops_per_launch": fl / len(self.records)}
+
+
+def cpu_baseline(a):
+    """The oracle (CPU fp32 restatement of the reference, kind 'port') timed on the host cores
+    on a bounded sample: cfg2 shapes at B=8 clips, one warm-up + two timed fwd+bwd+AdamW steps."""
+    from oracle import seqpan_ref as R
+    # the GPU box gives one job a 16-CPU share whatever os.cpu_count() says: oversubscribing stalls
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(16, cores))
+    torch.set_num_threads(cores)
+    b = dict(a); b["B"] = 8
+    cfg = make_cfg(b, "fp32")
+    weights = R.make_weights(cfg, 5)
+    P = R.to_params(weights, requires_grad=True)
+    batch = synth(b, 5)
+    g = R.gumbel_noise(b["B"], b["T"], 5)
+    params = [p for p in P.values() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4)
+
+    def drop(site, x):
+        return torch.nn.functional.dropout(x, a["droprate"], True)
+
+    def step():
+        loss, _, _ = R.train_loss(P, cfg, batch, g, drop)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
+        opt.step()
+    step()
+    print("[bench] cpu_baseline warm-up done", file=sys.stderr, flush=True)
+    t0 = time.time()
+    n = 2
+    for _ in range(n):
+        step()
+    dt = (time.time() - t0) / n
+    return {"value": b["B"] / dt, "unit": "clips/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle/seqpan_ref.py fp32 train step (fwd+losses+bwd+clip+AdamW, dropout on) at cfg2 "
+                      f"shapes with B=8 clips, mean of {n} steps after 1 warm-up ({dt:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import torch.distributed as dist
+    import vmrframe_amd as V
+    from vmrframe_amd import dp, ops
+    from vmrframe_amd.optim import FlatAdamW
+    if world > 1:
+        dp.init_process_group_from_env("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    a = CFG2
+    torch.manual_seed(1234)                      # reference main.py:41
+    cfg = make_cfg(a, args.dtype)
+    cfg.device = dev
+    rng = np.random.default_rng(1234)
+    glove = rng.standard_normal((a["num_words"] - 2, 300)).astype(np.float32)
+    model = V.SeqPAN(cfg, glove).to(dev)
+    model.sync_timing = False                    # the reference's in-forward wall-clock syncs are instrumentation
+    model.base_seed = 1234 + rank                # per-rank dropout / Gumbel streams
+    torch.manual_seed(1234 + rank)
+    dp.broadcast_parameters(model)
+    total_steps = args.steps + args.warmup
+    opt = FlatAdamW(model, lr=1e-4, weight_decay=0.01, max_norm=1.0, warmup_steps=0.0 * total_steps,
+                    total_steps=10 * total_steps)
+    reducer = dp.GradReducer(model, opt)
+    batch = {k: v.to(dev) for k, v in synth(a, 1234 + rank).items()}   # weak scaling: 64 clips per GPU
+    model.train()
+
+    def step():
+        loss, out = V.train_engine_SeqPAN(model, batch, cfg, "train")
+        opt.zero_grad()
+        loss.backward()
+        reducer.finish()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[bench] warm-up done, loss {float(loss.item()):.4f}", file=sys.stderr, flush=True)
+    timer = GemmTimer() if rank == 0 else None
+    ops.GEMM_HOOK = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ops.GEMM_HOOK = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+    assert np.isfinite(final_loss), "training diverged"
+
+    if rank == 0:
+        print(f"[bench] timed region done: {dt / args.steps * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
+        clips = a["B"] * world * args.steps
+        value = clips / dt
+        gs = timer.summary()
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = None
+        if gs:
+            roofline = {"kernel": "gemm_bf16_kernel<NT> (x.W^T pointwise-conv / projection GEMM)", "bound": "mfma",
+                        "achieved": round(gs["tflops"], 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(gs["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                        "launches_per_step": gs["launches"] / args.steps, "avg_launch_us": round(gs["avg_us"], 2),
+                        "flops_per_launch": gs["flops_per_launch"]}
+        out = {"metric": "clips/sec (train step) at BxT=64x128, D=1024", "value": round(value, 2),
+               "unit": "clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "SeqPAN anet/C3D synthetic features (configs[1]): B=64 clips/GPU, T=128, "
+                                      "L=20, D=1024, V=500, droprate 0.2; full train step "
+                                      "(fwd+losses+bwd+allreduce+clip+AdamW+schedule)",
+                          "global_batch": a["B"] * world, "parallelism": f"dp{world}"},
+               "step_mfma_frac": round(value * TRAIN_GFLOP_PER_CLIP * 1e9 / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
+               "final_loss": round(final_loss, 4),
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

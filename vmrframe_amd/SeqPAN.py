@@ -206,6 +206,7 @@ class SeqPAN(nn.Module):
         self.drop_step = None         # optional device int32[1] mixed into the dropout seeds
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
         self.last_drop_sites = []
+        self.sync_timing = True       # reference-style synchronised self-timing of forward (:51-52,85-87)
 
     # -- plumbing -------------------------------------------------------------
     def _register(self, dotted, param):
@@ -349,7 +350,8 @@ class SeqPAN(nn.Module):
     # -- forward --------------------------------------------------------------
     def forward(self, word_ids, char_ids, vfeat_in, vmask, tmask):
         L.require_gpu(word_ids, char_ids, vfeat_in, vmask, tmask)
-        torch.cuda.synchronize()          # reference models/SeqPAN.py:51-52 self-timing
+        if self.sync_timing:
+            torch.cuda.synchronize()      # reference models/SeqPAN.py:51-52 self-timing
         start = time.time()
         cdt, D = self.compute_dtype, self.dim
         B, T = vmask.shape
@@ -404,7 +406,8 @@ class SeqPAN(nn.Module):
         elogits = self._lin(eh, "predictor.end_dense").float().reshape(B, T)
         self.last_drop_sites = dc.sites
 
-        torch.cuda.synchronize()
+        if self.sync_timing:
+            torch.cuda.synchronize()
         consume_time = time.time() - start
         return {"slogits": slogits, "elogits": elogits, "vmask": vmask, "match_score": match_score,
                 "label_embs": self.P("label_embs"), "consume_time": consume_time}

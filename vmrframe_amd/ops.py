@@ -17,6 +17,7 @@ import torch
 from . import _lib as L
 
 NO_DROP = (0.0, 0, None)
+GEMM_HOOK = None   # bench.py: callable(launch, M, N, K, ta, tb, Z, dtype) timing the launch with HIP events
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -64,6 +65,10 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
     d.splitk = splitk
     d.drop_p, d.drop_seed = drop[0], drop[1]
     d.drop_step = _ptr(drop[2])
+    if GEMM_HOOK is not None:
+        GEMM_HOOK(lambda: L.check(L.lib().vmr_gemm(C.byref(d), L.stream_ptr()), "vmr_gemm"), M, N, K, ta, tb,
+                  Z1 * Z2, dtype)
+        return
     L.check(L.lib().vmr_gemm(C.byref(d), L.stream_ptr()), "vmr_gemm")
 
 

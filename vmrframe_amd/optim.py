@@ -1,0 +1,102 @@
+"""Fused optimizer step for the SeqPAN train loop (reference main.py:93-97 +
+utils/utils.py:87-97): AdamW with the reference's two decay groups (0.01 for
+weights, 0 for names containing bias / layer_norm), clip_grad_norm_(max_norm)
+and the transformers linear-warmup schedule -- as TWO HIP launches over one flat
+fp32 arena (vmr_sumsq + vmr_adamw) instead of ~170 per-tensor updates.
+
+Memory layout: after the first backward, every parameter that received a
+gradient is re-pointed (`p.data`, `p.grad`) at views of two contiguous fp32
+arenas `flat_p` / `flat_g`; the gradient arena is what the data-parallel
+all-reduce moves over xGMI (vmrframe_amd/dp.py).  Parameters that never get a
+gradient (the reference's 20 unused tensors, frozen GloVe rows) stay outside
+and are never touched, exactly like torch.optim.AdamW skipping `grad is None`.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from . import _lib as L
+
+NO_DECAY = ("bias", "layer_norm", "LayerNorm")   # reference utils/utils.py:89
+
+
+def linear_warmup_lambda(num_warmup_steps: float, num_training_steps: int):
+    """transformers.get_linear_schedule_with_warmup's lr multiplier (reference utils/utils.py:95-96)."""
+    def f(step: int) -> float:
+        if step < num_warmup_steps:
+            return float(step) / float(max(1, num_warmup_steps))
+        return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))
+    return f
+
+
+class FlatAdamW:
+    def __init__(self, model: torch.nn.Module, lr: float, weight_decay: float = 0.01, betas=(0.9, 0.999),
+                 eps: float = 1e-8, max_norm: float = 1.0, warmup_steps: float = 0.0, total_steps: int = 0):
+        self.model = model
+        self.base_lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.sched = linear_warmup_lambda(warmup_steps, total_steps) if total_steps > 0 else (lambda s: 1.0)
+        self.t = 0                 # optimizer steps taken
+        self.flat_p = self.flat_g = self.m = self.v = self.decay = self.gnorm_sq = None
+        self.names: List[str] = []
+        self.offsets = {}
+
+    # -- arena -----------------------------------------------------------------
+    def _build(self):
+        named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad and p.grad is not None]
+        assert named, "FlatAdamW.step() before any backward"
+        dev = named[0][1].device
+        L.require_gpu(named[0][1])
+        total, offs = 0, {}
+        for n, p in named:
+            offs[n] = total
+            total += (p.numel() + 3) // 4 * 4            # keep every tensor 16-byte aligned
+        self.flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.m = torch.zeros_like(self.flat_p)
+        self.v = torch.zeros_like(self.flat_p)
+        dec = torch.zeros(total, device=dev, dtype=torch.uint8)
+        for n, p in named:
+            o, k = offs[n], p.numel()
+            self.flat_p[o:o + k].copy_(p.data.reshape(-1))
+            self.flat_g[o:o + k].copy_(p.grad.reshape(-1))
+            p.data = self.flat_p[o:o + k].view(p.shape)
+            p.grad = self.flat_g[o:o + k].view(p.shape)
+            if not any(nd in n for nd in NO_DECAY):
+                dec[o:o + k] = 1
+        self.decay = dec
+        self.gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.names = [n for n, _ in named]
+        self.offsets = offs
+
+    @property
+    def grad_arena(self) -> torch.Tensor:
+        return self.flat_g
+
+    def zero_grad(self):
+        if self.flat_g is None:
+            for p in self.model.parameters():
+                p.grad = None
+        else:
+            self.flat_g.zero_()       # p.grad stay views: autograd accumulates in place
+
+    def lr(self) -> float:
+        return self.base_lr * self.sched(self.t)
+
+    def step(self):
+        if self.flat_p is None:
+            self._build()
+        lib, st = L.lib(), L.stream_ptr()
+        self.gnorm_sq.zero_()
+        n = self.flat_p.numel()
+        L.check(lib.vmr_sumsq(self.flat_g.data_ptr(), self.gnorm_sq.data_ptr(), n, st), "vmr_sumsq")
+        L.check(lib.vmr_adamw(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                              self.decay.data_ptr(), None, self.gnorm_sq.data_ptr(), self.max_norm, self.lr(),
+                              self.betas[0], self.betas[1], self.eps, self.wd, self.t + 1, n, st), "vmr_adamw")
+        self.t += 1                  # scheduler.step() of the reference loop
+        if hasattr(self.model, "_cache"):   # the masters changed under the compute-dtype weight cache
+            self.model._cache.clear()
+
+    def grad_norm(self) -> float:
+        return float(self.gnorm_sq.sqrt().item())
