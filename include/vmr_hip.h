@@ -33,6 +33,7 @@ extern "C" {
 
 int vmr_version(void);
 const char* vmr_last_error(void);
+int vmr_sizeof_gemm_desc(void); /* ABI guard for foreign-language bindings of vmr_gemm_t */
 
 /* ------------------------------------------------------------------ GEMM
  * C[z] = epilogue(alpha * opA(A[z]) . opB(B[z]))

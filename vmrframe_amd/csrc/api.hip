@@ -15,3 +15,4 @@ int vmr_fail(int code, const char* fmt, ...) {
 
 extern "C" int vmr_version(void) { return 100; }
 extern "C" const char* vmr_last_error(void) { return g_vmr_err; }
+extern "C" int vmr_sizeof_gemm_desc(void) { return (int)sizeof(vmr_gemm_t); }

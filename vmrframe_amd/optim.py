@@ -31,32 +31,21 @@ def linear_warmup_lambda(num_warmup_steps: float, num_training_steps: int):
     return f
 
 
-class FlatAdamW:
-    def __init__(self, model: torch.nn.Module, lr: float, weight_decay: float = 0.01, betas=(0.9, 0.999),
-                 eps: float = 1e-8, max_norm: float = 1.0, warmup_steps: float = 0.0, total_steps: int = 0):
-        self.model = model
-        self.base_lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
-        self.sched = linear_warmup_lambda(warmup_steps, total_steps) if total_steps > 0 else (lambda s: 1.0)
-        self.t = 0                 # optimizer steps taken
-        self.flat_p = self.flat_g = self.m = self.v = self.decay = self.gnorm_sq = None
-        self.names: List[str] = []
-        self.offsets = {}
+class FlatArena:
+    """Contiguous fp32 parameter / gradient arenas over the parameters that receive
+    gradients (device-agnostic: pure tensor plumbing, also used by the gloo DP tests)."""
 
-    # -- arena -----------------------------------------------------------------
-    def _build(self):
-        named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad and p.grad is not None]
-        assert named, "FlatAdamW.step() before any backward"
+    def __init__(self, model: torch.nn.Module):
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None]
+        assert named, "FlatArena needs one backward pass first (to learn which parameters get gradients)"
         dev = named[0][1].device
-        L.require_gpu(named[0][1])
         total, offs = 0, {}
         for n, p in named:
             offs[n] = total
             total += (p.numel() + 3) // 4 * 4            # keep every tensor 16-byte aligned
         self.flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros_like(self.flat_p)
-        self.m = torch.zeros_like(self.flat_p)
-        self.v = torch.zeros_like(self.flat_p)
-        dec = torch.zeros(total, device=dev, dtype=torch.uint8)
+        self.decay = torch.zeros(total, device=dev, dtype=torch.uint8)
         for n, p in named:
             o, k = offs[n], p.numel()
             self.flat_p[o:o + k].copy_(p.data.reshape(-1))
@@ -64,35 +53,61 @@ class FlatAdamW:
             p.data = self.flat_p[o:o + k].view(p.shape)
             p.grad = self.flat_g[o:o + k].view(p.shape)
             if not any(nd in n for nd in NO_DECAY):
-                dec[o:o + k] = 1
-        self.decay = dec
-        self.gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float32)
-        self.names = [n for n, _ in named]
+                self.decay[o:o + k] = 1
+        self.names: List[str] = [n for n, _ in named]
         self.offsets = offs
 
+
+class FlatAdamW:
+    def __init__(self, model: torch.nn.Module, lr: float, weight_decay: float = 0.01, betas=(0.9, 0.999),
+                 eps: float = 1e-8, max_norm: float = 1.0, warmup_steps: float = 0.0, total_steps: int = 0):
+        self.model = model
+        self.base_lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.sched = linear_warmup_lambda(warmup_steps, total_steps) if total_steps > 0 else (lambda s: 1.0)
+        self.t = 0                 # optimizer steps taken
+        self.arena = None
+        self.m = self.v = self.gnorm_sq = None
+
+    # -- arena -----------------------------------------------------------------
+    def _build(self):
+        self.arena = FlatArena(self.model)
+        L.require_gpu(self.arena.flat_p)
+        self.m = torch.zeros_like(self.arena.flat_p)
+        self.v = torch.zeros_like(self.arena.flat_p)
+        self.gnorm_sq = torch.zeros(1, device=self.arena.flat_p.device, dtype=torch.float32)
+
     @property
-    def grad_arena(self) -> torch.Tensor:
-        return self.flat_g
+    def grad_arena(self):
+        return None if self.arena is None else self.arena.flat_g
+
+    @property
+    def names(self):
+        return self.arena.names
+
+    @property
+    def offsets(self):
+        return self.arena.offsets
 
     def zero_grad(self):
-        if self.flat_g is None:
+        if self.arena is None:
             for p in self.model.parameters():
                 p.grad = None
         else:
-            self.flat_g.zero_()       # p.grad stay views: autograd accumulates in place
+            self.arena.flat_g.zero_()       # p.grad stay views: autograd accumulates in place
 
     def lr(self) -> float:
         return self.base_lr * self.sched(self.t)
 
     def step(self):
-        if self.flat_p is None:
+        if self.arena is None:
             self._build()
+        A = self.arena
         lib, st = L.lib(), L.stream_ptr()
         self.gnorm_sq.zero_()
-        n = self.flat_p.numel()
-        L.check(lib.vmr_sumsq(self.flat_g.data_ptr(), self.gnorm_sq.data_ptr(), n, st), "vmr_sumsq")
-        L.check(lib.vmr_adamw(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                              self.decay.data_ptr(), None, self.gnorm_sq.data_ptr(), self.max_norm, self.lr(),
+        n = A.flat_p.numel()
+        L.check(lib.vmr_sumsq(A.flat_g.data_ptr(), self.gnorm_sq.data_ptr(), n, st), "vmr_sumsq")
+        L.check(lib.vmr_adamw(A.flat_p.data_ptr(), A.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                              A.decay.data_ptr(), None, self.gnorm_sq.data_ptr(), self.max_norm, self.lr(),
                               self.betas[0], self.betas[1], self.eps, self.wd, self.t + 1, n, st), "vmr_adamw")
         self.t += 1                  # scheduler.step() of the reference loop
         if hasattr(self.model, "_cache"):   # the masters changed under the compute-dtype weight cache
