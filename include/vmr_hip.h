@@ -75,7 +75,7 @@ typedef struct {
   int32_t splitk; /* >1 requires VMR_EPI_ACCUM */
   float drop_p;
   uint32_t drop_seed;
-  uint32_t _pad;
+  uint32_t drop_row0; /* added to the row index of the dropout counter (a GEMM split by rows) */
   const uint32_t* drop_step; /* nullable device counter mixed into the seed (hipGraph replay) */
 } vmr_gemm_t;
 
@@ -92,11 +92,15 @@ int vmr_layernorm_fwd(const void* x, const float* gamma, const float* beta, floa
                       const uint32_t* drop_step, void* stream);
 /* dx = LN backward of dy (dropout mask regenerated from the seed), optionally
  * dx += dres (gradient arriving through a residual branch); dgamma/dbeta are
- * ACCUMULATED (fp32 atomics) and must be zeroed by the caller when needed.
- * dpos (optional, fp32 [S,D]) accumulates the positional-table gradient. */
+ * ACCUMULATED (+=, two-stage reduction through `workspace`, fp32
+ * VMR_LN_BWD_WS_FLOATS(D) floats, caller-owned scratch) and must be zeroed by the
+ * caller when needed.  dpos (optional, fp32 [S,D]) accumulates the
+ * positional-table gradient. */
+#define VMR_LN_BWD_MAX_BLOCKS 768
+#define VMR_LN_BWD_WS_FLOATS(D) ((int64_t)VMR_LN_BWD_MAX_BLOCKS * 2 * (D))
 int vmr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                       const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                      float* dpos, int S, int64_t rows, int D, int dtype, float drop_p,
+                      float* dpos, float* workspace, int S, int64_t rows, int D, int dtype, float drop_p,
                       uint32_t drop_seed, const uint32_t* drop_step, void* stream);
 
 /* ------------------------------------------ fused LayerNorm + depthwise conv
@@ -108,10 +112,11 @@ int vmr_ln_dwconv_fwd(const void* x, const float* gamma, const float* beta, floa
                       int B, int S, int D, int dtype, void* stream);
 /* backward of the depthwise conv alone: dn = conv^T(du); dw += sum du*n where
  * n = LN(x) is recomputed from x, mean, rstd.  dn then goes to
- * vmr_layernorm_bwd. dw is accumulated with fp32 atomics. */
+ * vmr_layernorm_bwd. dw is accumulated (+=) through `workspace` (fp32 [B, D*7]
+ * caller-owned scratch: per-sample partials, then one reduction). */
 int vmr_dwconv_bwd(const void* du, const void* x, const float* gamma, const float* beta,
                    const float* mean, const float* rstd, const float* w, void* dn, float* dw,
-                   int B, int S, int D, int dtype, void* stream);
+                   float* workspace, int B, int S, int D, int dtype, void* stream);
 
 /* ----------------------------------------------------------- masked softmax
  * P[z,r,:] = softmax_c( scale*S[z,r,c] + term ) with dropout on P.
@@ -158,6 +163,13 @@ int vmr_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t r
 int vmr_relu_bwd_bias(int mode, const void* dy, const void* h, void* dz, float* db, int64_t rows,
                       int D, int64_t ld, float scale, int dtype, float drop_p, uint32_t drop_seed,
                       const uint32_t* drop_step, void* stream);
+/* out[i,:] = table[idx[i],:] (fp32): WordEmbedding / CharacterEmbedding lookups
+ * (layers.py:42-48,66).  bwd: dtable[idx[i],:] += dout[i,:] for idx != padding_idx
+ * (dtable accumulated with float atomics; the caller zeroes it). */
+int vmr_embedding_fwd(const int64_t* idx, const float* table, float* out, int64_t n, int D,
+                      int64_t nrows, void* stream);
+int vmr_embedding_bwd(const int64_t* idx, const float* dout, float* dtable, int64_t n, int D,
+                      int64_t nrows, int64_t padding_idx, void* stream);
 /* dropout mask materialisation (tests): m[i] = keep(seed,i) ? 1/(1-p) : 0 */
 int vmr_dropout_mask(float* m, int64_t n, float drop_p, uint32_t seed, void* stream);
 
@@ -169,7 +181,9 @@ int vmr_dropout_mask(float* m, int64_t n, float drop_p, uint32_t seed, void* str
 int vmr_sumsq(const float* g, float* out /*[1], accumulated*/, int64_t n, void* stream);
 int vmr_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay, void* p_bf16,
               const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
-              float wd, int step, int64_t n, void* stream);
+              float wd, int step, const float* lr_dev /*nullable: overrides lr*/,
+              const int* step_dev /*nullable: 0-based step count on the device, overrides step*/,
+              int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

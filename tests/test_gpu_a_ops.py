@@ -43,6 +43,37 @@ def test_gemm_exact_integer_all_layouts(dev, dt, shape):
             assert torch.equal(out, ref), (dt, shape, ta, tb)
 
 
+@pytest.mark.parametrize("shape", [(512, 256, 128), (768, 384, 192), (9472, 1024, 128), (1024, 1024, 2368)])
+def test_gemm_lds_dma_kernels_exact(dev, shape):
+    """The interior LDS-DMA kernels (256x128 and 128x128 tiles, all four layouts), including the
+    ragged-M split ([8192 | 1280] rows -> big tiles + small tiles) and a fused epilogue with dropout
+    whose counter must stay row-consistent across the split."""
+    ops = _ops()
+    from vmrframe_amd import _lib as L
+    M, N, K = shape
+    torch.manual_seed(M + N + K)
+    dt = torch.bfloat16
+    for ta in (0, 1):
+        for tb in (0, 1):
+            A = _ints(K, M, dt, dev) if ta else _ints(M, K, dt, dev)
+            B = _ints(K, N, dt, dev) if tb else _ints(N, K, dt, dev)
+            ref = (A.float().t() if ta else A.float()) @ (B.float() if tb else B.float().t())
+            out = ops.mm(A, B, ta, tb, out_f32=True)
+            assert torch.equal(out, ref), (shape, ta, tb)
+    A, B = _ints(M, K, dt, dev), _ints(N, K, dt, dev)
+    res = _ints(M, N, dt, dev)
+    rs = torch.rand(M, device=dev)
+    o32 = torch.empty(M, N, device=dev)
+    ops.gemm(A, B, o32, M, N, K, 0, 0, K, K, N, dtype=L.BF16, residual=res, ldr=N, rowscale=rs,
+             flags=L.EPI_DROPOUT | L.EPI_OUT_F32 | L.EPI_RESIDUAL | L.EPI_ROWSCALE, drop=(0.25, 5, None))
+    mask = ops.dropout_mask(M * N, 0.25, 5, dev).view(M, N)
+    ref = ((A.float() @ B.float().t()) * mask + res.float()) * rs[:, None]
+    assert torch.allclose(o32, ref, atol=1e-3, rtol=1e-5)
+    acc = torch.ones(M, N, device=dev)
+    ops.gemm(A, B, acc, M, N, K, 0, 0, K, K, N, dtype=L.BF16, flags=L.EPI_ACCUM, splitk=2 if K >= 256 else 1)
+    assert torch.equal(acc - 1, A.float() @ B.float().t())
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_gemm_epilogue_splitk_dropout(dev, dt):
     ops = _ops()

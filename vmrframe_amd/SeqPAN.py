@@ -252,8 +252,8 @@ class SeqPAN(nn.Module):
         pre = "text_encoder."
         table = torch.cat([self.P(pre + "word_emb.pad_vec"), self.P(pre + "word_emb.unk_vec"),
                            self.P(pre + "word_emb.glove_vec")], 0)
-        wemb = F.embedding(word_ids, table, padding_idx=0)
-        cemb = F.embedding(char_ids, self.P(pre + "char_emb.char_emb.weight"), padding_idx=0)   # [B,L,C,cd]
+        wemb = ops.embedding(word_ids, table, 0)
+        cemb = ops.embedding(char_ids, self.P(pre + "char_emb.char_emb.weight"), 0)              # [B,L,C,cd]
         if dc.p > 0:
             wemb = F.dropout(wemb, dc.p, True)
             cemb = F.dropout(cemb, dc.p, True)

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvmr_hip.so")
 
 F32, BF16 = 0, 1
+LN_BWD_MAX_BLOCKS = 768   # == VMR_LN_BWD_MAX_BLOCKS
 
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_AUX, EPI_OUT_F32, EPI_ACCUM, EPI_ROWSCALE = \
     1, 2, 4, 8, 16, 32, 64, 128
@@ -33,7 +34,7 @@ class GemmDesc(C.Structure):
                 ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64),
                 ("sC1", C.c_int64), ("sC2", C.c_int64),
                 ("splitk", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
-                ("_pad", C.c_uint32), ("drop_step", C.c_void_p)]
+                ("drop_row0", C.c_uint32), ("drop_step", C.c_void_p)]
 
 
 _lib = None
@@ -43,9 +44,9 @@ _P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 SIGNATURES = {
     "vmr_gemm": [C.POINTER(GemmDesc), _P],
     "vmr_layernorm_fwd": [_P, _P, _P, _F, _P, _I, _P, _P, _P, _L, _I, _I, _F, _U, _P, _P],
-    "vmr_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _U, _P, _P],
+    "vmr_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _U, _P, _P],
     "vmr_ln_dwconv_fwd": [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "vmr_dwconv_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vmr_dwconv_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vmr_softmax_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _F, _U, _P, _P],
     "vmr_softmax_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U, _P, _P],
     "vmr_soft_ce_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
@@ -53,8 +54,10 @@ SIGNATURES = {
     "vmr_cast": [_P, _I, _P, _I, _L, _I, _L, _L, _F, _U, _P, _P],
     "vmr_relu_bwd_bias": [_I, _P, _P, _P, _P, _L, _I, _L, _F, _I, _F, _U, _P, _P],
     "vmr_dropout_mask": [_P, _L, _F, _U, _P],
+    "vmr_embedding_fwd": [_P, _P, _P, _L, _I, _L, _P],
+    "vmr_embedding_bwd": [_P, _P, _P, _L, _I, _L, _L, _P],
     "vmr_sumsq": [_P, _P, _L, _P],
-    "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _L, _P],
+    "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P, _P, _L, _P],
 }
 
 

@@ -18,13 +18,15 @@
 // The epilogue goes through LDS so bias/ReLU/dropout/residual/aux traffic is
 // 16-B coalesced.  blockIdx -> tile mapping is XCD-aware (tiles that share an A
 // row-panel run on one XCD / one L2).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128;
 constexpr int CST_LD = 132;                    // fp32 staging row stride (floats)
-constexpr int SMEM_BYTES = BM * CST_LD * 4;    // 67,584 B (>= 2 stages of A+B)
+constexpr int CST_BYTES = 64 * CST_LD * 4;     // epilogue staging: HALF a tile (64 rows) at a time = 33,792 B
 
 struct TileCoord {
   int tm, tn, zb, ks;
@@ -52,16 +54,20 @@ __device__ __forceinline__ TileCoord tile_coord(const vmr_gemm_t& g, int tiles_m
 __device__ __forceinline__ int swz_tr(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
 // ------------------------------------------------------------------ epilogue
-template <typename T, bool ALIGNED>
-__device__ __forceinline__ void epilogue(const vmr_gemm_t& g, float* cst, int m0, int n0, int zb,
-                                         T* __restrict__ C, const T* __restrict__ Rsd, T* __restrict__ Aux) {
+// The accumulators go through LDS one 64-row half tile at a time (33 KiB, so the
+// epilogue never decides the workgroup's LDS footprint): the two waves that own
+// the half stage it as fp32, then all 256 threads apply bias / ReLU / dropout /
+// aux / residual / row-mask with 16-byte coalesced global accesses.
+template <typename T, bool ALIGNED, int NT = 256, int ROWS = 64>
+__device__ __forceinline__ void epilogue_half(const vmr_gemm_t& g, const float* cst, int m0, int n0, int zb,
+                                              T* __restrict__ C, const T* __restrict__ Rsd, T* __restrict__ Aux) {
   const int tid = threadIdx.x;
   const int flags = g.flags;
   if (flags & VMR_EPI_ACCUM) {
     float* Cf = reinterpret_cast<float*>(C);
     // 256 contiguous bytes per wave-instruction: the fast shape for float atomics
-    for (int pass = 0; pass < 32; ++pass) {
-      const int row = pass * 4 + (tid >> 6);
+    for (int pass = 0; pass < ROWS / (NT / 64); ++pass) {
+      const int row = pass * (NT / 64) + (tid >> 6);
       const int gm = m0 + row;
       if (gm >= g.M) continue;
 #pragma unroll
@@ -77,8 +83,8 @@ __device__ __forceinline__ void epilogue(const vmr_gemm_t& g, float* cst, int m0
   const float dscale = (flags & VMR_EPI_DROPOUT) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
   const uint32_t seed = vmr_seed(g.drop_seed, g.drop_step);
   const bool out_f32 = (flags & VMR_EPI_OUT_F32) != 0;
-  for (int pass = 0; pass < 8; ++pass) {
-    const int row = pass * 16 + (tid >> 4);
+  for (int pass = 0; pass < ROWS / (NT / 16); ++pass) {
+    const int row = pass * (NT / 16) + (tid >> 4);
     const int col = (tid & 15) * 8;
     const int gm = m0 + row, gn = n0 + col;
     if (gm >= g.M || gn >= g.N) continue;
@@ -90,15 +96,21 @@ __device__ __forceinline__ void epilogue(const vmr_gemm_t& g, float* cst, int m0
       for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
     }
     const int nvalid = min(8, g.N - gn);
+    uint32_t keep = 0xFFu;
+    if (flags & VMR_EPI_DROPOUT) {
+      const uint64_t idx0 = ((uint64_t)zb * g.M + gm + g.drop_row0) * (uint64_t)g.N + (uint64_t)gn;
+      if ((g.N & 7) == 0) keep = vmr_keep8(seed, idx0, thresh);   // gn is a multiple of 8
+      else {
+        keep = 0;
+        for (int e = 0; e < 8; ++e) keep |= (uint32_t)vmr_keep(seed, idx0 + e, thresh) << e;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float x = v[e] * g.alpha;
       if ((flags & VMR_EPI_BIAS) && e < nvalid) x += g.bias[gn + e];
       if (flags & VMR_EPI_RELU) x = fmaxf(x, 0.0f);
-      if (flags & VMR_EPI_DROPOUT) {
-        const uint64_t idx = ((uint64_t)zb * g.M + gm) * (uint64_t)g.N + (uint64_t)(gn + e);
-        x = vmr_keep(seed, idx, thresh) ? x * dscale : 0.0f;
-      }
+      if (flags & VMR_EPI_DROPOUT) x = ((keep >> e) & 1) ? x * dscale : 0.0f;
       v[e] = x;
     }
     const bool vec = ALIGNED && nvalid == 8;
@@ -135,35 +147,62 @@ __device__ __forceinline__ void epilogue(const vmr_gemm_t& g, float* cst, int m0
   }
 }
 
-__device__ __forceinline__ void stage_acc(float* cst, const f32x4 (&acc)[4][4], int wm, int wn, int lane) {
+// caller has passed the barrier that ends the K loop
+template <typename T, bool ALIGNED, bool FULL = false>
+__device__ __forceinline__ void epilogue(const vmr_gemm_t& g, float* cst, const f32x4 (&acc)[4][4], int wm, int wn,
+                                         int lane, int m0, int n0, int zb, T* __restrict__ C,
+                                         const T* __restrict__ Rsd, T* __restrict__ Aux) {
+  if (FULL) {  // the kernel owns >= 128*132*4 B of LDS: stage the whole tile at once (one barrier)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        cst[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * CST_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+        for (int r = 0; r < 4; ++r)
+          cst[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * CST_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+    epilogue_half<T, ALIGNED, 256, 128>(g, cst, m0, n0, zb, C, Rsd, Aux);
+    return;
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            cst[(i * 16 + (lane >> 4) * 4 + r) * CST_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+    __syncthreads();
+    epilogue_half<T, ALIGNED>(g, cst, m0 + half * 64, n0, zb, C, Rsd, Aux);
+    if (half == 0) __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------- bf16 kernel
-constexpr int BK16 = 64;                      // bf16 K-step
-constexpr int OP_BYTES16 = 128 * BK16 * 2;    // 16 KiB per operand per stage
+// BK = 64: 2 x 32 KiB of staging -> 2 workgroups / CU.
+// BK = 32: 2 x 16 KiB            -> LDS allows 4 / CU, registers 3 / CU: 768 resident tiles, so the
+//          592-tile packed-token GEMMs ([9472 x 1024]) run as ONE wave of workgroups instead of two.
+__device__ __forceinline__ int swz_kc32(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
-// Load one operand tile (128 x 64 bf16) into 4 x bf16x8 registers per thread.
-//   KC (k-contiguous):  tile rows = 128 (m or n), 8 chunks of 8 k each
-//   !KC (m/n-contiguous): tile rows = 64 (k), 16 chunks of 8 m each
-template <bool KC, bool ALIGNED>
+// Load one operand tile (128 x BK bf16) into BK/16 x bf16x8 registers per thread.
+//   KC (k-contiguous):  tile rows = 128 (m or n), BK/8 chunks of 8 k each
+//   !KC (m/n-contiguous): tile rows = BK (k), 16 chunks of 8 m each
+template <bool KC, bool ALIGNED, int BK>
 __device__ __forceinline__ void load_operand(const bf16_t* __restrict__ P, int64_t ld, int r0, int R,
-                                             int k0, int k_end, bf16x8 (&reg)[4]) {
+                                             int k0, int k_end, bf16x8 (&reg)[BK / 16]) {
   const int tid = threadIdx.x;
+  constexpr int CPR = BK / 8;  // chunks per row of a k-contiguous tile
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < BK / 16; ++i) {
     const int id = tid + i * 256;
     int row, kk;  // element (index in the m/n space, k index)
     const bf16_t* p;
     bool full, any;
     if (KC) {
-      row = r0 + (id >> 3); kk = k0 + (id & 7) * 8;
+      row = r0 + id / CPR; kk = k0 + (id % CPR) * 8;
       p = P + (int64_t)row * ld + kk;
       any = row < R && kk < k_end;
       full = row < R && kk + 8 <= k_end;
@@ -189,16 +228,17 @@ __device__ __forceinline__ void load_operand(const bf16_t* __restrict__ P, int64
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_operand(unsigned char* lds, const bf16x8 (&reg)[4]) {
+template <bool KC, int BK>
+__device__ __forceinline__ void store_operand(unsigned char* lds, const bf16x8 (&reg)[BK / 16]) {
   const int tid = threadIdx.x;
+  constexpr int CPR = BK / 8;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < BK / 16; ++i) {
     const int id = tid + i * 256;
     int off;
     if (KC) {
-      const int row = id >> 3, c = id & 7;
-      off = row * 128 + ((c ^ (row & 7)) << 4);
+      const int row = id / CPR, c = id % CPR;
+      off = BK == 64 ? row * 128 + ((c ^ (row & 7)) << 4) : row * 64 + ((c ^ swz_kc32(row)) << 4);
     } else {
       const int row = id >> 4, c16 = id & 15;
       off = row * 256 + ((((c16 >> 1) ^ swz_tr(row))) << 5) + ((c16 & 1) << 4);
@@ -207,13 +247,17 @@ __device__ __forceinline__ void store_operand(unsigned char* lds, const bf16x8 (
   }
 }
 
-// fragment for the 16-row (or 16-col) MFMA tile `t16` (0..7 within the 128 tile), k-substep kk (0..1)
-template <bool KC>
+// fragment for the 16-row (or 16-col) MFMA tile `t16` (0..7 within the 128 tile), 32-deep k-substep kk
+template <bool KC, int BK>
 __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int t16, int kk, int lane) {
   if (KC) {
     const int row = t16 * 16 + (lane & 15);
-    const int chunk = kk * 4 + (lane >> 4);
-    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+    if (BK == 64) {
+      const int chunk = kk * 4 + (lane >> 4);
+      return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+    } else {
+      return *reinterpret_cast<const bf16x8*>(lds + row * 64 + (((lane >> 4) ^ swz_kc32(row)) << 4));
+    }
   } else {
     const int g = lane >> 4, ii = lane & 15, q = ii >> 2, p = ii & 3;
     const int r = kk * 32 + 8 * g + q;
@@ -228,9 +272,16 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int t16, i
   }
 }
 
-template <bool TA, bool TB, bool ALIGNED>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
+template <int BK> struct Geom16 {
+  static constexpr int OP_BYTES = 128 * BK * 2;
+  static constexpr int STAGES_BYTES = 4 * OP_BYTES;
+  static constexpr int SMEM = STAGES_BYTES > CST_BYTES ? STAGES_BYTES : CST_BYTES;
+};
+
+template <bool TA, bool TB, bool ALIGNED, int BK>
+__global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_bf16_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int OPB = Geom16<BK>::OP_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const TileCoord tc = tile_coord(g, tiles_m, tiles_n);
@@ -243,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(vmr_gemm_t g, int til
   int k_begin = 0, k_end = g.K;
   if (g.splitk > 1) {
     int chunk = (g.K + g.splitk - 1) / g.splitk;
-    chunk = (chunk + BK16 - 1) / BK16 * BK16;
+    chunk = (chunk + 63) / 64 * 64;
     k_begin = tc.ks * chunk;
     k_end = min(g.K, k_begin + chunk);
   }
@@ -253,31 +304,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(vmr_gemm_t g, int til
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = k_end > k_begin ? (k_end - k_begin + BK16 - 1) / BK16 : 0;
-  bf16x8 ra[4], rb[4];
+  const int nk = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
+  bf16x8 ra[BK / 16], rb[BK / 16];
   if (nk > 0) {
-    load_operand<!TA, ALIGNED>(A, g.lda, m0, g.M, k_begin, k_end, ra);
-    load_operand<!TB, ALIGNED>(B, g.ldb, n0, g.N, k_begin, k_end, rb);
-    store_operand<!TA>(smem, ra);
-    store_operand<!TB>(smem + OP_BYTES16, rb);
+    load_operand<!TA, ALIGNED, BK>(A, g.lda, m0, g.M, k_begin, k_end, ra);
+    load_operand<!TB, ALIGNED, BK>(B, g.ldb, n0, g.N, k_begin, k_end, rb);
+    store_operand<!TA, BK>(smem, ra);
+    store_operand<!TB, BK>(smem + OPB, rb);
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    unsigned char* cur = smem + (kt & 1) * 2 * OP_BYTES16;
-    unsigned char* nxt = smem + ((kt + 1) & 1) * 2 * OP_BYTES16;
+    unsigned char* cur = smem + (kt & 1) * 2 * OPB;
+    unsigned char* nxt = smem + ((kt + 1) & 1) * 2 * OPB;
     const bool more = kt + 1 < nk;
     if (more) {  // issue the next tile's global loads before the MFMAs (latency hides under compute)
-      const int k0 = k_begin + (kt + 1) * BK16;
-      load_operand<!TA, ALIGNED>(A, g.lda, m0, g.M, k0, k_end, ra);
-      load_operand<!TB, ALIGNED>(B, g.ldb, n0, g.N, k0, k_end, rb);
+      const int k0 = k_begin + (kt + 1) * BK;
+      load_operand<!TA, ALIGNED, BK>(A, g.lda, m0, g.M, k0, k_end, ra);
+      load_operand<!TB, ALIGNED, BK>(B, g.ldb, n0, g.N, k0, k_end, rb);
     }
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < BK / 32; ++kk) {
       bf16x8 fa[4], fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag<!TA>(cur, wm * 4 + i, kk, lane);
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag<!TA, BK>(cur, wm * 4 + i, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag<!TB>(cur + OP_BYTES16, wn * 4 + j, kk, lane);
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<!TB, BK>(cur + OPB, wn * 4 + j, kk, lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -285,20 +336,283 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(vmr_gemm_t g, int til
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      store_operand<!TA>(nxt, ra);
-      store_operand<!TB>(nxt + OP_BYTES16, rb);
+      store_operand<!TA, BK>(nxt, ra);
+      store_operand<!TB, BK>(nxt + OPB, rb);
     }
     __syncthreads();
   }
-  float* cst = reinterpret_cast<float*>(smem);
-  stage_acc(cst, acc, wm, wn, lane);
-  __syncthreads();
-  epilogue<bf16_t, ALIGNED>(g, cst, m0, n0, tc.zb,
+  epilogue<bf16_t, ALIGNED>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
                             (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM))
                                 ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
                                 : reinterpret_cast<bf16_t*>(g.C) + coff,
                             reinterpret_cast<const bf16_t*>(g.residual) + coff,
                             reinterpret_cast<bf16_t*>(g.aux) + coff);
+}
+
+// ------------------------------------------------------- bf16 LDS-DMA kernel
+// Interior path (M, N multiples of 128, K-range multiples of 32, 16-byte aligned rows): the
+// operand tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction,
+// no staging VGPRs, no ds_write), through a 4-deep LDS ring (4 x 16 KiB): the loads of K-step
+// t+3 are issued while step t is computed, and each step waits with a COUNTED vmcnt (8 loads of
+// the two later steps stay in flight) + one raw s_barrier, so HBM/L2 latency (~900 cycles) is
+// covered by three K-steps of MFMA instead of stalling every step.  The LDS image is lane-linear
+// per wave-instruction, so the XOR swizzles of the register path are applied to the per-lane SOURCE
+// address (same image, same fragment reads).
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+// one operand tile (128 rows x BK, or BK x 128 for the transposed image) = 128*BK*2 bytes = NB 1-KiB blocks
+template <bool KC, int BK>
+__device__ __forceinline__ void dma_operand(const bf16_t* __restrict__ P, int64_t ld, int r0, int k0,
+                                            unsigned char* lds, int wid, int lane) {
+  constexpr int NB = 128 * BK * 2 / 1024;  // 8 (BK=32) or 16 (BK=64) blocks, NB/4 per wave
+#pragma unroll
+  for (int jj = 0; jj < NB / 4; ++jj) {
+    const int j = wid * (NB / 4) + jj;
+    const bf16_t* src;
+    if (KC) {
+      if (BK == 64) {       // 128-B rows: one wave-instruction = 8 whole rows = 8 full cache lines
+        const int row = 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        src = P + (int64_t)(r0 + row) * ld + k0 + c * 8;
+      } else {              // 64-B rows
+        const int row = 16 * j + (lane >> 2);
+        const int c = (lane & 3) ^ swz_kc32(row);
+        src = P + (int64_t)(r0 + row) * ld + k0 + c * 8;
+      }
+    } else {
+      const int r = 4 * j + (lane >> 4);
+      const int ph16 = lane & 15;
+      const int c32 = (ph16 >> 1) ^ swz_tr(r);
+      src = P + (int64_t)(k0 + r) * ld + r0 + (c32 * 2 + (ph16 & 1)) * 8;
+    }
+    __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)(lds + j * 1024), 16, 0, 0);
+  }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else static_assert(N == 0 || N == 4 || N == 8 || N == 16, "add the immediate");
+}
+
+template <bool TA, bool TB, int BK, int NST>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int OPB = 128 * BK * 2;
+  constexpr int LPS = 2 * (OPB / 1024) / 4;  // loads per wave per K-step (A + B)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const TileCoord tc = tile_coord(g, tiles_m, tiles_n);
+  const int m0 = tc.tm * BM, n0 = tc.tn * BN;
+  const int z1 = tc.zb / g.Z2, z2 = tc.zb - z1 * g.Z2;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
+  const int64_t coff = z1 * g.sC1 + z2 * g.sC2;
+  int k_begin = 0, k_end = g.K;
+  if (g.splitk > 1) {
+    int chunk = (g.K + g.splitk - 1) / g.splitk;
+    chunk = (chunk + 63) / 64 * 64;
+    k_begin = tc.ks * chunk;
+    k_end = min(g.K, k_begin + chunk);
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = k_end > k_begin ? (k_end - k_begin) / BK : 0;
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) {
+    if (s < nk) {
+      dma_operand<!TA, BK>(A, g.lda, m0, k_begin + s * BK, smem + s * 2 * OPB, wid, lane);
+      dma_operand<!TB, BK>(B, g.ldb, n0, k_begin + s * BK, smem + s * 2 * OPB + OPB, wid, lane);
+    }
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's loads of step kt must have landed; those of the later NST-2 steps stay in flight
+    const int later = min(nk - 1 - kt, NST - 2);
+    if (later >= 2) wait_vmcnt<2 * LPS>();
+    else if (later == 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // every wave's part of step kt is in LDS; step kt-1's buffer is free
+    if (kt + NST - 1 < nk) {
+      unsigned char* dst = smem + ((kt + NST - 1) % NST) * 2 * OPB;
+      const int k0 = k_begin + (kt + NST - 1) * BK;
+      dma_operand<!TA, BK>(A, g.lda, m0, k0, dst, wid, lane);
+      dma_operand<!TB, BK>(B, g.ldb, n0, k0, dst + OPB, wid, lane);
+    }
+    const unsigned char* cur = smem + (kt % NST) * 2 * OPB;
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag<!TA, BK>(cur, wm * 4 + i, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<!TB, BK>(cur + OPB, wn * 4 + j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  epilogue<bf16_t, true, true>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
+                         (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM))
+                             ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
+                             : reinterpret_cast<bf16_t*>(g.C) + coff,
+                         reinterpret_cast<const bf16_t*>(g.residual) + coff,
+                         reinterpret_cast<bf16_t*>(g.aux) + coff);
+}
+
+// ------------------------------------------- bf16 LDS-DMA kernel, 256x128 tile
+// 512 threads = 8 waves (4 along M x 2 along N, 64x64 per wave), BK = 64 (whole 128-B lines for
+// k-contiguous operands), 3-stage LDS ring of 48 KiB (144 KiB, one workgroup per CU): the loads
+// of K-step t+2 are issued while step t is computed.  Relative to two 128x128 workgroups on a CU
+// the B tile is fetched once instead of twice (1.33x fewer L2->LDS bytes per flop) and the ring is
+// one stage deeper.  Requires M % 256 == 0, N % 128 == 0, K % 64 == 0 (the host splits ragged M).
+constexpr int BIG_BM = 256, BIG_BK = 64, BIG_NST = 3;
+constexpr int BIG_A_BYTES = BIG_BM * BIG_BK * 2;   // 32 KiB
+constexpr int BIG_B_BYTES = 128 * BIG_BK * 2;      // 16 KiB
+constexpr int BIG_STAGE = BIG_A_BYTES + BIG_B_BYTES;
+constexpr int BIG_SMEM = BIG_NST * BIG_STAGE;      // 147,456 B
+
+// A operand of the 256-row tile: k-contiguous image [256][128 B] or transposed image [64 k][512 B]
+template <bool KC>
+__device__ __forceinline__ void dma_operand_a256(const bf16_t* __restrict__ P, int64_t ld, int r0, int k0,
+                                                 unsigned char* lds, int wid, int lane) {
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int j = wid * 4 + jj;  // 32 blocks of 1 KiB
+    const bf16_t* src;
+    if (KC) {
+      const int row = 8 * j + (lane >> 3);
+      const int c = (lane & 7) ^ (row & 7);
+      src = P + (int64_t)(r0 + row) * ld + k0 + c * 8;
+    } else {
+      const int r = 2 * j + (lane >> 5);
+      const int ph16 = lane & 31;
+      const int c32 = (ph16 >> 1) ^ swz_tr(r);
+      src = P + (int64_t)(k0 + r) * ld + r0 + (c32 * 2 + (ph16 & 1)) * 8;
+    }
+    __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)(lds + j * 1024), 16, 0, 0);
+  }
+}
+// B operand (128 rows / cols): 16 blocks, 2 per wave
+template <bool KC>
+__device__ __forceinline__ void dma_operand_b128(const bf16_t* __restrict__ P, int64_t ld, int r0, int k0,
+                                                 unsigned char* lds, int wid, int lane) {
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = wid * 2 + jj;
+    const bf16_t* src;
+    if (KC) {
+      const int row = 8 * j + (lane >> 3);
+      const int c = (lane & 7) ^ (row & 7);
+      src = P + (int64_t)(r0 + row) * ld + k0 + c * 8;
+    } else {
+      const int r = 4 * j + (lane >> 4);
+      const int ph16 = lane & 15;
+      const int c32 = (ph16 >> 1) ^ swz_tr(r);
+      src = P + (int64_t)(k0 + r) * ld + r0 + (c32 * 2 + (ph16 & 1)) * 8;
+    }
+    __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)(lds + j * 1024), 16, 0, 0);
+  }
+}
+// fragment of the transposed 256-wide A image (512-B rows)
+__device__ __forceinline__ bf16x8 read_frag_tr512(const unsigned char* lds, int t16, int kk, int lane) {
+  const int g = lane >> 4, ii = lane & 15, q = ii >> 2, p = ii & 3;
+  const int r = kk * 32 + 8 * g + q;
+  const int a0 = r * 512 + ((t16 ^ swz_tr(r)) << 5) + p * 8;
+  const int a1 = (r + 4) * 512 + ((t16 ^ swz_tr(r + 4)) << 5) + p * 8;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a1));
+  union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+  u.s.l = lo; u.s.h = hi;
+  return u.v;
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_dma256_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const TileCoord tc = tile_coord(g, tiles_m, tiles_n);
+  const int m0 = tc.tm * BIG_BM, n0 = tc.tn * BN;
+  const int z1 = tc.zb / g.Z2, z2 = tc.zb - z1 * g.Z2;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
+  const int64_t coff = z1 * g.sC1 + z2 * g.sC2;
+  int k_begin = 0, k_end = g.K;
+  if (g.splitk > 1) {
+    int chunk = (g.K + g.splitk - 1) / g.splitk;
+    chunk = (chunk + 63) / 64 * 64;
+    k_begin = tc.ks * chunk;
+    k_end = min(g.K, k_begin + chunk);
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = k_end > k_begin ? (k_end - k_begin) / BIG_BK : 0;
+#pragma unroll
+  for (int s = 0; s < BIG_NST - 1; ++s) {
+    if (s < nk) {
+      dma_operand_a256<!TA>(A, g.lda, m0, k_begin + s * BIG_BK, smem + s * BIG_STAGE, wid, lane);
+      dma_operand_b128<!TB>(B, g.ldb, n0, k_begin + s * BIG_BK, smem + s * BIG_STAGE + BIG_A_BYTES, wid, lane);
+    }
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // step kt landed; kt+1's 6 loads in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + BIG_NST - 1 < nk) {
+      unsigned char* dst = smem + ((kt + BIG_NST - 1) % BIG_NST) * BIG_STAGE;
+      const int k0 = k_begin + (kt + BIG_NST - 1) * BIG_BK;
+      dma_operand_a256<!TA>(A, g.lda, m0, k0, dst, wid, lane);
+      dma_operand_b128<!TB>(B, g.ldb, n0, k0, dst + BIG_A_BYTES, wid, lane);
+    }
+    const unsigned char* cur = smem + (kt % BIG_NST) * BIG_STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[i] = TA ? read_frag_tr512(cur, wm * 4 + i, kk, lane) : read_frag<true, 64>(cur, wm * 4 + i, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<!TB, 64>(cur + BIG_A_BYTES, wn * 4 + j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  // epilogue: the whole 256x128 fp32 tile is staged at once (135 KiB of the 144-KiB ring)
+  float* cst = reinterpret_cast<float*>(smem);
+  bf16_t* Cp = (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM))
+                   ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
+                   : reinterpret_cast<bf16_t*>(g.C) + coff;
+  const bf16_t* Rp = reinterpret_cast<const bf16_t*>(g.residual) + coff;
+  bf16_t* Ap = reinterpret_cast<bf16_t*>(g.aux) + coff;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        cst[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * CST_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+  __syncthreads();
+  epilogue_half<bf16_t, true, 512, 256>(g, cst, m0, n0, tc.zb, Cp, Rp, Ap);
 }
 
 // ----------------------------------------------------------------- f32 kernel
@@ -415,25 +729,65 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(vmr_gemm_t g, int tile
     }
     __syncthreads();
   }
-  stage_acc(lds, acc, wm, wn, lane);
-  __syncthreads();
-  epilogue<float, ALIGNED>(g, lds, m0, n0, tc.zb, reinterpret_cast<float*>(g.C) + coff,
+  epilogue<float, ALIGNED>(g, lds, acc, wm, wn, lane, m0, n0, tc.zb, reinterpret_cast<float*>(g.C) + coff,
                            reinterpret_cast<const float*>(g.residual) + coff,
                            reinterpret_cast<float*>(g.aux) + coff);
 }
 
 typedef void (*gemm_fn)(vmr_gemm_t, int, int);
+constexpr int SMEM_F32 = (4 * OP_FLOATS32 * 4) > CST_BYTES ? (4 * OP_FLOATS32 * 4) : CST_BYTES;
+
+struct Pick {
+  gemm_fn fn;
+  int smem;
+};
 
 template <bool TA, bool TB, bool AL>
-gemm_fn pick_dtype(int dtype) {
-  return dtype == VMR_BF16 ? (gemm_fn)gemm_bf16_kernel<TA, TB, AL> : (gemm_fn)gemm_f32_kernel<TA, TB, AL>;
+Pick pick_dtype(int dtype, int bk) {
+  if (dtype != VMR_BF16) return {(gemm_fn)gemm_f32_kernel<TA, TB, AL>, SMEM_F32};
+  if (bk == 32) return {(gemm_fn)gemm_bf16_kernel<TA, TB, AL, 32>, Geom16<32>::SMEM};
+  return {(gemm_fn)gemm_bf16_kernel<TA, TB, AL, 64>, Geom16<64>::SMEM};
 }
 template <bool AL>
-gemm_fn pick_trans(int ta, int tb, int dtype) {
-  if (!ta && !tb) return pick_dtype<false, false, AL>(dtype);
-  if (!ta && tb) return pick_dtype<false, true, AL>(dtype);
-  if (ta && !tb) return pick_dtype<true, false, AL>(dtype);
-  return pick_dtype<true, true, AL>(dtype);
+Pick pick_trans(int ta, int tb, int dtype, int bk) {
+  if (!ta && !tb) return pick_dtype<false, false, AL>(dtype, bk);
+  if (!ta && tb) return pick_dtype<false, true, AL>(dtype, bk);
+  if (ta && !tb) return pick_dtype<true, false, AL>(dtype, bk);
+  return pick_dtype<true, true, AL>(dtype, bk);
+}
+
+int g_gemm_bk = 0;   // 0 = not read yet; VMR_GEMM_BK=32|64 selects the bf16 K-step of the register-staged path
+int g_gemm_dma = -1;  // VMR_GEMM_DMA: 0 off, 1: 128x128 BK=32 x4, 2: 128x128 BK=64 x2, 3 (default): + 256x128 tile
+
+gemm_fn pick_big(int ta, int tb) {
+  if (!ta && !tb) return (gemm_fn)gemm_bf16_dma256_kernel<false, false>;
+  if (!ta && tb) return (gemm_fn)gemm_bf16_dma256_kernel<false, true>;
+  if (ta && !tb) return (gemm_fn)gemm_bf16_dma256_kernel<true, false>;
+  return (gemm_fn)gemm_bf16_dma256_kernel<true, true>;
+}
+
+int set_big_lds(const void* fn, int bytes) {
+  static thread_local const void* done[48];
+  static thread_local int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done[i] == fn) return 0;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return vmr_fail(-5, "vmr_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  if (ndone < 48) done[ndone++] = fn;
+  return 0;
+}
+
+template <int BK, int NST>
+gemm_fn pick_dma_t(int ta, int tb) {
+  if (!ta && !tb) return (gemm_fn)gemm_bf16_dma_kernel<false, false, BK, NST>;
+  if (!ta && tb) return (gemm_fn)gemm_bf16_dma_kernel<false, true, BK, NST>;
+  if (ta && !tb) return (gemm_fn)gemm_bf16_dma_kernel<true, false, BK, NST>;
+  return (gemm_fn)gemm_bf16_dma_kernel<true, true, BK, NST>;
+}
+Pick pick_dma(int ta, int tb, int variant) {
+  // 64 KiB of stages; 67,584 B so the epilogue can stage the whole fp32 tile in one pass (still 2 / CU)
+  if (variant == 2) return {pick_dma_t<64, 2>(ta, tb), 128 * CST_LD * 4};
+  return {pick_dma_t<32, 4>(ta, tb), 128 * CST_LD * 4};
 }
 
 inline bool mult(int64_t v, int64_t m) { return (v % m) == 0; }
@@ -474,21 +828,74 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
     if (g.flags & VMR_EPI_AUX) al = al && aligned16(g.aux);
   }
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
-  gemm_fn fn = al ? pick_trans<true>(g.transA, g.transB, g.dtype) : pick_trans<false>(g.transA, g.transB, g.dtype);
-  {  // > 64 KiB of dynamic LDS must be opted into once per kernel
-    static thread_local const void* done[16];
+  if (g_gemm_bk == 0) {
+    const char* e = getenv("VMR_GEMM_BK");
+    g_gemm_bk = (e && atoi(e) == 64) ? 64 : 32;
+  }
+  if (g_gemm_dma < 0) {
+    const char* e = getenv("VMR_GEMM_DMA");
+    g_gemm_dma = e ? atoi(e) : 2;
+  }
+  Pick pk = al ? pick_trans<true>(g.transA, g.transB, g.dtype, g_gemm_bk)
+               : pick_trans<false>(g.transA, g.transB, g.dtype, g_gemm_bk);
+  const bool dma_ok = g_gemm_dma && al && g.dtype == VMR_BF16 && g.M % BM == 0 && g.N % BN == 0 && g.K % 64 == 0 &&
+                      g.K >= 128 * g.splitk;
+  if (dma_ok && g_gemm_dma >= 3 && g.M >= 256) {
+    // 256x128 tiles for the rows that fill whole rounds of the 256 CUs; the ragged remainder (e.g. the
+    // 1280 query-token rows of a packed [8192 | 1280] matrix) goes to the 128x128 kernel instead of
+    // costing a second, nearly empty round of big tiles.
+    const int64_t Zb = Z;
+    int big_tm = g.M / 256;
+    const int per_round = 256;
+    const int64_t total = (int64_t)big_tm * tiles_n * Zb;
+    if (total > per_round) {
+      const int64_t full = total / per_round * per_round;          // tiles in whole rounds
+      const int64_t rem_tiles = total - full;
+      if (rem_tiles * 4 < per_round * 3 && !((g.flags & VMR_EPI_DROPOUT) && Zb > 1)) {  // last round < 75 % full: trim it
+        const int keep_tm = (int)(full / ((int64_t)tiles_n * Zb));
+        if (keep_tm > 0) big_tm = keep_tm;
+      }
+    }
+    const int Mbig = big_tm * 256;
+    gemm_fn bf = pick_big(g.transA, g.transB);
+    if (int rc = set_big_lds(reinterpret_cast<const void*>(bf), BIG_SMEM)) return rc;
+    vmr_gemm_t gb = g;
+    gb.M = Mbig;
+    hipLaunchKernelGGL(bf, dim3((unsigned)(big_tm * tiles_n), 1, (unsigned)Z), dim3(512), BIG_SMEM,
+                       (hipStream_t)stream, gb, big_tm, tiles_n);
+    VMR_LAUNCH_CHECK();
+    if (Mbig == g.M) return 0;
+    // remainder rows [Mbig, M): shift the row-indexed pointers
+    const int64_t esz = 2, csz = (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM)) ? 4 : 2;
+    g.A = reinterpret_cast<const char*>(g.A) + (g.transA ? (int64_t)Mbig : (int64_t)Mbig * g.lda) * esz;
+    g.C = reinterpret_cast<char*>(g.C) + (int64_t)Mbig * g.ldc * csz;
+    if (g.residual) g.residual = reinterpret_cast<const char*>(g.residual) + (int64_t)Mbig * g.ldr * esz;
+    if (g.aux) g.aux = reinterpret_cast<char*>(g.aux) + (int64_t)Mbig * g.ldr * esz;
+    if (g.rowscale) g.rowscale += Mbig;
+    g.M -= Mbig;
+    g.drop_row0 += Mbig;
+    const int tm2 = cdiv(g.M, BM);
+    const Pick p2 = pick_dma(g.transA, g.transB, 2);
+    hipLaunchKernelGGL(p2.fn, dim3((unsigned)(tm2 * tiles_n), 1, (unsigned)Z), dim3(256), p2.smem,
+                       (hipStream_t)stream, g, tm2, tiles_n);
+    VMR_LAUNCH_CHECK();
+    return 0;
+  }
+  if (dma_ok) pk = pick_dma(g.transA, g.transB, g_gemm_dma >= 2 ? 2 : 1);
+  if (pk.smem > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into once per kernel
+    static thread_local const void* done[32];
     static thread_local int ndone = 0;
     bool seen = false;
-    for (int i = 0; i < ndone; ++i) seen = seen || done[i] == reinterpret_cast<const void*>(fn);
+    for (int i = 0; i < ndone; ++i) seen = seen || done[i] == reinterpret_cast<const void*>(pk.fn);
     if (!seen) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk.fn),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, pk.smem);
       if (e != hipSuccess) return vmr_fail(-5, "vmr_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      if (ndone < 16) done[ndone++] = reinterpret_cast<const void*>(fn);
+      if (ndone < 32) done[ndone++] = reinterpret_cast<const void*>(pk.fn);
     }
   }
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)Z);
-  hipLaunchKernelGGL(fn, grid, dim3(256), SMEM_BYTES, (hipStream_t)stream, g, tiles_m, tiles_n);
+  hipLaunchKernelGGL(pk.fn, grid, dim3(256), pk.smem, (hipStream_t)stream, g, tiles_m, tiles_n);
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -60,9 +60,9 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const T* __restrict_
         for (int e = 0; e < 8; ++e) g[e] = hv[e] > 0.f ? g[e] * scale : 0.f;
         Vec8<T>::store(dz + r * ld + c0, g);
       } else if (MODE == 2) {
+        const uint32_t keep = vmr_keep8(seed, (uint64_t)r * D + c0, thresh);
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          g[e] = vmr_keep(seed, (uint64_t)r * D + c0 + e, thresh) ? g[e] * scale : 0.f;
+        for (int e = 0; e < 8; ++e) g[e] = ((keep >> e) & 1) ? g[e] * scale : 0.f;
         Vec8<T>::store(dz + r * ld + c0, g);
       }
 #pragma unroll
@@ -88,6 +88,33 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ m
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     m[i] = (drop_p > 0.f ? vmr_keep(seed, (uint64_t)i, thresh) : true) ? dscale : 0.f;
+}
+
+// ------------------------------------------------------- embedding gather
+// out[i,:] = table[idx[i],:]  (reference WordEmbedding / CharacterEmbedding lookups,
+// models/layers.py:42-48,66); backward: dtable[idx[i],:] += dout[i,:] for idx != padding_idx
+// (nn.Embedding(padding_idx=0) semantics).  One wave per looked-up row; fp32; float atomics.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restrict__ idx,
+                                                          const float* __restrict__ table, float* __restrict__ out,
+                                                          int64_t n, int D, int64_t nrows) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
+    int64_t r = idx[i];
+    r = r < 0 ? 0 : (r >= nrows ? nrows - 1 : r);   // never read outside the table
+    for (int c = lane; c < D; c += 64) out[i * D + c] = table[r * D + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const int64_t* __restrict__ idx,
+                                                               const float* __restrict__ dout,
+                                                               float* __restrict__ dtable, int64_t n, int D,
+                                                               int64_t nrows, int64_t padding_idx) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
+    const int64_t r = idx[i];
+    if (r == padding_idx || r < 0 || r >= nrows) continue;
+    for (int c = lane; c < D; c += 64) atomicAdd(&dtable[r * D + c], dout[i * D + c]);
+  }
 }
 
 // -------------------------------------------- boundary-label cross-entropy
@@ -165,7 +192,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     const uint8_t* __restrict__ decay, bf16_t* __restrict__ pb,
                                                     const float* __restrict__ gnorm_sq, float max_norm, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1,
-                                                    float bc2, int64_t n) {
+                                                    float bc2, const float* __restrict__ lr_dev,
+                                                    const int* __restrict__ step_dev, int64_t n) {
+  if (lr_dev) lr = lr_dev[0];                 // device-resident schedule: a captured hipGraph replays
+  if (step_dev) {                             // with the current lr / bias corrections
+    const float t = (float)(step_dev[0] + 1);
+    bc1 = 1.f - powf(beta1, t);
+    bc2 = 1.f - powf(beta2, t);
+  }
   float clip = 1.f;
   if (gnorm_sq && max_norm > 0.f) {
     const float nrm = sqrtf(gnorm_sq[0]);
@@ -293,13 +327,34 @@ extern "C" int vmr_sumsq(const float* g, float* out, int64_t n, void* stream) {
 
 extern "C" int vmr_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay, void* p_bf16,
                          const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
-                         float wd, int step, int64_t n, void* stream) {
+                         float wd, int step, const float* lr_dev, const int* step_dev, int64_t n, void* stream) {
   VMR_CHECK(p && g && m && v && decay, "vmr_adamw: null pointer");
-  VMR_CHECK(step >= 1, "vmr_adamw: step starts at 1");
+  VMR_CHECK(step >= 1 || step_dev, "vmr_adamw: step starts at 1");
   if (n == 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3((int)min((int64_t)4096, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     p, g, m, v, decay, (bf16_t*)p_bf16, gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, n);
+                     p, g, m, v, decay, (bf16_t*)p_bf16, gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, lr_dev,
+                     step_dev, n);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_embedding_fwd(const int64_t* idx, const float* table, float* out, int64_t n, int D, int64_t nrows,
+                                 void* stream) {
+  VMR_CHECK(idx && table && out && nrows > 0, "vmr_embedding_fwd: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((int)min((int64_t)4096, (n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     idx, table, out, n, D, nrows);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_embedding_bwd(const int64_t* idx, const float* dout, float* dtable, int64_t n, int D, int64_t nrows,
+                                 int64_t padding_idx, void* stream) {
+  VMR_CHECK(idx && dout && dtable && nrows > 0, "vmr_embedding_bwd: null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((int)min((int64_t)4096, (n + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, idx, dout, dtable, n, D, nrows, padding_idx);
   VMR_LAUNCH_CHECK();
   return 0;
 }

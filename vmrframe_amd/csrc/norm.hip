@@ -12,9 +12,10 @@
 
 namespace {
 
-constexpr int MAXC = 4;  // chunks of 8 elements per lane => D <= 64*8*4 = 2048
+constexpr int MAXC_MAX = 4;  // chunks of 8 elements per lane => D <= 64*8*4 = 2048 (kernels are
+                             // instantiated for 1/2/4 chunks so D <= 1024 rows cost half the registers)
 
-template <typename T>
+template <typename T, int MAXC>
 __device__ __forceinline__ void load_row(const T* __restrict__ p, int D, int lane, float (&v)[MAXC][8]) {
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
@@ -27,6 +28,7 @@ __device__ __forceinline__ void load_row(const T* __restrict__ p, int D, int lan
   }
 }
 
+template <int MAXC>
 __device__ __forceinline__ void row_stats(const float (&v)[MAXC][8], int D, int lane, float eps, float& mean,
                                           float& rstd) {
   float s = 0.f;
@@ -48,7 +50,7 @@ __device__ __forceinline__ void row_stats(const float (&v)[MAXC][8], int D, int 
 }
 
 // ------------------------------------------------------------ LayerNorm fwd
-template <typename T>
+template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps,
                                                      const T* __restrict__ pos, int S, T* __restrict__ y,
@@ -61,9 +63,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
     float v[MAXC][8];
-    load_row<T>(x + row * D, D, lane, v);
+    load_row<T, MAXC>(x + row * D, D, lane, v);
     float mean, rstd;
-    row_stats(v, D, lane, eps, mean, rstd);
+    row_stats<MAXC>(v, D, lane, eps, mean, rstd);
     if (lane == 0) {
       if (mean_o) mean_o[row] = mean;
       if (rstd_o) rstd_o[row] = rstd;
@@ -84,9 +86,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         for (int e = 0; e < 8; ++e) o[e] += pv[e];
       }
       if (drop_p > 0.f) {
+        const uint32_t keep = vmr_keep8(seed, (uint64_t)row * D + i, thresh);
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          o[e] = vmr_keep(seed, (uint64_t)row * D + i + e, thresh) ? o[e] * dscale : 0.f;
+        for (int e = 0; e < 8; ++e) o[e] = ((keep >> e) & 1) ? o[e] * dscale : 0.f;
       }
       Vec8<T>::store(y + row * D + i, o);
     }
@@ -94,15 +96,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 }
 
 // ------------------------------------------------------------ LayerNorm bwd
-// dgamma/dbeta partials are kept per lane across the rows a wave visits, combined
-// across the 4 waves through LDS and flushed with contiguous float atomics.
-template <typename T>
+// One wave per row, two rows in flight per wave (the loads of the next row are issued before the
+// current row's reductions), gamma held in registers.  dgamma/dbeta partials are kept per lane
+// across the rows a wave visits, combined across the 4 waves through LDS and flushed with
+// contiguous float atomics.
+template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const T* __restrict__ dres,
-                                                     T* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, float* __restrict__ dpos, int S,
+                                                     T* __restrict__ dx, float* __restrict__ part,
+                                                     float* __restrict__ dpos, int S,
                                                      int64_t rows, int D, float drop_p, uint32_t seed0,
                                                      const uint32_t* __restrict__ step) {
   const uint32_t seed = vmr_seed(seed0, step);
@@ -111,32 +115,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const uint32_t thresh = vmr_drop_thresh(drop_p);
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  float ag[MAXC][8], ab[MAXC][8];
+  float ag[MAXC][8], ab[MAXC][8], gm[MAXC][8];
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c)
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * 64 + lane) * 8;
+    if (i < D) Vec8<float>::load(gamma + i, gm[c]);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+    for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; if (i >= D) gm[c][e] = 0.f; }
+  }
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  float xn[MAXC][8], gn[MAXC][8];
+  if (row < rows) {
+    load_row<T, MAXC>(x + row * D, D, lane, xn);
+    load_row<T, MAXC>(dy + row * D, D, lane, gn);
+  }
+  for (; row < rows; row += stride) {
     float xv[MAXC][8], gv[MAXC][8];
-    load_row<T>(x + row * D, D, lane, xv);
-    load_row<T>(dy + row * D, D, lane, gv);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { xv[c][e] = xn[c][e]; gv[c][e] = gn[c][e]; }
+    const int64_t nxt = row + stride;
+    if (nxt < rows) {  // prefetch the next row of this wave
+      load_row<T, MAXC>(x + nxt * D, D, lane, xn);
+      load_row<T, MAXC>(dy + nxt * D, D, lane, gn);
+    }
     const float mean = mean_i[row], rstd = rstd_i[row];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       const int i = (c * 64 + lane) * 8;
       if (i >= D) continue;
-      float g[8];
-      Vec8<float>::load(gamma + i, g);
+      const uint32_t keep = drop_p > 0.f ? vmr_keep8(seed, (uint64_t)row * D + i, thresh) : 0xFFu;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float d = gv[c][e];
-        if (drop_p > 0.f) d = vmr_keep(seed, (uint64_t)row * D + i + e, thresh) ? d * dscale : 0.f;
+        if (drop_p > 0.f) d = ((keep >> e) & 1) ? d * dscale : 0.f;
         const float xh = (xv[c][e] - mean) * rstd;
         ag[c][e] += d * xh;
         ab[c][e] += d;
         if (dpos) atomicAdd(&dpos[(int64_t)(row % S) * D + i + e], d);
-        const float dxh = d * g[e];
+        const float dxh = d * gm[c][e];
         s1 += dxh;
         s2 += dxh * xh;
         xv[c][e] = xh;
@@ -161,7 +181,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       Vec8<T>::store(dx + row * D + i, o);
     }
   }
-  if (!dgamma) return;
+  if (!part) return;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
     const int i = (c * 64 + lane) * 8;
@@ -173,13 +193,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
   }
   __syncthreads();
+  // per-workgroup partials [block][2][D]: every workgroup hammering the same 8 KiB with float
+  // atomics runs ~14x below the atomic rate (MI355X_MICROARCH "contention"); a second tiny
+  // kernel sums the partials instead.
+  float* mine = part + (int64_t)blockIdx.x * 2 * D;
   for (int i = threadIdx.x; i < D; i += 256) {
     float sg = 0.f, sb = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { sg += red[(0 * 4 + w) * D + i]; sb += red[(1 * 4 + w) * D + i]; }
-    atomicAdd(&dgamma[i], sg);
-    atomicAdd(&dbeta[i], sb);
+    mine[i] = sg;
+    mine[D + i] = sb;
   }
+}
+
+// out[j] += sum_b part[b][j]   (j < n): second stage of the column reductions.  blockIdx.y takes
+// 16 partial rows (16 independent loads in flight per thread), so only nblocks/16 adders meet on
+// an address.
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                                        float* __restrict__ out1, int nblocks, int n0, int n1) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int n = n0 + n1;
+  if (j >= n) return;
+  const int b0 = blockIdx.y * 16;
+  float v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = (b0 + k < nblocks) ? part[(int64_t)(b0 + k) * n + j] : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += v[k];
+  atomicAdd(j < n0 ? &out0[j] : &out1[j - n0], s);
 }
 
 // ----------------------------------------------- fused LayerNorm + dwconv fwd
@@ -187,7 +229,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 // the R+6 rows (3-row halo each side) into LDS; rows outside [0,S) are the
 // conv's zero padding.  Phase 2: each thread owns 4 channels and produces the
 // R output rows from the LDS tile.
-template <typename T>
+template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
                                                             const float* __restrict__ w, T* __restrict__ u,
@@ -204,8 +246,8 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict_
     const bool in = s >= 0 && s < S;
     float mean = 0.f, rstd = 0.f;
     if (in) {
-      load_row<T>(x + ((int64_t)b * S + s) * D, D, lane, v);
-      row_stats(v, D, lane, eps, mean, rstd);
+      load_row<T, MAXC>(x + ((int64_t)b * S + s) * D, D, lane, v);
+      row_stats<MAXC>(v, D, lane, eps, mean, rstd);
       if (lane == 0 && r >= 3 && r < 3 + R) {
         mean_o[(int64_t)b * S + s] = mean;
         rstd_o[(int64_t)b * S + s] = rstd;
@@ -267,7 +309,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
                                                          const float* __restrict__ mean_i,
                                                          const float* __restrict__ rstd_i,
                                                          const float* __restrict__ w, T* __restrict__ dn,
-                                                         float* __restrict__ dw, int S, int D, int slices) {
+                                                         float* __restrict__ part, int S, int D, int slices) {
   __shared__ float red[4][256 * 7];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b = blockIdx.x / slices, c0 = (blockIdx.x % slices) * 256 + lane * 4;
@@ -328,16 +370,27 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
 #pragma unroll
     for (int k = 0; k < 7; ++k) red[wid][(lane * 4 + ch) * 7 + k] = aw[ch][k];
   __syncthreads();
+  // per-sample partials [b][D*7] (plain stores); colreduce_kernel sums them over b
   const int cbase = (blockIdx.x % slices) * 256;
+  float* mine = part + (int64_t)b * D * 7;
   for (int i = threadIdx.x; i < 256 * 7; i += 256) {
-    if (cbase + i / 7 < D) atomicAdd(&dw[(int64_t)cbase * 7 + i], red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+    if (cbase + i / 7 < D) mine[(int64_t)cbase * 7 + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
   }
 }
 
 int ln_check(int D) {
-  if (D % 8 != 0 || D > 64 * 8 * MAXC || D <= 0) return vmr_fail(-22, "LayerNorm kernels need D %% 8 == 0 and D <= %d (got %d)", 64 * 8 * MAXC, D);
+  if (D % 8 != 0 || D > 64 * 8 * MAXC_MAX || D <= 0)
+    return vmr_fail(-22, "LayerNorm kernels need D %% 8 == 0 and D <= %d (got %d)", 64 * 8 * MAXC_MAX, D);
   return 0;
 }
+
+// dispatch on the number of 8-element chunks a lane needs for a row of D elements
+#define LN_DISPATCH(D, ...)                                       \
+  do {                                                            \
+    if ((D) <= 512) { constexpr int MC = 1; __VA_ARGS__; }        \
+    else if ((D) <= 1024) { constexpr int MC = 2; __VA_ARGS__; }  \
+    else { constexpr int MC = 4; __VA_ARGS__; }                   \
+  } while (0)
 
 }  // namespace
 
@@ -350,34 +403,43 @@ extern "C" int vmr_layernorm_fwd(const void* x, const float* gamma, const float*
   if (rows == 0) return 0;
   const int grid = (int)min((int64_t)4096, (rows + 3) / 4);
   if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma,
-                       beta, eps, (const bf16_t*)pos, S, (bf16_t*)y, mean, rstd, rows, D, drop_p, drop_seed, drop_step);
+    LN_DISPATCH(D, hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, MC>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                      (const bf16_t*)x, gamma, beta, eps, (const bf16_t*)pos, S, (bf16_t*)y, mean, rstd,
+                                      rows, D, drop_p, drop_seed, drop_step));
   else
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma,
-                       beta, eps, (const float*)pos, S, (float*)y, mean, rstd, rows, D, drop_p, drop_seed, drop_step);
+    LN_DISPATCH(D, hipLaunchKernelGGL((ln_fwd_kernel<float, MC>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                      (const float*)x, gamma, beta, eps, (const float*)pos, S, (float*)y, mean, rstd,
+                                      rows, D, drop_p, drop_seed, drop_step));
   VMR_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vmr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                  const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                                 float* dpos, int S, int64_t rows, int D, int dtype, float drop_p,
+                                 float* dpos, float* workspace, int S, int64_t rows, int D, int dtype, float drop_p,
                                  uint32_t drop_seed, const uint32_t* drop_step, void* stream) {
   if (int rc = ln_check(D)) return rc;
   VMR_CHECK(dy && x && gamma && mean && rstd && dx, "vmr_layernorm_bwd: null pointer");
   VMR_CHECK((dgamma == nullptr) == (dbeta == nullptr), "vmr_layernorm_bwd: dgamma/dbeta must come together");
+  VMR_CHECK(!dgamma || workspace, "vmr_layernorm_bwd: dgamma/dbeta need the workspace (VMR_LN_BWD_WS_FLOATS(D))");
   if (rows == 0) return 0;
-  const int grid = (int)min((int64_t)512, (rows + 3) / 4);
+  const int grid = (int)min((int64_t)VMR_LN_BWD_MAX_BLOCKS, (rows + 7) / 8);   // >= 2 rows per wave: the prefetch pays
+  float* part = dgamma ? workspace : nullptr;
   const size_t lds = (size_t)2 * 4 * D * sizeof(float);
   if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy,
-                       (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, dpos, S,
-                       rows, D, drop_p, drop_seed, drop_step);
+    LN_DISPATCH(D, hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, MC>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
+                                      (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres,
+                                      (bf16_t*)dx, part, dpos, S, rows, D, drop_p, drop_seed, drop_step));
   else
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const float*)dy,
-                       (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, dpos, S, rows,
-                       D, drop_p, drop_seed, drop_step);
+    LN_DISPATCH(D, hipLaunchKernelGGL((ln_bwd_kernel<float, MC>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
+                                      (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres,
+                                      (float*)dx, part, dpos, S, rows, D, drop_p, drop_seed, drop_step));
   VMR_LAUNCH_CHECK();
+  if (part) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3(cdiv(2 * D, 256), cdiv(grid, 16)), dim3(256), 0, (hipStream_t)stream,
+                       part, dgamma, dbeta, grid, D, D);
+    VMR_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -393,34 +455,43 @@ extern "C" int vmr_ln_dwconv_fwd(const void* x, const float* gamma, const float*
   const int tiles = cdiv(S, R);
   R = cdiv(S, tiles);  // balance the tiles
   const size_t lds = (size_t)(R + 6) * D * esz;
-  const void* fn = dtype == VMR_BF16 ? (const void*)ln_dwconv_fwd_kernel<bf16_t> : (const void*)ln_dwconv_fwd_kernel<float>;
+  const void* fn = nullptr;
+  if (dtype == VMR_BF16) LN_DISPATCH(D, fn = (const void*)ln_dwconv_fwd_kernel<bf16_t, MC>);
+  else LN_DISPATCH(D, fn = (const void*)ln_dwconv_fwd_kernel<float, MC>);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vmr_fail(-5, "vmr_ln_dwconv_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(ln_dwconv_fwd_kernel<bf16_t>, dim3(B * tiles), dim3(256), lds, (hipStream_t)stream,
-                       (const bf16_t*)x, gamma, beta, eps, w, (bf16_t*)u, mean, rstd, S, D, R, tiles);
+    LN_DISPATCH(D, hipLaunchKernelGGL((ln_dwconv_fwd_kernel<bf16_t, MC>), dim3(B * tiles), dim3(256), lds,
+                                      (hipStream_t)stream, (const bf16_t*)x, gamma, beta, eps, w, (bf16_t*)u, mean,
+                                      rstd, S, D, R, tiles));
   else
-    hipLaunchKernelGGL(ln_dwconv_fwd_kernel<float>, dim3(B * tiles), dim3(256), lds, (hipStream_t)stream,
-                       (const float*)x, gamma, beta, eps, w, (float*)u, mean, rstd, S, D, R, tiles);
+    LN_DISPATCH(D, hipLaunchKernelGGL((ln_dwconv_fwd_kernel<float, MC>), dim3(B * tiles), dim3(256), lds,
+                                      (hipStream_t)stream, (const float*)x, gamma, beta, eps, w, (float*)u, mean, rstd,
+                                      S, D, R, tiles));
   VMR_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vmr_dwconv_bwd(const void* du, const void* x, const float* gamma, const float* beta,
-                              const float* mean, const float* rstd, const float* w, void* dn, float* dw, int B,
-                              int S, int D, int dtype, void* stream) {
-  VMR_CHECK(du && x && gamma && beta && mean && rstd && w && dn && dw, "vmr_dwconv_bwd: null pointer");
+                              const float* mean, const float* rstd, const float* w, void* dn, float* dw,
+                              float* workspace, int B, int S, int D, int dtype, void* stream) {
+  VMR_CHECK(du && x && gamma && beta && mean && rstd && w && dn && dw && workspace, "vmr_dwconv_bwd: null pointer");
   VMR_CHECK(D % 4 == 0, "vmr_dwconv_bwd: D %% 4 != 0");
   if (B == 0 || S == 0) return 0;
   const int slices = cdiv(D, 256);
   if (dtype == VMR_BF16)
     hipLaunchKernelGGL(dwconv_bwd_kernel<bf16_t>, dim3(B * slices), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)du, (const bf16_t*)x, gamma, beta, mean, rstd, w, (bf16_t*)dn, dw, S, D, slices);
+                       (const bf16_t*)du, (const bf16_t*)x, gamma, beta, mean, rstd, w, (bf16_t*)dn, workspace, S, D,
+                       slices);
   else
     hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(B * slices), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)du, (const float*)x, gamma, beta, mean, rstd, w, (float*)dn, dw, S, D, slices);
+                       (const float*)du, (const float*)x, gamma, beta, mean, rstd, w, (float*)dn, workspace, S, D,
+                       slices);
+  VMR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colreduce_kernel, dim3(cdiv(D * 7, 256), cdiv(B, 16)), dim3(256), 0, (hipStream_t)stream,
+                     workspace, dw, dw, B, D * 7, 0);
   VMR_LAUNCH_CHECK();
   return 0;
 }

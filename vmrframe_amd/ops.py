@@ -10,8 +10,10 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -101,13 +103,23 @@ def bmm4(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, ta: int, tb: int, *,
          sC=(c.stride(0), c.stride(1)), **kw)
 
 
+SPLITK_TARGET = int(os.environ.get("VMR_SPLITK_TARGET", "256"))   # workgroups to aim for in dW products
+
+
 def splitk_for(M: int, N: int, K: int) -> int:
-    """dW products have few output tiles and a long K: split K until ~512 workgroups."""
+    """dW products have few output tiles and a long K (= tokens): split K until the grid has about
+    one workgroup per CU; every split costs one more fp32 atomic pass over the [M,N] output."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     sk = 1
-    while tiles * sk < 384 and K // (sk * 2) >= 512:
+    while tiles * sk * 2 <= SPLITK_TARGET and K // (sk * 2) >= 512:
         sk *= 2
     return sk
+
+
+def main_grad(p):
+    """fp32 gradient slot of a parameter inside the flat gradient arena (optim.FlatArena), if any:
+    weight-gradient kernels then accumulate straight into it and autograd sees no gradient."""
+    return getattr(p, "_vmr_main_grad", None)
 
 
 # ---------------------------------------------------------------------------
@@ -247,6 +259,8 @@ class _Linear(torch.autograd.Function):
              residual=residual, aux=aux, ldr=N, rowscale=rowscale, drop=drop)
         ctx.save_for_backward(x, W, aux if aux is not None else (ybuf if relu else None), rowscale)
         ctx.meta = (relu, drop, bias is not None, residual is not None, [tuple(w.shape) for w in weights])
+        ctx.weights = weights
+        ctx.bias_param = bias
         return y
 
     @staticmethod
@@ -269,7 +283,9 @@ class _Linear(torch.autograd.Function):
         dt = L.dtype_code(dyb)
         lib, st = L.lib(), L.stream_ptr()
         scale = 1.0 / (1.0 - drop[0]) if drop[0] > 0 else 1.0
-        db = torch.zeros(Np, device=dy.device, dtype=torch.float32) if has_bias else None
+        bgrad = main_grad(ctx.bias_param) if (has_bias and Np == N) else None
+        db = (bgrad if bgrad is not None else torch.zeros(Np, device=dy.device, dtype=torch.float32)) \
+            if has_bias else None
         if relu:
             dzb = torch.empty_like(dyb)
             L.check(lib.vmr_relu_bwd_bias(1, dyb.data_ptr(), h.data_ptr(), dzb.data_ptr(), _ptr(db), M, Np, Np, scale,
@@ -289,6 +305,19 @@ class _Linear(torch.autograd.Function):
             dx = mm(dz, W, 0, 1)                       # [M,N] . [N,Kp]
         # dW = dz^T . x  -> fp32 [N,Kp], split-K over the M (token) dimension
         sk = splitk_for(N, Kp, M)
+        slots = [main_grad(w) for w in ctx.weights]
+        if all(g is not None for g in slots) and all(int(np.prod(shp[1:])) == Kp for shp in wshapes):
+            # accumulate straight into the flat gradient arena: no zero-fill, no autograd add
+            r = 0
+            for g_, shp in zip(slots, wshapes):
+                n = shp[0]
+                a = dz[:, r:r + n]
+                gemm(a, x, g_, n, Kp, M, 1, 1, a.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_ACCUM,
+                     splitk=splitk_for(n, Kp, M))
+                r += n
+            if db is not None and Np != N:
+                db = db[:N]
+            return (dx, None if bgrad is not None else db, dres, None, None, None, None, *([None] * len(wshapes)))
         if sk > 1:
             dW = torch.zeros(N, Kp, device=dy.device, dtype=torch.float32)
             gemm(dz, x, dW, N, Kp, M, 1, 1, dz.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_ACCUM, splitk=sk)
@@ -305,7 +334,7 @@ class _Linear(torch.autograd.Function):
             r += n
         if db is not None and Np != N:
             db = db[:N]
-        return (dx, db, dres, None, None, None, None, *grads)
+        return (dx, None if bgrad is not None else db, dres, None, None, None, None, *grads)
 
 
 def linear(x, weights, bias, cache, *, relu=False, drop=NO_DROP, residual=None, rowscale=None):
@@ -335,6 +364,7 @@ class _LayerNorm(torch.autograd.Function):
                                           drop[0], drop[1], _ptr(drop[2]), L.stream_ptr()), "vmr_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.meta = (drop, S, None if pos is None else tuple(pos.shape))
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -344,14 +374,18 @@ class _LayerNorm(torch.autograd.Function):
         dy = dy.contiguous()
         rows, D = x.shape
         dx = torch.empty_like(x)
-        dg = torch.zeros(D, device=x.device, dtype=torch.float32)
-        db = torch.zeros_like(dg)
+        mg, mb = main_grad(ctx.params[0]), main_grad(ctx.params[1])
+        direct = mg is not None and mb is not None
+        dg = mg if direct else torch.zeros(D, device=x.device, dtype=torch.float32)
+        db = mb if direct else torch.zeros_like(dg)
         dpos = torch.zeros(pshape, device=x.device, dtype=torch.float32) if pshape else None
+        ws = torch.empty(L.LN_BWD_MAX_BLOCKS * 2 * D, device=x.device, dtype=torch.float32)
         L.check(L.lib().vmr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                           rstd.data_ptr(), None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                                          _ptr(dpos), S, rows, D, L.dtype_code(x), drop[0], drop[1], _ptr(drop[2]),
+                                          _ptr(dpos), ws.data_ptr(), S, rows, D, L.dtype_code(x), drop[0], drop[1],
+                                          _ptr(drop[2]),
                                           L.stream_ptr()), "vmr_layernorm_bwd")
-        return dx, dg, db, None, dpos, None, None, None
+        return dx, (None if direct else dg), (None if direct else db), None, dpos, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps, cache, *, pos=None, S=0, drop=NO_DROP):
@@ -384,6 +418,7 @@ class _LnDwConv(torch.autograd.Function):
             r += B * S
         ctx.save_for_backward(x, gamma, beta, w2, mean, rstd)
         ctx.meta = (segs, tuple(w.shape))
+        ctx.params = (gamma, beta, w)
         return u
 
     @staticmethod
@@ -394,19 +429,25 @@ class _LnDwConv(torch.autograd.Function):
         du = du.contiguous()
         lib, st, dt = L.lib(), L.stream_ptr(), L.dtype_code(x)
         dn = torch.empty_like(x)
-        dw = torch.zeros(D, 7, device=x.device, dtype=torch.float32)
+        mg, mb, mw = (main_grad(p_) for p_ in ctx.params)
+        direct = mg is not None and mb is not None and mw is not None
+        dw = mw if direct else torch.zeros(D, 7, device=x.device, dtype=torch.float32)
         r = 0
+        ws = torch.empty(max(max(b for b, _ in segs) * D * 7, L.LN_BWD_MAX_BLOCKS * 2 * D), device=x.device,
+                         dtype=torch.float32)
         for (B, S) in segs:
             L.check(lib.vmr_dwconv_bwd(du[r:].data_ptr(), x[r:].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                        mean[r:].data_ptr(), rstd[r:].data_ptr(), w2.data_ptr(), dn[r:].data_ptr(),
-                                       dw.data_ptr(), B, S, D, dt, st), "vmr_dwconv_bwd")
+                                       dw.data_ptr(), ws.data_ptr(), B, S, D, dt, st), "vmr_dwconv_bwd")
             r += B * S
         dx = torch.empty_like(x)
-        dg = torch.zeros(D, device=x.device, dtype=torch.float32)
-        db = torch.zeros_like(dg)
+        dg = mg if direct else torch.zeros(D, device=x.device, dtype=torch.float32)
+        db = mb if direct else torch.zeros_like(dg)
         L.check(lib.vmr_layernorm_bwd(dn.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                      None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, 0, rows, D, dt,
-                                      0.0, 0, None, st), "vmr_layernorm_bwd")
+                                      None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, ws.data_ptr(), 0, rows, D,
+                                      dt, 0.0, 0, None, st), "vmr_layernorm_bwd")
+        if direct:
+            return dx, None, None, None, None, None
         return dx, dg, db, dw.reshape(wshape), None, None
 
 
@@ -686,6 +727,38 @@ class _SoftCE(torch.autograd.Function):
 
 def soft_ce(zs, ze, ys, ye):
     return _SoftCE.apply(zs, ze, ys, ye)
+
+
+class _Embedding(torch.autograd.Function):
+    """F.embedding(idx, table, padding_idx) as a HIP row gather; the backward is a float-atomic
+    scatter-add (graph-capturable: no host-side segment counting as in torch's kernel)."""
+
+    @staticmethod
+    def forward(ctx, idx, table, padding_idx):
+        L.require_gpu(idx, table)
+        idx = idx.contiguous()
+        table = table.contiguous().float()
+        n, D = idx.numel(), table.shape[1]
+        out = torch.empty(*idx.shape, D, device=table.device, dtype=torch.float32)
+        L.check(L.lib().vmr_embedding_fwd(idx.data_ptr(), table.data_ptr(), out.data_ptr(), n, D, table.shape[0],
+                                          L.stream_ptr()), "vmr_embedding_fwd")
+        ctx.save_for_backward(idx)
+        ctx.meta = (tuple(table.shape), padding_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        shape, padding_idx = ctx.meta
+        dout = dout.contiguous().float()
+        dtable = torch.zeros(shape, device=dout.device, dtype=torch.float32)
+        L.check(L.lib().vmr_embedding_bwd(idx.data_ptr(), dout.data_ptr(), dtable.data_ptr(), idx.numel(), shape[1],
+                                          shape[0], padding_idx, L.stream_ptr()), "vmr_embedding_bwd")
+        return None, dtable, None
+
+
+def embedding(idx, table, padding_idx=0):
+    return _Embedding.apply(idx, table, padding_idx)
 
 
 def dropout_mask(n: int, p: float, seed: int, device) -> torch.Tensor:

@@ -52,6 +52,7 @@ class FlatArena:
             self.flat_g[o:o + k].copy_(p.grad.reshape(-1))
             p.data = self.flat_p[o:o + k].view(p.shape)
             p.grad = self.flat_g[o:o + k].view(p.shape)
+            p._vmr_main_grad = p.grad      # weight-gradient kernels accumulate straight into the arena
             if not any(nd in n for nd in NO_DECAY):
                 self.decay[o:o + k] = 1
         self.names: List[str] = [n for n, _ in named]
@@ -64,9 +65,11 @@ class FlatAdamW:
         self.model = model
         self.base_lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
         self.sched = linear_warmup_lambda(warmup_steps, total_steps) if total_steps > 0 else (lambda s: 1.0)
-        self.t = 0                 # optimizer steps taken
+        self.t = 0                 # optimizer steps taken (host mirror)
         self.arena = None
         self.m = self.v = self.gnorm_sq = None
+        self.warmup_steps, self.total_steps = float(warmup_steps), int(total_steps)
+        self.step_t = self.lr_t = None   # device-resident step / lr (hipGraph-replayable schedule)
 
     # -- arena -----------------------------------------------------------------
     def _build(self):
@@ -74,7 +77,21 @@ class FlatAdamW:
         L.require_gpu(self.arena.flat_p)
         self.m = torch.zeros_like(self.arena.flat_p)
         self.v = torch.zeros_like(self.arena.flat_p)
-        self.gnorm_sq = torch.zeros(1, device=self.arena.flat_p.device, dtype=torch.float32)
+        dev = self.arena.flat_p.device
+        self.gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.step_t = torch.full((1,), self.t, device=dev, dtype=torch.int32)
+        self.lr_t = torch.zeros(1, device=dev, dtype=torch.float32)
+
+    def _device_lr(self):
+        """lr_t = base_lr * linear-warmup(step_t), computed on the device (no host read)."""
+        s = self.step_t.float()
+        if self.total_steps <= 0:
+            f = torch.ones_like(s)
+        else:
+            warm = s / max(1.0, self.warmup_steps)
+            decay = (self.total_steps - s).clamp_min(0.0) / max(1.0, self.total_steps - self.warmup_steps)
+            f = torch.where(s < self.warmup_steps, warm, decay)
+        self.lr_t.copy_(f * self.base_lr)
 
     @property
     def grad_arena(self):
@@ -106,10 +123,13 @@ class FlatAdamW:
         self.gnorm_sq.zero_()
         n = A.flat_p.numel()
         L.check(lib.vmr_sumsq(A.flat_g.data_ptr(), self.gnorm_sq.data_ptr(), n, st), "vmr_sumsq")
+        self._device_lr()
         L.check(lib.vmr_adamw(A.flat_p.data_ptr(), A.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                              A.decay.data_ptr(), None, self.gnorm_sq.data_ptr(), self.max_norm, self.lr(),
-                              self.betas[0], self.betas[1], self.eps, self.wd, self.t + 1, n, st), "vmr_adamw")
-        self.t += 1                  # scheduler.step() of the reference loop
+                              A.decay.data_ptr(), None, self.gnorm_sq.data_ptr(), self.max_norm, 0.0,
+                              self.betas[0], self.betas[1], self.eps, self.wd, 0, self.lr_t.data_ptr(),
+                              self.step_t.data_ptr(), n, st), "vmr_adamw")
+        self.step_t += 1             # scheduler.step() of the reference loop
+        self.t += 1
         if hasattr(self.model, "_cache"):   # the masters changed under the compute-dtype weight cache
             self.model._cache.clear()
 
