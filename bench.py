@@ -166,7 +166,7 @@ def main():
         # one captured HIP graph per step (vmrframe_amd/trainer.py): the eager loop is launch-bound
         from vmrframe_amd.trainer import GraphedTrainStep
         gstep = GraphedTrainStep(model, opt, V.train_engine_SeqPAN, cfg, reducer if world > 1 else None,
-                                 warmup=3).capture(batch)
+                                 warmup=3, overlap_dw=os.environ.get("VMR_OVERLAP_DW", "0") != "0").capture(batch)
         step = gstep
         for _ in range(args.warmup):
             loss = step()

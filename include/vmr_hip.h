@@ -54,6 +54,7 @@ int vmr_sizeof_gemm_desc(void); /* ABI guard for foreign-language bindings of vm
 #define VMR_EPI_OUT_F32 32  /* C is fp32 regardless of dtype                   */
 #define VMR_EPI_ACCUM 64    /* C (fp32) += result, via atomics (split-K safe)  */
 #define VMR_EPI_ROWSCALE 128 /* multiply row m by rowscale[m] (fp32) at the end */
+#define VMR_EPI_SLAB 256     /* split-K without atomics: split ks writes fp32 C + ks*M*ldc (then vmr_splitk_reduce) */
 
 typedef struct {
   const void* A;
@@ -93,11 +94,11 @@ int vmr_layernorm_fwd(const void* x, const float* gamma, const float* beta, floa
 /* dx = LN backward of dy (dropout mask regenerated from the seed), optionally
  * dx += dres (gradient arriving through a residual branch); dgamma/dbeta are
  * ACCUMULATED (+=, two-stage reduction through `workspace`, fp32
- * VMR_LN_BWD_WS_FLOATS(D) floats, caller-owned scratch) and must be zeroed by the
+ * VMR_LN_BWD_WS_FLOATS(rows, D) floats, caller-owned scratch) and must be zeroed by the
  * caller when needed.  dpos (optional, fp32 [S,D]) accumulates the
  * positional-table gradient. */
-#define VMR_LN_BWD_MAX_BLOCKS 768
-#define VMR_LN_BWD_WS_FLOATS(D) ((int64_t)VMR_LN_BWD_MAX_BLOCKS * 2 * (D))
+#define VMR_LN_BWD_MAX_BLOCKS 8192 /* 8 rows per block: up to 65,536 rows per call */
+#define VMR_LN_BWD_WS_FLOATS(rows, D) ((((int64_t)(rows) + 7) / 8) * 2 * ((D) <= 512 ? 512 : ((D) <= 1024 ? 1024 : 2048)))
 int vmr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                       const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
                       float* dpos, float* workspace, int S, int64_t rows, int D, int dtype, float drop_p,
@@ -112,8 +113,10 @@ int vmr_ln_dwconv_fwd(const void* x, const float* gamma, const float* beta, floa
                       int B, int S, int D, int dtype, void* stream);
 /* backward of the depthwise conv alone: dn = conv^T(du); dw += sum du*n where
  * n = LN(x) is recomputed from x, mean, rstd.  dn then goes to
- * vmr_layernorm_bwd. dw is accumulated (+=) through `workspace` (fp32 [B, D*7]
- * caller-owned scratch: per-sample partials, then one reduction). */
+ * vmr_layernorm_bwd. dw is accumulated (+=) through `workspace` (fp32
+ * [B * VMR_DWCONV_BWD_BPS(S), D*7] caller-owned scratch: per-workgroup partials,
+ * then one reduction). */
+#define VMR_DWCONV_BWD_BPS(S) (((S) + 63) / 64)
 int vmr_dwconv_bwd(const void* du, const void* x, const float* gamma, const float* beta,
                    const float* mean, const float* rstd, const float* w, void* dn, float* dw,
                    float* workspace, int B, int S, int D, int dtype, void* stream);
@@ -172,6 +175,21 @@ int vmr_embedding_bwd(const int64_t* idx, const float* dout, float* dtable, int6
                       int64_t nrows, int64_t padding_idx, void* stream);
 /* dropout mask materialisation (tests): m[i] = keep(seed,i) ? 1/(1-p) : 0 */
 int vmr_dropout_mask(float* m, int64_t n, float drop_p, uint32_t seed, void* stream);
+
+/* fused elementwise programs of the dual-attention gating and the CQAttention concat
+ * (layers.py:370-380, 424); rows x D, activation dtype.  op:
+ *  0 GATE_FWD   o0 = a*d + c*b                       (a=s_score b=s_value c=x_score d=x_value)
+ *  1 GATE_BWD   a=do, b..e = s_score,s_value,x_score,x_value -> o0..o3 = their gradients
+ *  2 SIGGATE_FWD a = [scores|values] [rows,2D] -> o0 = sigmoid(scores + (1-rowmask)*-1e30)*values
+ *  3 SIGGATE_BWD a = do, b = [scores|values] -> o0 = d[scores|values] [rows,2D]
+ *  4 CAT4_FWD   a=C b=c2q c=q2c -> o0 = [C, c2q, C*c2q, C*q2c] [rows,4D]
+ *  5 CAT4_BWD   a=dcat [rows,4D], b=C c=c2q d=q2c -> o0=dC o1=dc2q o2=dq2c */
+int vmr_eltwise(int op, const void* a, const void* b, const void* c, const void* d, const void* e,
+                const float* rowmask, void* o0, void* o1, void* o2, void* o3, int64_t rows, int D,
+                int dtype, void* stream);
+/* dst[i] += sum_k slab[k*n + i] (fp32): second stage of a split-K GEMM whose splits were
+ * written as plain slabs (VMR_EPI_SLAB) instead of float atomics. */
+int vmr_splitk_reduce(const float* slab, float* dst, int nsplit, int64_t n, void* stream);
 
 /* --------------------------------------------------------------- optimizer
  * fused AdamW over a flat fp32 parameter arena (utils/utils.py:87-97:

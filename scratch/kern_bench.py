@@ -18,7 +18,7 @@ N, D = 9472, 1024
 lib=L.lib(); st=lambda: torch.cuda.current_stream().cuda_stream
 x=torch.randn(N,D,device=dev).to(dt); dy=torch.randn(N,D,device=dev).to(dt); y=torch.empty_like(x); dx=torch.empty_like(x)
 g=torch.ones(D,device=dev); b=torch.zeros(D,device=dev); mean=torch.zeros(N,device=dev); rstd=torch.ones(N,device=dev)
-dg=torch.zeros(D,device=dev); db=torch.zeros(D,device=dev); ws=torch.empty(768*2*D,device=dev)
+dg=torch.zeros(D,device=dev); db=torch.zeros(D,device=dev); ws=torch.empty(4096*2*D,device=dev)
 timeit("ln_fwd", lambda: lib.vmr_layernorm_fwd(x.data_ptr(),g.data_ptr(),b.data_ptr(),1e-6,None,0,y.data_ptr(),mean.data_ptr(),rstd.data_ptr(),N,D,1,0.0,0,None,st()), 2*N*D*2)
 timeit("ln_fwd+dropout", lambda: lib.vmr_layernorm_fwd(x.data_ptr(),g.data_ptr(),b.data_ptr(),1e-6,None,0,y.data_ptr(),mean.data_ptr(),rstd.data_ptr(),N,D,1,0.2,5,None,st()), 2*N*D*2)
 timeit("ln_bwd", lambda: lib.vmr_layernorm_bwd(dy.data_ptr(),x.data_ptr(),g.data_ptr(),mean.data_ptr(),rstd.data_ptr(),None,dx.data_ptr(),dg.data_ptr(),db.data_ptr(),None,ws.data_ptr(),0,N,D,1,0.0,0,None,st()), 3*N*D*2)

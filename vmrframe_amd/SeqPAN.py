@@ -218,6 +218,16 @@ class SeqPAN(nn.Module):
             mod = mod._modules[part]
         mod.register_parameter(parts[-1], param)
 
+    def weight_groups(self):
+        """Parameter names whose weights are consumed by ONE grouped GEMM, in consumption order."""
+        out = []
+        for blk in (1, 2):
+            m = f"dual_attention_block_{blk}.dual_multihead_attention"
+            out.append([f"{m}.{n}.conv1d.weight" for n in ("query", "f_key", "f_value")])
+            out.append([f"{m}.{n}.conv1d.weight" for n in ("t_key", "t_value")])
+            out.append([f"{m}.bilinear_{b}.dense_1.conv1d.weight" for b in (1, 2)])
+        return out
+
     def P(self, name):
         mod = self
         parts = name.split(".")
@@ -285,16 +295,16 @@ class SeqPAN(nn.Module):
         xval = ops.linear(xo, W("x_dense"), Bv("x_dense"), c)
         sscore = ops.linear(sval, W("s_gate"), Bv("s_gate"), c)
         xscore = ops.linear(xval, W("x_gate"), Bv("x_gate"), c)
-        gated = sscore * xval + xscore * sval                                   # cross gating (:374)
-        gd = ops.linear(gated, W("guided_dense"), Bv("guided_dense"), c)
+        gated = ops.cross_gate(sscore, sval, xscore, xval)                      # cross gating (:374)
+        # guided_dense(...) + n1 : the BiLinear input a+b, added in the GEMM epilogue
+        bl_in = ops.linear(gated, W("guided_dense"), Bv("guided_dense"), c, residual=n1)
         # BiLinear x2: dense_1(a)+dense_1(b)+bias_value == dense_1(a+b) + 2*b1 + bias_value (:257-263)
         b1, b2 = m + ".bilinear_1", m + ".bilinear_2"
         bias = torch.cat([2.0 * self.P(b1 + ".dense_1.conv1d.bias") + self.P(b1 + ".bias_value"),
                           2.0 * self.P(b2 + ".dense_1.conv1d.bias") + self.P(b2 + ".bias_value")])
-        sv = ops.linear(n1 + gd, [self.P(b1 + ".dense_1.conv1d.weight"), self.P(b2 + ".dense_1.conv1d.weight")],
+        sv = ops.linear(bl_in, [self.P(b1 + ".dense_1.conv1d.weight"), self.P(b2 + ".dense_1.conv1d.weight")],
                         bias, c)
-        scores, values = sv[:, :D], sv[:, D:]
-        out = torch.sigmoid(scores + NEG * (1.0 - rowmask)) * values            # (:380)
+        out = ops.sigmoid_gate(sv, rowmask)                                     # (:380)
         o1 = self._lin(out, prefix + ".dense_1", drop=dc.next(prefix + ".d1"), residual=X)
         o2 = self._ln(o1, prefix + ".layer_norm_2", 1e-6, drop=dc.next(prefix + ".ln2"))
         return self._lin(o2, prefix + ".dense_2", drop=dc.next(prefix + ".d2"), residual=o1)
@@ -328,7 +338,7 @@ class SeqPAN(nn.Module):
         c2q = ops.bmm(S_p, qry, 0, 1)                      # [B,Lc,D]
         mid = ops.bmm(S_tp, ctx, 1, 1)                     # S_t^T . C   [B,Lq,D]
         q2c = ops.bmm(S_p, mid, 0, 1)                      # [B,Lc,D]
-        cat4 = torch.cat([ctx, c2q, ctx * c2q, ctx * q2c], dim=2).reshape(B * Lc, 4 * D)
+        cat4 = ops.cat4(ctx.reshape(B * Lc, D), c2q.reshape(B * Lc, D), q2c.reshape(B * Lc, D))
         return self._lin(cat4, prefix + ".cqa_linear")
 
     def _predict_encoder(self, x, vmask, B, T, dc, tag):
@@ -372,7 +382,7 @@ class SeqPAN(nn.Module):
         X = torch.cat([xv, xt], 0)
         # the SAME encoder on both streams (reference models/SeqPAN.py:59-60)
         X = self._conv_block(X, "vfeat_encoder.conv_block", segs, dc)
-        rowmask = torch.cat([vmask.reshape(-1), tmask.reshape(-1)])[:, None].to(cdt)
+        rowmask = torch.cat([vmask.reshape(-1), tmask.reshape(-1)])
         for blk in (1, 2):
             X = self._dual_block(X, f"dual_attention_block_{blk}", vmask, tmask, rowmask, B, T, Lq, dc)
         V3, T3 = X[:Nv].view(B, T, D), X[Nv:].view(B, Lq, D)

@@ -16,10 +16,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvmr_hip.so")
 
 F32, BF16 = 0, 1
-LN_BWD_MAX_BLOCKS = 768   # == VMR_LN_BWD_MAX_BLOCKS
+LN_BWD_MAX_BLOCKS = 8192   # == VMR_LN_BWD_MAX_BLOCKS
 
-EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_AUX, EPI_OUT_F32, EPI_ACCUM, EPI_ROWSCALE = \
-    1, 2, 4, 8, 16, 32, 64, 128
+
+def ln_bwd_ws_floats(rows: int, D: int) -> int:
+    """== VMR_LN_BWD_WS_FLOATS(rows, D)"""
+    return ((rows + 7) // 8) * 2 * (512 if D <= 512 else (1024 if D <= 1024 else 2048))
+
+EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_AUX, EPI_OUT_F32, EPI_ACCUM, EPI_ROWSCALE, EPI_SLAB = \
+    1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
 class GemmDesc(C.Structure):
@@ -56,6 +61,8 @@ SIGNATURES = {
     "vmr_dropout_mask": [_P, _L, _F, _U, _P],
     "vmr_embedding_fwd": [_P, _P, _P, _L, _I, _L, _P],
     "vmr_embedding_bwd": [_P, _P, _P, _L, _I, _L, _L, _P],
+    "vmr_eltwise": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "vmr_splitk_reduce": [_P, _P, _I, _L, _P],
     "vmr_sumsq": [_P, _P, _L, _P],
     "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P, _P, _L, _P],
 }

@@ -72,6 +72,36 @@ template <> struct Vec8<float> {
   }
 };
 
+// 4-element vector load/store of T as floats (8 B for bf16, 16 B for f32): hipcc does not merge
+// scalar 2-byte accesses by itself
+template <typename T> struct Vec4;
+template <> struct Vec4<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+    bf16x4 x = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)x[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+    bf16x4 x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x4*>(p) = x;
+  }
+};
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a[i];
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    f32x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = v[i];
+    *reinterpret_cast<f32x4*>(p) = a;
+  }
+};
+
 // ---------------------------------------------------------------- dropout
 // Counter-based keep decision: a pure function of (seed, element index), so the
 // backward pass regenerates the mask instead of storing it.  One strong 2x32-bit

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_bf16_kernel(vmr_
   const int z1 = tc.zb / g.Z2, z2 = tc.zb - z1 * g.Z2;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
-  const int64_t coff = z1 * g.sC1 + z2 * g.sC2;
+  const int64_t coff = z1 * g.sC1 + z2 * g.sC2 + ((g.flags & VMR_EPI_SLAB) ? (int64_t)tc.ks * g.M * g.ldc : 0);
 
   int k_begin = 0, k_end = g.K;
   if (g.splitk > 1) {
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
   const int z1 = tc.zb / g.Z2, z2 = tc.zb - z1 * g.Z2;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
-  const int64_t coff = z1 * g.sC1 + z2 * g.sC2;
+  const int64_t coff = z1 * g.sC1 + z2 * g.sC2 + ((g.flags & VMR_EPI_SLAB) ? (int64_t)tc.ks * g.M * g.ldc : 0);
   int k_begin = 0, k_end = g.K;
   if (g.splitk > 1) {
     int chunk = (g.K + g.splitk - 1) / g.splitk;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma256_kernel(vmr_gemm_t g, 
   const int z1 = tc.zb / g.Z2, z2 = tc.zb - z1 * g.Z2;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
-  const int64_t coff = z1 * g.sC1 + z2 * g.sC2;
+  const int64_t coff = z1 * g.sC1 + z2 * g.sC2 + ((g.flags & VMR_EPI_SLAB) ? (int64_t)tc.ks * g.M * g.ldc : 0);
   int k_begin = 0, k_end = g.K;
   if (g.splitk > 1) {
     int chunk = (g.K + g.splitk - 1) / g.splitk;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(vmr_gemm_t g, int tile
   const int z1 = tc.zb / g.Z2, z2 = tc.zb - z1 * g.Z2;
   const float* A = reinterpret_cast<const float*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
   const float* B = reinterpret_cast<const float*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
-  const int64_t coff = z1 * g.sC1 + z2 * g.sC2;
+  const int64_t coff = z1 * g.sC1 + z2 * g.sC2 + ((g.flags & VMR_EPI_SLAB) ? (int64_t)tc.ks * g.M * g.ldc : 0);
   int k_begin = 0, k_end = g.K;
   if (g.splitk > 1) {
     int chunk = (g.K + g.splitk - 1) / g.splitk;
@@ -804,7 +804,8 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   if (g.Z1 <= 0) g.Z1 = 1;
   if (g.Z2 <= 0) g.Z2 = 1;
   if (g.splitk <= 0) g.splitk = 1;
-  VMR_CHECK(g.splitk == 1 || (g.flags & VMR_EPI_ACCUM), "vmr_gemm: splitk>1 needs VMR_EPI_ACCUM");
+  VMR_CHECK(g.splitk == 1 || (g.flags & (VMR_EPI_ACCUM | VMR_EPI_SLAB)), "vmr_gemm: splitk>1 needs VMR_EPI_ACCUM or VMR_EPI_SLAB");
+  if (g.flags & VMR_EPI_SLAB) g.flags |= VMR_EPI_OUT_F32;
   VMR_CHECK(!(g.flags & VMR_EPI_BIAS) || g.bias, "vmr_gemm: bias flag without pointer");
   VMR_CHECK(!(g.flags & VMR_EPI_RESIDUAL) || g.residual, "vmr_gemm: residual flag without pointer");
   VMR_CHECK(!(g.flags & VMR_EPI_AUX) || g.aux, "vmr_gemm: aux flag without pointer");

@@ -96,10 +96,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 }
 
 // ------------------------------------------------------------ LayerNorm bwd
-// One wave per row, two rows in flight per wave (the loads of the next row are issued before the
-// current row's reductions), gamma held in registers.  dgamma/dbeta partials are kept per lane
-// across the rows a wave visits, combined across the 4 waves through LDS and flushed with
-// contiguous float atomics.
+// A wave owns TWO consecutive rows whose loads are issued together; a 256-thread workgroup covers
+// 8 rows, so a [9472 x 1024] tensor is 1184 workgroups of short waves (parallelism, not per-wave
+// pipelining, hides the HBM latency here -- the forward kernel reaches 4 TB/s the same way).
+// dgamma/dbeta: the 4 waves' partials meet in LDS in a lane-major (conflict-free) order, and one
+// partial row per workgroup goes to the second-stage reduction (colreduce_kernel, which undoes
+// the permutation).
+constexpr int LNB_ROWS = 8;  // rows per workgroup (4 waves x 2 rows)
+
 template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma,
@@ -111,56 +115,52 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const uint32_t* __restrict__ step) {
   const uint32_t seed = vmr_seed(seed0, step);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* red = reinterpret_cast<float*>(smem);  // [2][4][D]
+  float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][MAXC*8][64 lanes]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const uint32_t thresh = vmr_drop_thresh(drop_p);
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  float ag[MAXC][8], ab[MAXC][8], gm[MAXC][8];
+  const int64_t r0 = (int64_t)blockIdx.x * LNB_ROWS + wid * 2;
+  float xv[2][MAXC][8], gv[2][MAXC][8];
+  bool ok[2];
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const int i = (c * 64 + lane) * 8;
-    if (i < D) Vec8<float>::load(gamma + i, gm[c]);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; if (i >= D) gm[c][e] = 0.f; }
-  }
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  int64_t row = (int64_t)blockIdx.x * 4 + wid;
-  float xn[MAXC][8], gn[MAXC][8];
-  if (row < rows) {
-    load_row<T, MAXC>(x + row * D, D, lane, xn);
-    load_row<T, MAXC>(dy + row * D, D, lane, gn);
-  }
-  for (; row < rows; row += stride) {
-    float xv[MAXC][8], gv[MAXC][8];
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { xv[c][e] = xn[c][e]; gv[c][e] = gn[c][e]; }
-    const int64_t nxt = row + stride;
-    if (nxt < rows) {  // prefetch the next row of this wave
-      load_row<T, MAXC>(x + nxt * D, D, lane, xn);
-      load_row<T, MAXC>(dy + nxt * D, D, lane, gn);
+  for (int u = 0; u < 2; ++u) {
+    ok[u] = r0 + u < rows;
+    if (ok[u]) {
+      load_row<T, MAXC>(x + (r0 + u) * D, D, lane, xv[u]);
+      load_row<T, MAXC>(dy + (r0 + u) * D, D, lane, gv[u]);
     }
+  }
+  float ag[MAXC][8], ab[MAXC][8];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (!ok[u]) continue;
+    const int64_t row = r0 + u;
     const float mean = mean_i[row], rstd = rstd_i[row];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       const int i = (c * 64 + lane) * 8;
       if (i >= D) continue;
+      float g[8];
+      Vec8<float>::load(gamma + i, g);
       const uint32_t keep = drop_p > 0.f ? vmr_keep8(seed, (uint64_t)row * D + i, thresh) : 0xFFu;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float d = gv[c][e];
+        float d = gv[u][c][e];
         if (drop_p > 0.f) d = ((keep >> e) & 1) ? d * dscale : 0.f;
-        const float xh = (xv[c][e] - mean) * rstd;
+        const float xh = (xv[u][c][e] - mean) * rstd;
         ag[c][e] += d * xh;
         ab[c][e] += d;
         if (dpos) atomicAdd(&dpos[(int64_t)(row % S) * D + i + e], d);
-        const float dxh = d * gm[c][e];
+        const float dxh = d * g[e];
         s1 += dxh;
         s2 += dxh * xh;
-        xv[c][e] = xh;
-        gv[c][e] = dxh;
+        xv[u][c][e] = xh;
+        gv[u][c][e] = dxh;
       }
     }
     s1 = wave_sum(s1) / (float)D;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       if (i >= D) continue;
       float o[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[c][e] - s1 - xv[c][e] * s2);
+      for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[u][c][e] - s1 - xv[u][c][e] * s2);
       if (dres) {
         float r[8];
         Vec8<T>::load(dres + row * D + i, r);
@@ -182,42 +182,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
   }
   if (!part) return;
+  constexpr int SLOTS = MAXC * 8 * 64;   // permuted row: slot (c*8+e)*64 + lane  <->  column (c*64+lane)*8 + e
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const int i = (c * 64 + lane) * 8;
-    if (i >= D) continue;
+  for (int c = 0; c < MAXC; ++c)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      red[(0 * 4 + wid) * D + i + e] = ag[c][e];
-      red[(1 * 4 + wid) * D + i + e] = ab[c][e];
+      red[(wid * 2 + 0) * SLOTS + (c * 8 + e) * 64 + lane] = ag[c][e];
+      red[(wid * 2 + 1) * SLOTS + (c * 8 + e) * 64 + lane] = ab[c][e];
     }
-  }
   __syncthreads();
-  // per-workgroup partials [block][2][D]: every workgroup hammering the same 8 KiB with float
-  // atomics runs ~14x below the atomic rate (MI355X_MICROARCH "contention"); a second tiny
-  // kernel sums the partials instead.
-  float* mine = part + (int64_t)blockIdx.x * 2 * D;
-  for (int i = threadIdx.x; i < D; i += 256) {
-    float sg = 0.f, sb = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { sg += red[(0 * 4 + w) * D + i]; sb += red[(1 * 4 + w) * D + i]; }
-    mine[i] = sg;
-    mine[D + i] = sb;
-  }
+  float* mine = part + (int64_t)blockIdx.x * 2 * SLOTS;
+  for (int i = threadIdx.x; i < 2 * SLOTS; i += 256)
+    mine[i] = red[i] + red[2 * SLOTS + i] + red[4 * SLOTS + i] + red[6 * SLOTS + i];
 }
 
 // out[j] += sum_b part[b][j]   (j < n): second stage of the column reductions.  blockIdx.y takes
 // 16 partial rows (16 independent loads in flight per thread), so only nblocks/16 adders meet on
 // an address.
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out0,
-                                                        float* __restrict__ out1, int nblocks, int n0, int n1) {
+                                                        float* __restrict__ out1, int nblocks, int n0, int n1,
+                                                        int slots /*0: plain rows; else ln_bwd's permuted rows*/) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int n = n0 + n1;
   if (j >= n) return;
+  int64_t src = j, stride = n;
+  if (slots) {  // column jj of half h sits at slot ((c*8+e)*64 + lane) with jj = (c*64+lane)*8 + e
+    const int h = j >= n0, jj = h ? j - n0 : j;
+    const int e = jj & 7, cl = jj >> 3, lane = cl & 63, c = cl >> 6;
+    src = (int64_t)h * slots + (c * 8 + e) * 64 + lane;
+    stride = 2 * (int64_t)slots;
+  }
   const int b0 = blockIdx.y * 16;
   float v[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = (b0 + k < nblocks) ? part[(int64_t)(b0 + k) * n + j] : 0.f;
+  for (int k = 0; k < 16; ++k) v[k] = (b0 + k < nblocks) ? part[(int64_t)(b0 + k) * stride + src] : 0.f;
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) s += v[k];
@@ -240,35 +238,48 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict_
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b = blockIdx.x / tiles, s0 = (blockIdx.x % tiles) * R;
   const int nrows = R + 6;
-  for (int r = wid; r < nrows; r += 4) {
-    const int s = s0 - 3 + r;
-    float v[MAXC][8];
-    const bool in = s >= 0 && s < S;
-    float mean = 0.f, rstd = 0.f;
-    if (in) {
-      load_row<T, MAXC>(x + ((int64_t)b * S + s) * D, D, lane, v);
-      row_stats<MAXC>(v, D, lane, eps, mean, rstd);
-      if (lane == 0 && r >= 3 && r < 3 + R) {
-        mean_o[(int64_t)b * S + s] = mean;
-        rstd_o[(int64_t)b * S + s] = rstd;
+  for (int r0 = wid; r0 < nrows; r0 += 8) {   // two rows (r0, r0+4) per iteration: their loads and
+    float v[2][MAXC][8];                        // reductions overlap
+    float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+    bool in[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = r0 + 4 * u, s = s0 - 3 + r;
+      in[u] = r < nrows && s >= 0 && s < S;
+      if (in[u]) load_row<T, MAXC>(x + ((int64_t)b * S + s) * D, D, lane, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = r0 + 4 * u, s = s0 - 3 + r;
+      if (in[u]) {
+        row_stats<MAXC>(v[u], D, lane, eps, mean[u], rstd[u]);
+        if (lane == 0 && r >= 3 && r < 3 + R) {
+          mean_o[(int64_t)b * S + s] = mean[u];
+          rstd_o[(int64_t)b * S + s] = rstd[u];
+        }
       }
     }
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-      const int i = (c * 64 + lane) * 8;
-      if (i >= D) continue;
-      float o[8];
-      if (in) {
-        float g[8], bb[8];
-        Vec8<float>::load(gamma + i, g);
-        Vec8<float>::load(beta + i, bb);
+    for (int u = 0; u < 2; ++u) {
+      const int r = r0 + 4 * u;
+      if (r >= nrows) continue;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + bb[e];
-      } else {
+      for (int c = 0; c < MAXC; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i >= D) continue;
+        float o[8];
+        if (in[u]) {
+          float g[8], bb[8];
+          Vec8<float>::load(gamma + i, g);
+          Vec8<float>::load(beta + i, bb);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+          for (int e = 0; e < 8; ++e) o[e] = (v[u][c][e] - mean[u]) * rstd[u] * g[e] + bb[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        }
+        Vec8<T>::store(tile + (int64_t)r * D + i, o);
       }
-      Vec8<T>::store(tile + (int64_t)r * D + i, o);
     }
   }
   __syncthreads();
@@ -285,13 +296,12 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict_
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
-        const T* p = tile + (int64_t)(r + k) * D + c0;
+        float nv[4];
+        Vec4<T>::load(tile + (int64_t)(r + k) * D + c0, nv);
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) acc[ch] += wk[ch][k] * to_f<T>(p[ch]);
+        for (int ch = 0; ch < 4; ++ch) acc[ch] += wk[ch][k] * nv[ch];
       }
-      T* q = u + ((int64_t)b * S + s) * D + c0;
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch) q[ch] = from_f<T>(acc[ch]);
+      Vec4<T>::store(u + ((int64_t)b * S + s) * D + c0, acc);
     }
   }
 }
@@ -309,13 +319,15 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
                                                          const float* __restrict__ mean_i,
                                                          const float* __restrict__ rstd_i,
                                                          const float* __restrict__ w, T* __restrict__ dn,
-                                                         float* __restrict__ part, int S, int D, int slices) {
+                                                         float* __restrict__ part, int S, int D, int slices,
+                                                         int bps /*workgroups per (sample, slice)*/) {
   __shared__ float red[4][256 * 7];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int b = blockIdx.x / slices, c0 = (blockIdx.x % slices) * 256 + lane * 4;
+  const int j4 = blockIdx.x % bps, bs = blockIdx.x / bps;
+  const int b = bs / slices, c0 = (bs % slices) * 256 + lane * 4;
   const bool act = c0 < D;
-  const int seg = (S + 3) / 4;
-  const int sb = wid * seg, se = min(S, sb + seg);
+  constexpr int seg = 16;   // rows per wave: short waves, many of them (latency hidden by parallelism)
+  const int sb = min(S, (j4 * 4 + wid) * seg), se = min(S, sb + seg);
   float wk[4][7], aw[4][7], g[4], bt[4];
 #pragma unroll
   for (int ch = 0; ch < 4; ++ch) {
@@ -330,11 +342,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
     if (act && s >= 0 && s < S) {
       const int64_t off = ((int64_t)b * S + s) * D + c0;
       const float mean = mean_i[(int64_t)b * S + s], rstd = rstd_i[(int64_t)b * S + s];
+      float xv4[4];
+      Vec4<T>::load(du + off, odu);
+      Vec4<T>::load(x + off, xv4);
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
-        odu[ch] = to_f<T>(du[off + ch]);
-        on[ch] = (to_f<T>(x[off + ch]) - mean) * rstd * g[ch] + bt[ch];
-      }
+      for (int ch = 0; ch < 4; ++ch) on[ch] = (xv4[ch] - mean) * rstd * g[ch] + bt[ch];
     } else {
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) { odu[ch] = 0.f; on[ch] = 0.f; }
@@ -342,27 +354,34 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
   };
 #pragma unroll
   for (int j = 0; j < 6; ++j) fetch(sb - 3 + j, wdu[j + 1], wn[j + 1]);
-  for (int s = sb; s < se; ++s) {
+  constexpr int CH = 8;  // rows whose loads are issued together (memory-level parallelism per wave)
+  for (int s0 = sb; s0 < se; s0 += CH) {
+    float ndu[CH][4], nn[CH][4];
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
+    for (int j = 0; j < CH; ++j) fetch(s0 + 3 + j, ndu[j], nn[j]);
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) { wdu[j][ch] = wdu[j + 1][ch]; wn[j][ch] = wn[j + 1][ch]; }
-    fetch(s + 3, wdu[6], wn[6]);
-    // dn[s] = sum_k w[k] * du[s + 3 - k]  -> window index (3 + 3 - k) = 6 - k
-    float o[4];
+    for (int j = 0; j < CH; ++j) {
+      const int s = s0 + j;
+      if (s < se) {
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-      float a = 0.f;
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
-      for (int k = 0; k < 7; ++k) a += wk[ch][k] * wdu[6 - k][ch];
-      o[ch] = a;
+          for (int ch = 0; ch < 4; ++ch) { wdu[t][ch] = wdu[t + 1][ch]; wn[t][ch] = wn[t + 1][ch]; }
 #pragma unroll
-      for (int k = 0; k < 7; ++k) aw[ch][k] += wdu[3][ch] * wn[k][ch];  // du[s] * n[s+k-3]
-    }
-    if (act) {
-      T* q = dn + ((int64_t)b * S + s) * D + c0;
+        for (int ch = 0; ch < 4; ++ch) { wdu[6][ch] = ndu[j][ch]; wn[6][ch] = nn[j][ch]; }
+        // dn[s] = sum_k w[k] * du[s + 3 - k]  -> window index 6 - k;  dw[k] += du[s] * n[s + k - 3]
+        float o[4];
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) q[ch] = from_f<T>(o[ch]);
+        for (int ch = 0; ch < 4; ++ch) {
+          float a = 0.f;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) a += wk[ch][k] * wdu[6 - k][ch];
+          o[ch] = a;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) aw[ch][k] += wdu[3][ch] * wn[k][ch];
+        }
+        if (act) Vec4<T>::store(dn + ((int64_t)b * S + s) * D + c0, o);
+      }
     }
   }
 #pragma unroll
@@ -370,9 +389,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
 #pragma unroll
     for (int k = 0; k < 7; ++k) red[wid][(lane * 4 + ch) * 7 + k] = aw[ch][k];
   __syncthreads();
-  // per-sample partials [b][D*7] (plain stores); colreduce_kernel sums them over b
-  const int cbase = (blockIdx.x % slices) * 256;
-  float* mine = part + (int64_t)b * D * 7;
+  // per-workgroup partials [b*bps + j4][D*7] (plain stores); colreduce_kernel sums them
+  const int cbase = (bs % slices) * 256;
+  float* mine = part + ((int64_t)b * bps + j4) * D * 7;
   for (int i = threadIdx.x; i < 256 * 7; i += 256) {
     if (cbase + i / 7 < D) mine[(int64_t)cbase * 7 + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
   }
@@ -421,11 +440,15 @@ extern "C" int vmr_layernorm_bwd(const void* dy, const void* x, const float* gam
   if (int rc = ln_check(D)) return rc;
   VMR_CHECK(dy && x && gamma && mean && rstd && dx, "vmr_layernorm_bwd: null pointer");
   VMR_CHECK((dgamma == nullptr) == (dbeta == nullptr), "vmr_layernorm_bwd: dgamma/dbeta must come together");
-  VMR_CHECK(!dgamma || workspace, "vmr_layernorm_bwd: dgamma/dbeta need the workspace (VMR_LN_BWD_WS_FLOATS(D))");
+  VMR_CHECK(!dgamma || workspace, "vmr_layernorm_bwd: dgamma/dbeta need the workspace (VMR_LN_BWD_WS_FLOATS(rows, D))");
   if (rows == 0) return 0;
-  const int grid = (int)min((int64_t)VMR_LN_BWD_MAX_BLOCKS, (rows + 7) / 8);   // >= 2 rows per wave: the prefetch pays
+  const int grid = (int)((rows + LNB_ROWS - 1) / LNB_ROWS);
+  VMR_CHECK(grid <= VMR_LN_BWD_MAX_BLOCKS || !dgamma, "vmr_layernorm_bwd: more than %d row blocks (rows=%lld): split the call",
+            VMR_LN_BWD_MAX_BLOCKS, (long long)rows);
   float* part = dgamma ? workspace : nullptr;
-  const size_t lds = (size_t)2 * 4 * D * sizeof(float);
+  const int maxc = D <= 512 ? 1 : (D <= 1024 ? 2 : 4);
+  const int slots = maxc * 8 * 64;
+  const size_t lds = (size_t)4 * 2 * slots * sizeof(float);
   if (dtype == VMR_BF16)
     LN_DISPATCH(D, hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, MC>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
                                       (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres,
@@ -437,7 +460,7 @@ extern "C" int vmr_layernorm_bwd(const void* dy, const void* x, const float* gam
   VMR_LAUNCH_CHECK();
   if (part) {
     hipLaunchKernelGGL(colreduce_kernel, dim3(cdiv(2 * D, 256), cdiv(grid, 16)), dim3(256), 0, (hipStream_t)stream,
-                       part, dgamma, dbeta, grid, D, D);
+                       part, dgamma, dbeta, grid, D, D, slots);
     VMR_LAUNCH_CHECK();
   }
   return 0;
@@ -449,7 +472,9 @@ extern "C" int vmr_ln_dwconv_fwd(const void* x, const float* gamma, const float*
   VMR_CHECK(x && gamma && beta && w && u && mean && rstd, "vmr_ln_dwconv_fwd: null pointer");
   if (B == 0 || S == 0) return 0;
   const size_t esz = dtype == VMR_BF16 ? 2 : 4;
-  int nrows = (int)min((size_t)32, (size_t)(128 * 1024) / ((size_t)D * esz));
+  // 16-row LDS tiles (10 output rows + halo): 32 KiB at D=1024 bf16 -> 4 workgroups / CU, 13 tiles
+  // per 128-frame clip; the extra halo re-reads are L2 hits, the parallelism hides the row latency
+  int nrows = (int)min((size_t)16, (size_t)(128 * 1024) / ((size_t)D * esz));
   VMR_CHECK(nrows >= 7, "vmr_ln_dwconv_fwd: D too large for the LDS tile");
   int R = min(nrows - 6, S);
   const int tiles = cdiv(S, R);
@@ -481,17 +506,18 @@ extern "C" int vmr_dwconv_bwd(const void* du, const void* x, const float* gamma,
   VMR_CHECK(D % 4 == 0, "vmr_dwconv_bwd: D %% 4 != 0");
   if (B == 0 || S == 0) return 0;
   const int slices = cdiv(D, 256);
+  const int bps = VMR_DWCONV_BWD_BPS(S);
   if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(dwconv_bwd_kernel<bf16_t>, dim3(B * slices), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(dwconv_bwd_kernel<bf16_t>, dim3(B * slices * bps), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)du, (const bf16_t*)x, gamma, beta, mean, rstd, w, (bf16_t*)dn, workspace, S, D,
-                       slices);
+                       slices, bps);
   else
-    hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(B * slices), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(B * slices * bps), dim3(256), 0, (hipStream_t)stream,
                        (const float*)du, (const float*)x, gamma, beta, mean, rstd, w, (float*)dn, workspace, S, D,
-                       slices);
+                       slices, bps);
   VMR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colreduce_kernel, dim3(cdiv(D * 7, 256), cdiv(B, 16)), dim3(256), 0, (hipStream_t)stream,
-                     workspace, dw, dw, B, D * 7, 0);
+  hipLaunchKernelGGL(colreduce_kernel, dim3(cdiv(D * 7, 256), cdiv(B * bps, 16)), dim3(256), 0, (hipStream_t)stream,
+                     workspace, dw, dw, B * bps, D * 7, 0, 0);
   VMR_LAUNCH_CHECK();
   return 0;
 }

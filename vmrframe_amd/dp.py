@@ -70,7 +70,7 @@ class GradReducer:
         for n in names:
             o, k = opt.offsets[n], params[n].numel()
             if cur is None or (cur["hi"] - o) > per:
-                cur = {"lo": o, "hi": o + (k + 3) // 4 * 4, "pending": 0, "count": 0}
+                cur = {"lo": o, "hi": o + (k + 7) // 8 * 8, "pending": 0, "count": 0}
                 self.buckets.append(cur)
             cur["lo"] = o
             cur["count"] += 1

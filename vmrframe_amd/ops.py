@@ -8,6 +8,7 @@ Dropout never stores a mask: every site gets a (p, seed, step_ptr) triple from
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 import os
@@ -20,6 +21,12 @@ from . import _lib as L
 
 NO_DROP = (0.0, 0, None)
 GEMM_HOOK = None   # bench.py: callable(launch, M, N, K, ta, tb, Z, dtype) timing the launch with HIP events
+# Optional side stream for the weight-gradient GEMMs (dW = dY^T.X).  They are off the backward's
+# critical path (only the optimizer needs them), so the trainer lets them run beside the dX chain:
+# the hardware fills the single-round tails / epilogue bursts of one kernel with workgroups of the
+# other instead of idling at every in-order kernel boundary.  Whoever sets this MUST make the main
+# stream wait for it after backward() (trainer.GraphedTrainStep does); default None = in-order.
+DW_SIDE_STREAM = None
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -104,6 +111,7 @@ def bmm4(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, ta: int, tb: int, *,
 
 
 SPLITK_TARGET = int(os.environ.get("VMR_SPLITK_TARGET", "256"))   # workgroups to aim for in dW products
+USE_SLABS = os.environ.get("VMR_SPLITK_SLABS", "1") != "0"
 
 
 def splitk_for(M: int, N: int, K: int) -> int:
@@ -135,7 +143,9 @@ class WeightCache:
         self.store = {}
 
     def clear(self):
-        self.store.clear()
+        """Forget the cast copies (the masters changed); mirror-backed entries stay valid because
+        the optimizer kernel rewrites the mirror in place."""
+        self.store = {k: v for k, v in self.store.items() if getattr(v[1], "_vmr_mirror", False)}
 
     def get(self, params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
         key = (tuple(id(p) for p in params), dtype)
@@ -143,6 +153,21 @@ class WeightCache:
         hit = self.store.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
+        if dtype == torch.bfloat16:
+            # masters living in the flat arena have a bf16 mirror maintained by the AdamW kernel
+            # (optim.FlatArena): a group laid out back to back is used in place, no cast launch
+            mirrors = [getattr(p, "_vmr_w16", None) for p in params]
+            if all(m is not None for m in mirrors):
+                K = mirrors[0].numel() // mirrors[0].shape[0]
+                ok = K % 8 == 0
+                for a_, b_ in zip(mirrors[:-1], mirrors[1:]):
+                    ok = ok and a_.data_ptr() + a_.numel() * 2 == b_.data_ptr()
+                if ok:
+                    n = sum(m.shape[0] for m in mirrors)
+                    w = torch.as_strided(mirrors[0], (n, K), (K, 1))
+                    w._vmr_mirror = True
+                    self.store[key] = (ver, w)
+                    return w
         with torch.no_grad():
             mats = [p.detach().reshape(p.shape[0], -1).contiguous() for p in params]
             K = mats[0].shape[1]
@@ -308,13 +333,29 @@ class _Linear(torch.autograd.Function):
         slots = [main_grad(w) for w in ctx.weights]
         if all(g is not None for g in slots) and all(int(np.prod(shp[1:])) == Kp for shp in wshapes):
             # accumulate straight into the flat gradient arena: no zero-fill, no autograd add
-            r = 0
-            for g_, shp in zip(slots, wshapes):
-                n = shp[0]
-                a = dz[:, r:r + n]
-                gemm(a, x, g_, n, Kp, M, 1, 1, a.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_ACCUM,
-                     splitk=splitk_for(n, Kp, M))
-                r += n
+            side = DW_SIDE_STREAM
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                dz.record_stream(side)
+                x.record_stream(side)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                r = 0
+                for g_, shp in zip(slots, wshapes):
+                    n = shp[0]
+                    a = dz[:, r:r + n]
+                    sk_ = splitk_for(n, Kp, M)
+                    if sk_ > 1 and USE_SLABS:
+                        # split-K partials as plain fp32 slabs + one reduce pass: float atomics from
+                        # every workgroup of a single-round grid land together and run far below HBM speed
+                        ws = torch.empty(sk_, n, Kp, device=dy.device, dtype=torch.float32)
+                        gemm(a, x, ws, n, Kp, M, 1, 1, a.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_SLAB,
+                             splitk=sk_)
+                        L.check(lib.vmr_splitk_reduce(ws.data_ptr(), g_.data_ptr(), sk_, n * Kp, L.stream_ptr()),
+                                "vmr_splitk_reduce")
+                    else:
+                        gemm(a, x, g_, n, Kp, M, 1, 1, a.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_ACCUM,
+                             splitk=sk_)
+                    r += n
             if db is not None and Np != N:
                 db = db[:N]
             return (dx, None if bgrad is not None else db, dres, None, None, None, None, *([None] * len(wshapes)))
@@ -379,7 +420,7 @@ class _LayerNorm(torch.autograd.Function):
         dg = mg if direct else torch.zeros(D, device=x.device, dtype=torch.float32)
         db = mb if direct else torch.zeros_like(dg)
         dpos = torch.zeros(pshape, device=x.device, dtype=torch.float32) if pshape else None
-        ws = torch.empty(L.LN_BWD_MAX_BLOCKS * 2 * D, device=x.device, dtype=torch.float32)
+        ws = torch.empty(L.ln_bwd_ws_floats(rows, D), device=x.device, dtype=torch.float32)
         L.check(L.lib().vmr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                           rstd.data_ptr(), None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                           _ptr(dpos), ws.data_ptr(), S, rows, D, L.dtype_code(x), drop[0], drop[1],
@@ -433,7 +474,8 @@ class _LnDwConv(torch.autograd.Function):
         direct = mg is not None and mb is not None and mw is not None
         dw = mw if direct else torch.zeros(D, 7, device=x.device, dtype=torch.float32)
         r = 0
-        ws = torch.empty(max(max(b for b, _ in segs) * D * 7, L.LN_BWD_MAX_BLOCKS * 2 * D), device=x.device,
+        ws = torch.empty(max(max(b * ((sq + 63) // 64) for b, sq in segs) * D * 7, L.ln_bwd_ws_floats(rows, D)),
+                         device=x.device,
                          dtype=torch.float32)
         for (B, S) in segs:
             L.check(lib.vmr_dwconv_bwd(du[r:].data_ptr(), x[r:].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
@@ -695,6 +737,95 @@ class _Dropout(torch.autograd.Function):
 
 def dropout(x, drop):
     return x if drop[0] <= 0.0 else _Dropout.apply(x, drop)
+
+
+# ---------------------------------------------------------------------------
+# fused elementwise programs (dual-attention gating, CQ concat)
+# ---------------------------------------------------------------------------
+def _elt(op, a, b, c, d, e, rowmask, outs, rows, D):
+    o = [_ptr(t) for t in outs] + [None] * (4 - len(outs))
+    L.check(L.lib().vmr_eltwise(op, _ptr(a), _ptr(b), _ptr(c), _ptr(d), _ptr(e), _ptr(rowmask), o[0], o[1], o[2], o[3],
+                                rows, D, L.dtype_code(a), L.stream_ptr()), "vmr_eltwise")
+
+
+class _CrossGate(torch.autograd.Function):
+    """s_score * x_value + x_score * s_value (reference models/layers.py:374), one pass."""
+
+    @staticmethod
+    def forward(ctx, ss, sv, xs, xv):
+        L.require_gpu(ss)
+        ss, sv, xs, xv = (t.contiguous() for t in (ss, sv, xs, xv))
+        out = torch.empty_like(ss)
+        _elt(0, ss, sv, xs, xv, None, None, [out], ss.shape[0], ss.shape[1])
+        ctx.save_for_backward(ss, sv, xs, xv)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        ss, sv, xs, xv = ctx.saved_tensors
+        do = do.contiguous()
+        g = [torch.empty_like(ss) for _ in range(4)]
+        _elt(1, do, ss, sv, xs, xv, None, g, ss.shape[0], ss.shape[1])
+        return tuple(g)
+
+
+def cross_gate(ss, sv, xs, xv):
+    return _CrossGate.apply(ss, sv, xs, xv)
+
+
+class _SigmoidGate(torch.autograd.Function):
+    """sigmoid(mask_logits(scores, row_mask)) * values on the [rows, 2D] = (scores | values) GEMM
+    output (reference models/layers.py:380)."""
+
+    @staticmethod
+    def forward(ctx, sv2, rowmask):
+        L.require_gpu(sv2)
+        sv2 = sv2.contiguous()
+        rows, D = sv2.shape[0], sv2.shape[1] // 2
+        out = torch.empty(rows, D, device=sv2.device, dtype=sv2.dtype)
+        _elt(2, sv2, None, None, None, None, rowmask, [out], rows, D)
+        ctx.save_for_backward(sv2, rowmask)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        sv2, rowmask = ctx.saved_tensors
+        do = do.contiguous()
+        rows, D = do.shape
+        dsv = torch.empty_like(sv2)
+        _elt(3, do, sv2, None, None, None, rowmask, [dsv], rows, D)
+        return dsv, None
+
+
+def sigmoid_gate(sv2, rowmask_f32):
+    return _SigmoidGate.apply(sv2, rowmask_f32)
+
+
+class _Cat4(torch.autograd.Function):
+    """[C, c2q, C*c2q, C*q2c] of CQAttention (reference models/layers.py:424) in one pass."""
+
+    @staticmethod
+    def forward(ctx, C_, c2q, q2c):
+        L.require_gpu(C_)
+        C_, c2q, q2c = (t.contiguous() for t in (C_, c2q, q2c))
+        rows, D = C_.shape
+        out = torch.empty(rows, 4 * D, device=C_.device, dtype=C_.dtype)
+        _elt(4, C_, c2q, q2c, None, None, None, [out], rows, D)
+        ctx.save_for_backward(C_, c2q, q2c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dcat):
+        C_, c2q, q2c = ctx.saved_tensors
+        dcat = dcat.contiguous()
+        rows, D = C_.shape
+        g = [torch.empty_like(C_) for _ in range(3)]
+        _elt(5, dcat, C_, c2q, q2c, None, None, g, rows, D)
+        return tuple(g)
+
+
+def cat4(C_, c2q, q2c):
+    return _Cat4.apply(C_, c2q, q2c)
 
 
 # ---------------------------------------------------------------------------

@@ -35,14 +35,21 @@ class FlatArena:
     """Contiguous fp32 parameter / gradient arenas over the parameters that receive
     gradients (device-agnostic: pure tensor plumbing, also used by the gloo DP tests)."""
 
-    def __init__(self, model: torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, bf16_mirror: bool = False):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None]
         assert named, "FlatArena needs one backward pass first (to learn which parameters get gradients)"
+        # weights that feed ONE grouped GEMM (q|k|v, ...) are laid out back to back so their
+        # compute-dtype mirror is a single [sum N, K] matrix without any per-step concat / cast
+        groups = model.weight_groups() if hasattr(model, "weight_groups") else []
+        have = dict(named)
+        first = [n for grp in groups if all(g in have for g in grp) for n in grp]
+        seen = set(first)
+        named = [(n, have[n]) for n in first] + [(n, p) for n, p in named if n not in seen]
         dev = named[0][1].device
         total, offs = 0, {}
         for n, p in named:
             offs[n] = total
-            total += (p.numel() + 3) // 4 * 4            # keep every tensor 16-byte aligned
+            total += (p.numel() + 7) // 8 * 8            # 16-byte aligned slots in the fp32 AND the bf16 arena
         self.flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros_like(self.flat_p)
         self.decay = torch.zeros(total, device=dev, dtype=torch.uint8)
@@ -57,6 +64,13 @@ class FlatArena:
                 self.decay[o:o + k] = 1
         self.names: List[str] = [n for n, _ in named]
         self.offsets = offs
+        self.flat_w = None
+        if bf16_mirror:
+            # bf16 copy of every master weight, refreshed by the fused AdamW kernel itself
+            self.flat_w = self.flat_p.to(torch.bfloat16)
+            for n, p in named:
+                o, k = offs[n], p.numel()
+                p._vmr_w16 = self.flat_w[o:o + k].view(p.shape)
 
 
 class FlatAdamW:
@@ -73,7 +87,7 @@ class FlatAdamW:
 
     # -- arena -----------------------------------------------------------------
     def _build(self):
-        self.arena = FlatArena(self.model)
+        self.arena = FlatArena(self.model, bf16_mirror=getattr(self.model, "compute_dtype", None) == torch.bfloat16)
         L.require_gpu(self.arena.flat_p)
         self.m = torch.zeros_like(self.arena.flat_p)
         self.v = torch.zeros_like(self.arena.flat_p)
@@ -125,7 +139,8 @@ class FlatAdamW:
         L.check(lib.vmr_sumsq(A.flat_g.data_ptr(), self.gnorm_sq.data_ptr(), n, st), "vmr_sumsq")
         self._device_lr()
         L.check(lib.vmr_adamw(A.flat_p.data_ptr(), A.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                              A.decay.data_ptr(), None, self.gnorm_sq.data_ptr(), self.max_norm, 0.0,
+                              A.decay.data_ptr(), None if A.flat_w is None else A.flat_w.data_ptr(),
+                              self.gnorm_sq.data_ptr(), self.max_norm, 0.0,
                               self.betas[0], self.betas[1], self.eps, self.wd, 0, self.lr_t.data_ptr(),
                               self.step_t.data_ptr(), n, st), "vmr_adamw")
         self.step_t += 1             # scheduler.step() of the reference loop

@@ -24,7 +24,7 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, engine, configs, reducer=None, warmup: int = 3):
+    def __init__(self, model, optimizer, engine, configs, reducer=None, warmup: int = 3, overlap_dw: bool = False):
         self.model, self.opt, self.engine, self.cfg, self.reducer = model, optimizer, engine, configs, reducer
         self.warmup = max(2, warmup)        # >= 2: the flat arena exists only after the first optimizer step
         self.g_fb: Optional[torch.cuda.CUDAGraph] = None
@@ -33,12 +33,22 @@ class GraphedTrainStep:
         self.loss = None
         self.out = None
         self.split = reducer is not None and getattr(reducer, "world", 1) > 1
+        self.dw_stream = torch.cuda.Stream() if overlap_dw else None
 
     def _fwd_bwd(self):
+        from . import ops
         self.model.drop_step.add_(1)
         self.opt.zero_grad()
         loss, out = self.engine(self.model, self.static_batch, self.cfg, "train")
-        loss.backward()
+        if self.dw_stream is not None and self.opt.arena is not None:
+            ops.DW_SIDE_STREAM = self.dw_stream        # dW GEMMs run beside the dX chain
+            self.dw_stream.wait_stream(torch.cuda.current_stream())   # ... after zero_grad / the forward
+        try:
+            loss.backward()
+        finally:
+            if ops.DW_SIDE_STREAM is not None:
+                torch.cuda.current_stream().wait_stream(self.dw_stream)   # join before the optimizer
+            ops.DW_SIDE_STREAM = None
         return loss, out
 
     def capture(self, batch: Dict[str, torch.Tensor]):
