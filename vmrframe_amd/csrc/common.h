@@ -102,6 +102,30 @@ template <> struct Vec4<float> {
   }
 };
 
+template <typename T> struct Vec2;
+template <> struct Vec2<bf16_t> {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[2]) {
+    bf16x2 x = *reinterpret_cast<const bf16x2*>(p);
+    v[0] = (float)x[0]; v[1] = (float)x[1];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[2]) {
+    bf16x2 x; x[0] = (bf16_t)v[0]; x[1] = (bf16_t)v[1];
+    *reinterpret_cast<bf16x2*>(p) = x;
+  }
+};
+template <> struct Vec2<float> {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[2]) {
+    f32x2 x = *reinterpret_cast<const f32x2*>(p);
+    v[0] = x[0]; v[1] = x[1];
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[2]) {
+    f32x2 x; x[0] = v[0]; x[1] = v[1];
+    *reinterpret_cast<f32x2*>(p) = x;
+  }
+};
+
 // ---------------------------------------------------------------- dropout
 // Counter-based keep decision: a pure function of (seed, element index), so the
 // backward pass regenerates the mask instead of storing it.  One strong 2x32-bit

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      int64_t rows, int D, float drop_p, uint32_t seed0,
                                                      const uint32_t* __restrict__ step) {
   const uint32_t seed = vmr_seed(seed0, step);
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar branches
   const uint32_t thresh = vmr_drop_thresh(drop_p);
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   const uint32_t seed = vmr_seed(seed0, step);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][MAXC*8][64 lanes]
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar branches
   const uint32_t thresh = vmr_drop_thresh(drop_p);
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int64_t r0 = (int64_t)blockIdx.x * LNB_ROWS + wid * 2;
@@ -125,10 +127,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     ok[u] = r0 + u < rows;
-    if (ok[u]) {
-      load_row<T, MAXC>(x + (r0 + u) * D, D, lane, xv[u]);
-      load_row<T, MAXC>(dy + (r0 + u) * D, D, lane, gv[u]);
-    }
+    const int64_t rc = min(r0 + u, rows - 1);   // clamped: both rows' loads issue unconditionally
+    load_row<T, MAXC>(x + rc * D, D, lane, xv[u]);
+    load_row<T, MAXC>(dy + rc * D, D, lane, gv[u]);
   }
   float ag[MAXC][8], ab[MAXC][8];
 #pragma unroll
@@ -235,49 +236,44 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict_
                                                             int S, int D, int R, int tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* tile = reinterpret_cast<T*>(smem);  // [R+6][D]
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar branches
   const int b = blockIdx.x / tiles, s0 = (blockIdx.x % tiles) * R;
   const int nrows = R + 6;
-  for (int r0 = wid; r0 < nrows; r0 += 8) {   // two rows (r0, r0+4) per iteration: their loads and
-    float v[2][MAXC][8];                        // reductions overlap
-    float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
-    bool in[2];
+  constexpr int RW = 4;   // rows a wave keeps in flight: their (unconditional, index-clamped) loads issue together
+  for (int rb = wid; rb < nrows; rb += 4 * RW) {
+    float v[RW][MAXC][8];
+    float mean[RW], rstd[RW], msk[RW];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int r = r0 + 4 * u, s = s0 - 3 + r;
-      in[u] = r < nrows && s >= 0 && s < S;
-      if (in[u]) load_row<T, MAXC>(x + ((int64_t)b * S + s) * D, D, lane, v[u]);
+    for (int u = 0; u < RW; ++u) {
+      const int r = rb + 4 * u, s = s0 - 3 + r;
+      msk[u] = (r < nrows && s >= 0 && s < S) ? 1.f : 0.f;   // zero padding of the conv / unused slots
+      const int sc = min(max(s, 0), S - 1);
+      load_row<T, MAXC>(x + ((int64_t)b * S + sc) * D, D, lane, v[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int r = r0 + 4 * u, s = s0 - 3 + r;
-      if (in[u]) {
-        row_stats<MAXC>(v[u], D, lane, eps, mean[u], rstd[u]);
-        if (lane == 0 && r >= 3 && r < 3 + R) {
-          mean_o[(int64_t)b * S + s] = mean[u];
-          rstd_o[(int64_t)b * S + s] = rstd[u];
-        }
+    for (int u = 0; u < RW; ++u) {
+      const int r = rb + 4 * u, s = s0 - 3 + r;
+      row_stats<MAXC>(v[u], D, lane, eps, mean[u], rstd[u]);
+      if (lane == 0 && msk[u] != 0.f && r >= 3 && r < 3 + R) {
+        mean_o[(int64_t)b * S + s] = mean[u];
+        rstd_o[(int64_t)b * S + s] = rstd[u];
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int r = r0 + 4 * u;
-      if (r >= nrows) continue;
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = (c * 64 + lane) * 8;
+      if (i >= D) continue;
+      float g[8], bb[8];
+      Vec8<float>::load(gamma + i, g);
+      Vec8<float>::load(beta + i, bb);
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) {
-        const int i = (c * 64 + lane) * 8;
-        if (i >= D) continue;
+      for (int u = 0; u < RW; ++u) {
+        const int r = rb + 4 * u;
+        if (r >= nrows) continue;
         float o[8];
-        if (in[u]) {
-          float g[8], bb[8];
-          Vec8<float>::load(gamma + i, g);
-          Vec8<float>::load(beta + i, bb);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (v[u][c][e] - mean[u]) * rstd[u] * g[e] + bb[e];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = 0.f;
-        }
+        for (int e = 0; e < 8; ++e) o[e] = ((v[u][c][e] - mean[u]) * rstd[u] * g[e] + bb[e]) * msk[u];
         Vec8<T>::store(tile + (int64_t)r * D + i, o);
       }
     }
@@ -307,11 +303,13 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict_
 }
 
 // ------------------------------------------------------------- dwconv bwd
-// Workgroup = (sample b, slice of 256 channels); wave w streams rows
-// [w*S/4, (w+1)*S/4) (+3-row halos) keeping 7-row windows of du and n=LN(x) in
-// registers; each lane owns 4 channels.  dn[s] = sum_k w[k]*du[s-k+3];
-// dw[k] += sum_s du[s]*n[s+k-3].  dw partials of the 4 waves are combined in
-// LDS and flushed with contiguous float atomics.
+// Workgroup = (sample b, slice of 128 channels, 4 x 16 rows); wave w streams 16 rows (+3-row
+// halos) keeping 7-row windows of du and n=LN(x) in registers; each lane owns 2 channels (small
+// register footprint -> many short waves resident: this kernel is latency-, not bandwidth-bound).
+// dn[s] = sum_k w[k]*du[s-k+3];  dw[k] += sum_s du[s]*n[s+k-3].  The 4 waves' dw partials are
+// combined in LDS and stored as one partial row per workgroup (colreduce_kernel sums them).
+constexpr int DWB_CH = 2, DWB_SLICE = 64 * DWB_CH;
+
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ du, const T* __restrict__ x,
                                                          const float* __restrict__ gamma,
@@ -321,78 +319,84 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
                                                          const float* __restrict__ w, T* __restrict__ dn,
                                                          float* __restrict__ part, int S, int D, int slices,
                                                          int bps /*workgroups per (sample, slice)*/) {
-  __shared__ float red[4][256 * 7];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  constexpr int CHN = DWB_CH;
+  __shared__ float red[4][DWB_SLICE * 7];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar branches
   const int j4 = blockIdx.x % bps, bs = blockIdx.x / bps;
-  const int b = bs / slices, c0 = (bs % slices) * 256 + lane * 4;
+  const int b = bs / slices, c0 = (bs % slices) * DWB_SLICE + lane * CHN;
   const bool act = c0 < D;
-  constexpr int seg = 16;   // rows per wave: short waves, many of them (latency hidden by parallelism)
+  constexpr int seg = 16;   // rows per wave
   const int sb = min(S, (j4 * 4 + wid) * seg), se = min(S, sb + seg);
-  float wk[4][7], aw[4][7], g[4], bt[4];
+  float wk[CHN][7], aw[CHN][7], g[CHN], bt[CHN];
 #pragma unroll
-  for (int ch = 0; ch < 4; ++ch) {
+  for (int ch = 0; ch < CHN; ++ch) {
     g[ch] = act ? gamma[c0 + ch] : 0.f;
     bt[ch] = act ? beta[c0 + ch] : 0.f;
 #pragma unroll
     for (int k = 0; k < 7; ++k) { wk[ch][k] = act ? w[(c0 + ch) * 7 + k] : 0.f; aw[ch][k] = 0.f; }
   }
-  // windows: index j holds row (cur - 3 + j), cur = the row whose dn is produced
-  float wdu[7][4], wn[7][4];
-  auto fetch = [&](int s, float (&odu)[4], float (&on)[4]) {
-    if (act && s >= 0 && s < S) {
-      const int64_t off = ((int64_t)b * S + s) * D + c0;
-      const float mean = mean_i[(int64_t)b * S + s], rstd = rstd_i[(int64_t)b * S + s];
-      float xv4[4];
-      Vec4<T>::load(du + off, odu);
-      Vec4<T>::load(x + off, xv4);
+  float wdu[7][CHN], wn[7][CHN];   // window index j holds row (cur - 3 + j)
+  // branch-free: out-of-range rows / channels load a clamped (valid) address and are zeroed by a
+  // select, so the 16 loads of a chunk issue back to back instead of one predicated region each
+  const int c0c = act ? c0 : 0;
+  auto fetch = [&](int s, float (&odu)[CHN], float (&on)[CHN]) {
+    const bool valid = act && s >= 0 && s < S;
+    const int sc = min(max(s, 0), S - 1);
+    const int64_t off = ((int64_t)b * S + sc) * D + c0c;
+    const float mean = mean_i[(int64_t)b * S + sc], rstd = rstd_i[(int64_t)b * S + sc];
+    float xv[CHN], dv[CHN];
+    Vec2<T>::load(du + off, dv);
+    Vec2<T>::load(x + off, xv);
+    // multiply by a 0/1 mask (NOT a select): the compiler must keep the loads unconditional, so all
+    // loads of a chunk are in flight together; a select lets it sink each load into its own branch
+    const float m = valid ? 1.f : 0.f;
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) on[ch] = (xv4[ch] - mean) * rstd * g[ch] + bt[ch];
-    } else {
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch) { odu[ch] = 0.f; on[ch] = 0.f; }
+    for (int ch = 0; ch < CHN; ++ch) {
+      odu[ch] = dv[ch] * m;
+      on[ch] = ((xv[ch] - mean) * rstd * g[ch] + bt[ch]) * m;
     }
   };
 #pragma unroll
   for (int j = 0; j < 6; ++j) fetch(sb - 3 + j, wdu[j + 1], wn[j + 1]);
-  constexpr int CH = 8;  // rows whose loads are issued together (memory-level parallelism per wave)
-  for (int s0 = sb; s0 < se; s0 += CH) {
-    float ndu[CH][4], nn[CH][4];
+  constexpr int CHK = 8;  // rows whose loads are issued together
+  for (int s0 = sb; s0 < se; s0 += CHK) {
+    float ndu[CHK][CHN], nn[CHK][CHN];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) fetch(s0 + 3 + j, ndu[j], nn[j]);
+    for (int j = 0; j < CHK; ++j) fetch(s0 + 3 + j, ndu[j], nn[j]);
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
+    for (int j = 0; j < CHK; ++j) {
       const int s = s0 + j;
       if (s < se) {
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
-          for (int ch = 0; ch < 4; ++ch) { wdu[t][ch] = wdu[t + 1][ch]; wn[t][ch] = wn[t + 1][ch]; }
+          for (int ch = 0; ch < CHN; ++ch) { wdu[t][ch] = wdu[t + 1][ch]; wn[t][ch] = wn[t + 1][ch]; }
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) { wdu[6][ch] = ndu[j][ch]; wn[6][ch] = nn[j][ch]; }
-        // dn[s] = sum_k w[k] * du[s + 3 - k]  -> window index 6 - k;  dw[k] += du[s] * n[s + k - 3]
-        float o[4];
+        for (int ch = 0; ch < CHN; ++ch) { wdu[6][ch] = ndu[j][ch]; wn[6][ch] = nn[j][ch]; }
+        float o[CHN];
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
+        for (int ch = 0; ch < CHN; ++ch) {
           float a = 0.f;
 #pragma unroll
-          for (int k = 0; k < 7; ++k) a += wk[ch][k] * wdu[6 - k][ch];
+          for (int k = 0; k < 7; ++k) a += wk[ch][k] * wdu[6 - k][ch];   // dn[s] = sum_k w[k]*du[s+3-k]
           o[ch] = a;
 #pragma unroll
-          for (int k = 0; k < 7; ++k) aw[ch][k] += wdu[3][ch] * wn[k][ch];
+          for (int k = 0; k < 7; ++k) aw[ch][k] += wdu[3][ch] * wn[k][ch];  // du[s] * n[s+k-3]
         }
-        if (act) Vec4<T>::store(dn + ((int64_t)b * S + s) * D + c0, o);
+        if (act) Vec2<T>::store(dn + ((int64_t)b * S + s) * D + c0, o);
       }
     }
   }
 #pragma unroll
-  for (int ch = 0; ch < 4; ++ch)
+  for (int ch = 0; ch < CHN; ++ch)
 #pragma unroll
-    for (int k = 0; k < 7; ++k) red[wid][(lane * 4 + ch) * 7 + k] = aw[ch][k];
+    for (int k = 0; k < 7; ++k) red[wid][(lane * CHN + ch) * 7 + k] = aw[ch][k];
   __syncthreads();
   // per-workgroup partials [b*bps + j4][D*7] (plain stores); colreduce_kernel sums them
-  const int cbase = (bs % slices) * 256;
+  const int cbase = (bs % slices) * DWB_SLICE;
   float* mine = part + ((int64_t)b * bps + j4) * D * 7;
-  for (int i = threadIdx.x; i < 256 * 7; i += 256) {
+  for (int i = threadIdx.x; i < DWB_SLICE * 7; i += 256) {
     if (cbase + i / 7 < D) mine[(int64_t)cbase * 7 + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
   }
 }
@@ -503,9 +507,9 @@ extern "C" int vmr_dwconv_bwd(const void* du, const void* x, const float* gamma,
                               const float* mean, const float* rstd, const float* w, void* dn, float* dw,
                               float* workspace, int B, int S, int D, int dtype, void* stream) {
   VMR_CHECK(du && x && gamma && beta && mean && rstd && w && dn && dw && workspace, "vmr_dwconv_bwd: null pointer");
-  VMR_CHECK(D % 4 == 0, "vmr_dwconv_bwd: D %% 4 != 0");
+  VMR_CHECK(D % 2 == 0, "vmr_dwconv_bwd: D %% 2 != 0");
   if (B == 0 || S == 0) return 0;
-  const int slices = cdiv(D, 256);
+  const int slices = cdiv(D, DWB_SLICE);
   const int bps = VMR_DWCONV_BWD_BPS(S);
   if (dtype == VMR_BF16)
     hipLaunchKernelGGL(dwconv_bwd_kernel<bf16_t>, dim3(B * slices * bps), dim3(256), 0, (hipStream_t)stream,

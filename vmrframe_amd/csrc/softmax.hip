@@ -14,9 +14,9 @@
 
 namespace {
 
-constexpr int MAXN = 16;
+constexpr int MAXN_MAX = 16;  // kernels are instantiated for 1/2/4/8/16 columns per lane
 
-template <typename T>
+template <typename T, int MAXN>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, T* __restrict__ P,
                                                           T* __restrict__ Pkeep, const float* __restrict__ rmask,
                                                           const float* __restrict__ cmask, int mode, int64_t nrows,
@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
                                                           float scale, float drop_p, uint32_t seed0,
                                                           const uint32_t* __restrict__ step) {
   const uint32_t seed = vmr_seed(seed0, step);
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t thresh = vmr_drop_thresh(drop_p);
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < nrows; row += (int64_t)gridDim.x * 4) {
@@ -76,13 +77,14 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
 // dS = scale * Pk * (dPk - sum_c dPk*Pk), where Pk are the pre-dropout
 // probabilities and dPk = mask*dscale*dP (mask regenerated from the seed).  With
 // dropout active the forward writes both P (dropped, feeds P.V) and Pk.
-template <typename T>
+template <typename T, int MAXN>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dP, const T* __restrict__ Pk,
                                                           T* __restrict__ dS, int64_t nrows, int C, int ldS,
                                                           int ldP, float scale, float drop_p, uint32_t seed0,
                                                           const uint32_t* __restrict__ step) {
   const uint32_t seed = vmr_seed(seed0, step);
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t thresh = vmr_drop_thresh(drop_p);
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < nrows; row += (int64_t)gridDim.x * 4) {
@@ -111,6 +113,15 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   }
 }
 
+#define SM_DISPATCH(W, ...)                                   \
+  do {                                                        \
+    if ((W) <= 64) { constexpr int MN = 1; __VA_ARGS__; }     \
+    else if ((W) <= 128) { constexpr int MN = 2; __VA_ARGS__; } \
+    else if ((W) <= 256) { constexpr int MN = 4; __VA_ARGS__; } \
+    else if ((W) <= 512) { constexpr int MN = 8; __VA_ARGS__; } \
+    else { constexpr int MN = 16; __VA_ARGS__; }              \
+  } while (0)
+
 }  // namespace
 
 extern "C" int vmr_softmax_fwd(const float* S, void* P, void* Pkeep, const float* rmask, const float* cmask, int mode, int Z,
@@ -119,17 +130,19 @@ extern "C" int vmr_softmax_fwd(const float* S, void* P, void* Pkeep, const float
   VMR_CHECK(S && P && cmask, "vmr_softmax_fwd: null pointer");
   VMR_CHECK(mode == 0 || mode == 1, "vmr_softmax_fwd: bad mode %d", mode);
   VMR_CHECK(mode != 0 || rmask, "vmr_softmax_fwd: mode 0 needs rmask");
-  VMR_CHECK(C >= 1 && C <= 64 * MAXN && ldP <= 64 * MAXN && ldP >= C && ldS >= C && H >= 1,
+  VMR_CHECK(C >= 1 && C <= 64 * MAXN_MAX && ldP <= 64 * MAXN_MAX && ldP >= C && ldS >= C && H >= 1,
             "vmr_softmax_fwd: bad sizes C=%d ldS=%d ldP=%d", C, ldS, ldP);
   const int64_t nrows = (int64_t)Z * R;
   if (nrows == 0) return 0;
   const int grid = (int)min((int64_t)8192, (nrows + 3) / 4);
   if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, S, (bf16_t*)P, (bf16_t*)Pkeep, rmask,
-                       cmask, mode, nrows, H, R, C, ldS, ldP, cm_stride, scale, drop_p, drop_seed, drop_step);
+    SM_DISPATCH(ldP, hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t, MN>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                        S, (bf16_t*)P, (bf16_t*)Pkeep, rmask, cmask, mode, nrows, H, R, C, ldS, ldP,
+                                        cm_stride, scale, drop_p, drop_seed, drop_step));
   else
-    hipLaunchKernelGGL(softmax_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, S, (float*)P, (float*)Pkeep, rmask,
-                       cmask, mode, nrows, H, R, C, ldS, ldP, cm_stride, scale, drop_p, drop_seed, drop_step);
+    SM_DISPATCH(ldP, hipLaunchKernelGGL((softmax_fwd_kernel<float, MN>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                        S, (float*)P, (float*)Pkeep, rmask, cmask, mode, nrows, H, R, C, ldS, ldP,
+                                        cm_stride, scale, drop_p, drop_seed, drop_step));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -138,16 +151,18 @@ extern "C" int vmr_softmax_bwd(const float* dP, const void* P, void* dS, int Z, 
                                float scale, int dtype, float drop_p, uint32_t drop_seed, const uint32_t* drop_step,
                                void* stream) {
   VMR_CHECK(dP && P && dS, "vmr_softmax_bwd: null pointer");
-  VMR_CHECK(C >= 1 && C <= 64 * MAXN && ldP >= C && ldP <= 64 * MAXN && ldS >= C, "vmr_softmax_bwd: bad sizes");
+  VMR_CHECK(C >= 1 && C <= 64 * MAXN_MAX && ldP >= C && ldP <= 64 * MAXN_MAX && ldS >= C, "vmr_softmax_bwd: bad sizes");
   const int64_t nrows = (int64_t)Z * R;
   if (nrows == 0) return 0;
   const int grid = (int)min((int64_t)8192, (nrows + 3) / 4);
   if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dP,
-                       (const bf16_t*)P, (bf16_t*)dS, nrows, C, ldS, ldP, scale, drop_p, drop_seed, drop_step);
+    SM_DISPATCH(ldP, hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t, MN>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                        dP, (const bf16_t*)P, (bf16_t*)dS, nrows, C, ldS, ldP, scale, drop_p, drop_seed,
+                                        drop_step));
   else
-    hipLaunchKernelGGL(softmax_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dP, (const float*)P,
-                       (float*)dS, nrows, C, ldS, ldP, scale, drop_p, drop_seed, drop_step);
+    SM_DISPATCH(ldP, hipLaunchKernelGGL((softmax_bwd_kernel<float, MN>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                        dP, (const float*)P, (float*)dS, nrows, C, ldS, ldP, scale, drop_p, drop_seed,
+                                        drop_step));
   VMR_LAUNCH_CHECK();
   return 0;
 }
