@@ -83,7 +83,20 @@ __device__ __forceinline__ void epilogue_half(const vmr_gemm_t& g, const float* 
   const float dscale = (flags & VMR_EPI_DROPOUT) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
   const uint32_t seed = vmr_seed(g.drop_seed, g.drop_step);
   const bool out_f32 = (flags & VMR_EPI_OUT_F32) != 0;
-  for (int pass = 0; pass < ROWS / (NT / 16); ++pass) {
+  constexpr int PASSES = ROWS / (NT / 16);
+  // residual rows of ALL passes are requested up front: one exposed HBM latency per tile instead of
+  // one per pass (the epilogue is a dependent load -> math -> store chain otherwise)
+  float rres[PASSES][8];
+  const bool res_vec = ALIGNED && (flags & VMR_EPI_RESIDUAL) && (g.N - n0 - (tid & 15) * 8) >= 8;
+  if (res_vec) {
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+      const int gm = min(m0 + pass * (NT / 16) + (tid >> 4), g.M - 1);   // clamped: the load is unconditional
+      Vec8<T>::load(Rsd + (int64_t)gm * g.ldr + n0 + (tid & 15) * 8, rres[pass]);
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < PASSES; ++pass) {
     const int row = pass * (NT / 16) + (tid >> 4);
     const int col = (tid & 15) * 8;
     const int gm = m0 + row, gn = n0 + col;
@@ -120,13 +133,11 @@ __device__ __forceinline__ void epilogue_half(const vmr_gemm_t& g, const float* 
       else for (int e = 0; e < nvalid; ++e) ap[e] = from_f<T>(v[e]);
     }
     if (flags & VMR_EPI_RESIDUAL) {
-      const T* rp = Rsd + (int64_t)gm * g.ldr + gn;
-      if (vec) {
-        float rv[8];
-        Vec8<T>::load(rp, rv);
+      if (res_vec) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        for (int e = 0; e < 8; ++e) v[e] += rres[pass][e];
       } else {
+        const T* rp = Rsd + (int64_t)gm * g.ldr + gn;
         for (int e = 0; e < nvalid; ++e) v[e] += to_f<T>(rp[e]);
       }
     }
@@ -454,11 +465,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
       for (int i = 0; i < 4; ++i) fa[i] = read_frag<!TA, BK>(cur, wm * 4 + i, kk, lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[j] = read_frag<!TB, BK>(cur + OPB, wn * 4 + j, kk, lane);
+      __builtin_amdgcn_s_setprio(1);   // keep the MFMA cluster together (compiler + arbitration hint)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
   }
   __syncthreads();
