@@ -246,8 +246,9 @@ class SeqPAN(nn.Module):
         pw conv + bias -> ReLU -> dropout -> + residual}; LN+dw is one kernel, the rest is the
         GEMM epilogue."""
         for l in range(4):
-            u = ops.ln_dwconv(x, self.P(f"{prefix}.layer_norms.{l}.weight"), self.P(f"{prefix}.layer_norms.{l}.bias"),
-                              self.P(f"{prefix}.depthwise_separable_conv.{l}.0.weight"), 1e-6, segs)
+            u, x = ops.ln_dwconv(x, self.P(f"{prefix}.layer_norms.{l}.weight"),
+                                 self.P(f"{prefix}.layer_norms.{l}.bias"),
+                                 self.P(f"{prefix}.depthwise_separable_conv.{l}.0.weight"), 1e-6, segs, tee=True)
             x = ops.linear(u, self.P(f"{prefix}.depthwise_separable_conv.{l}.1.weight"),
                            self.P(f"{prefix}.depthwise_separable_conv.{l}.1.bias"), self._cache,
                            relu=True, drop=dc.next(f"{prefix}.{l}"), residual=x)
@@ -284,7 +285,7 @@ class SeqPAN(nn.Module):
         m = prefix + ".dual_multihead_attention"
         W = lambda n: self.P(f"{m}.{n}.conv1d.weight")
         Bv = lambda n: self.P(f"{m}.{n}.conv1d.bias")
-        n1 = self._ln(X, prefix + ".layer_norm_1", 1e-6, drop=dc.next(prefix + ".ln1"))
+        n1, Xr = self._ln(X, prefix + ".layer_norm_1", 1e-6, drop=dc.next(prefix + ".ln1"), tee=True)
         nt = self._ln(X, prefix + ".layer_norm_t", 1e-6)
         qkv = ops.linear(n1, [W("query"), W("f_key"), W("f_value")],
                          torch.cat([Bv("query"), Bv("f_key"), Bv("f_value")]), c)
@@ -305,9 +306,9 @@ class SeqPAN(nn.Module):
         sv = ops.linear(bl_in, [self.P(b1 + ".dense_1.conv1d.weight"), self.P(b2 + ".dense_1.conv1d.weight")],
                         bias, c)
         out = ops.sigmoid_gate(sv, rowmask)                                     # (:380)
-        o1 = self._lin(out, prefix + ".dense_1", drop=dc.next(prefix + ".d1"), residual=X)
-        o2 = self._ln(o1, prefix + ".layer_norm_2", 1e-6, drop=dc.next(prefix + ".ln2"))
-        return self._lin(o2, prefix + ".dense_2", drop=dc.next(prefix + ".d2"), residual=o1)
+        o1 = self._lin(out, prefix + ".dense_1", drop=dc.next(prefix + ".d1"), residual=Xr)
+        o2, o1r = self._ln(o1, prefix + ".layer_norm_2", 1e-6, drop=dc.next(prefix + ".ln2"), tee=True)
+        return self._lin(o2, prefix + ".dense_2", drop=dc.next(prefix + ".d2"), residual=o1r)
 
     def _cq_attention(self, prefix, ctx, qry, cmask, qmask, dc):
         """CQAttention.forward (reference layers.py:417-437).  The rank-1 terms of the
@@ -348,13 +349,13 @@ class SeqPAN(nn.Module):
         pos = ops.to_dtype(self.P(fe + ".pos_embedding.position_embeddings.weight")[:T], x.dtype)
         feat = (x.view(B, T, D) + pos[:T].view(1, T, D)).reshape(B * T, D)
         feat = self._conv_block(feat, fe + ".conv_block", [(B, T)], dc)
-        o = self._ln(feat, fe + ".layer_norm_1", 1e-5, drop=dc.next(tag + ".ln1"))
+        o, feat = self._ln(feat, fe + ".layer_norm_1", 1e-5, drop=dc.next(tag + ".ln1"), tee=True)
         att = fe + ".top_self_attention.selfattn"
         qkv = ops.linear(o, self.P(att + ".in_proj_weight"), self.P(att + ".in_proj_bias"), c)
         ctxv = ops.batch_axis_attention(qkv, vmask, B, T, 4, dc.next(tag + ".attn"))
         res = ops.linear(ctxv, self.P(att + ".out_proj.weight"), self.P(att + ".out_proj.bias"), c,
                          drop=dc.next(tag + ".att"), residual=feat)
-        o = self._ln(res, fe + ".layer_norm_2", 1e-5, drop=dc.next(tag + ".ln2"))
+        o, res = self._ln(res, fe + ".layer_norm_2", 1e-5, drop=dc.next(tag + ".ln2"), tee=True)
         return self._lin(o, fe + ".dense", drop=dc.next(tag + ".dense"), residual=res)
 
     # -- forward --------------------------------------------------------------

@@ -388,8 +388,12 @@ def linear(x, weights, bias, cache, *, relu=False, drop=NO_DROP, residual=None, 
 # LayerNorm (+pos, +dropout)
 # ---------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):
+    """tee=True also returns an alias of x: use it for the residual branch, so the gradient of
+    that branch arrives here and is added inside the LN-backward kernel (dres) instead of by a
+    separate elementwise pass."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, pos, S, drop, cache):
+    def forward(ctx, x, gamma, beta, eps, pos, S, drop, cache, tee=False):
         L.require_gpu(x)
         x = x.contiguous()
         rows, D = x.shape
@@ -406,13 +410,16 @@ class _LayerNorm(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.meta = (drop, S, None if pos is None else tuple(pos.shape))
         ctx.params = (gamma, beta)
+        if tee:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma, mean, rstd = ctx.saved_tensors
         drop, S, pshape = ctx.meta
         dy = dy.contiguous()
+        dres = None if dres is None else dres.contiguous()
         rows, D = x.shape
         dx = torch.empty_like(x)
         mg, mb = main_grad(ctx.params[0]), main_grad(ctx.params[1])
@@ -422,15 +429,15 @@ class _LayerNorm(torch.autograd.Function):
         dpos = torch.zeros(pshape, device=x.device, dtype=torch.float32) if pshape else None
         ws = torch.empty(L.ln_bwd_ws_floats(rows, D), device=x.device, dtype=torch.float32)
         L.check(L.lib().vmr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                          rstd.data_ptr(), None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                          rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                           _ptr(dpos), ws.data_ptr(), S, rows, D, L.dtype_code(x), drop[0], drop[1],
                                           _ptr(drop[2]),
                                           L.stream_ptr()), "vmr_layernorm_bwd")
-        return dx, (None if direct else dg), (None if direct else db), None, dpos, None, None, None
+        return dx, (None if direct else dg), (None if direct else db), None, dpos, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps, cache, *, pos=None, S=0, drop=NO_DROP):
-    return _LayerNorm.apply(x, gamma, beta, eps, pos, S, drop, cache)
+def layer_norm(x, gamma, beta, eps, cache, *, pos=None, S=0, drop=NO_DROP, tee=False):
+    return _LayerNorm.apply(x, gamma, beta, eps, pos, S, drop, cache, tee)
 
 
 # ---------------------------------------------------------------------------
@@ -442,7 +449,7 @@ class _LnDwConv(torch.autograd.Function):
     sequence groups stored back to back (video clips, then query sentences)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, w, eps, segs):
+    def forward(ctx, x, gamma, beta, w, eps, segs, tee=False):
         L.require_gpu(x)
         x = x.contiguous()
         rows, D = x.shape
@@ -460,14 +467,17 @@ class _LnDwConv(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, beta, w2, mean, rstd)
         ctx.meta = (segs, tuple(w.shape))
         ctx.params = (gamma, beta, w)
+        if tee:
+            return u, x.view_as(x)
         return u
 
     @staticmethod
-    def backward(ctx, du):
+    def backward(ctx, du, dres=None):
         x, gamma, beta, w2, mean, rstd = ctx.saved_tensors
         segs, wshape = ctx.meta
         rows, D = x.shape
         du = du.contiguous()
+        dres = None if dres is None else dres.contiguous()
         lib, st, dt = L.lib(), L.stream_ptr(), L.dtype_code(x)
         dn = torch.empty_like(x)
         mg, mb, mw = (main_grad(p_) for p_ in ctx.params)
@@ -486,15 +496,15 @@ class _LnDwConv(torch.autograd.Function):
         dg = mg if direct else torch.zeros(D, device=x.device, dtype=torch.float32)
         db = mb if direct else torch.zeros_like(dg)
         L.check(lib.vmr_layernorm_bwd(dn.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                      None, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, ws.data_ptr(), 0, rows, D,
-                                      dt, 0.0, 0, None, st), "vmr_layernorm_bwd")
+                                      _ptr(dres), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, ws.data_ptr(), 0,
+                                      rows, D, dt, 0.0, 0, None, st), "vmr_layernorm_bwd")
         if direct:
-            return dx, None, None, None, None, None
-        return dx, dg, db, dw.reshape(wshape), None, None
+            return dx, None, None, None, None, None, None
+        return dx, dg, db, dw.reshape(wshape), None, None, None
 
 
-def ln_dwconv(x, gamma, beta, w, eps, segs):
-    return _LnDwConv.apply(x, gamma, beta, w, eps, tuple(segs))
+def ln_dwconv(x, gamma, beta, w, eps, segs, tee=False):
+    return _LnDwConv.apply(x, gamma, beta, w, eps, tuple(segs), tee)
 
 
 # ---------------------------------------------------------------------------
