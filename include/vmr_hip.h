@@ -140,6 +140,19 @@ int vmr_softmax_bwd(const float* dP, const void* P, void* dS /*dtype, ld = ldP*/
                     int ldP, float scale, int dtype, float drop_p, uint32_t drop_seed,
                     const uint32_t* drop_step, void* stream);
 
+/* ------------------------------------------------- CQAttention softmaxes
+ * The two masked softmaxes of CQAttention (layers.py:419-421) over the trilinear
+ * score S = S2 + rowterm[b,c] + colterm[b,q] (S2 from the batched MFMA GEMM, the
+ * rank-1 terms optional): Srow = softmax_q(S + qmask term), Scol = softmax_c(S +
+ * cmask term), both [B,Lc,ldP] in the activation dtype (pad columns zeroed).
+ * bwd: dS2 [B,Lc,ldS] fp32, drow[b,c] = sum_q dS, dcol[b,q] = sum_c dS (nullable). */
+int vmr_cq_softmax_fwd(const float* S2, const float* rowterm, const float* colterm,
+                       const float* cmask, const float* qmask, void* Srow, void* Scol,
+                       int B, int Lc, int Lq, int ldS, int ldP, int dtype, void* stream);
+int vmr_cq_softmax_bwd(const void* dSrow, const void* dScol, const void* Srow, const void* Scol,
+                       float* dS2, float* drow, float* dcol, int B, int Lc, int Lq, int ldS,
+                       int ldP, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ losses
  * lossfun_loc (models/loss.py:43-54): mean_b( -sum_t y[b,t]*log_softmax(z[b,:])[t] ),
  * start + end in one launch. loss: fp32[1] (accumulated, caller zeroes). */

@@ -300,3 +300,81 @@ def test_product_path_rejects_cpu_tensors(dev):
     ops = _ops()
     with pytest.raises(RuntimeError):
         ops.soft_ce(torch.zeros(2, 4), torch.zeros(2, 4), torch.zeros(2, 4), torch.zeros(2, 4))
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dims", [(3, 16, 6), (2, 128, 20), (2, 20, 128), (1, 1, 1)])
+def test_cq_softmax_fwd_bwd(dev, dt, tol, dims):
+    """The two masked softmaxes of CQAttention (models/layers.py:419-421) incl. fully masked rows/columns."""
+    ops = _ops()
+    B, Lc, Lq = dims
+    torch.manual_seed(7)
+    ld = (Lq + 7) // 8 * 8
+    S2buf = torch.randn(B, Lc, ld, device=dev)
+    S2 = S2buf[..., :Lq].requires_grad_(True)
+    rowt = torch.randn(B, Lc, device=dev, requires_grad=True)
+    colt = torch.randn(B, Lq, device=dev, requires_grad=True)
+    cmask = (torch.rand(B, Lc, device=dev) > 0.3).float(); cmask[:, 0] = 1
+    qmask = (torch.rand(B, Lq, device=dev) > 0.3).float(); qmask[:, 0] = 1
+    if B > 1:
+        qmask[1] = 0          # a sample whose queries are all padding: uniform softmax, not NaN
+    Sr, Sc = ops.cq_softmax(S2, rowt, colt, cmask, qmask, dt)
+    S = S2 + rowt[:, :, None] + colt[:, None, :]
+    Rr = torch.softmax(S + (1 - qmask[:, None, :]) * -1e30, dim=2)
+    Rc = torch.softmax(S + (1 - cmask[:, :, None]) * -1e30, dim=1)
+    _close(Sr, Rr, tol, "S_row"); _close(Sc, Rc, tol, "S_col")
+    assert torch.isfinite(Sr.float()).all() and torch.isfinite(Sc.float()).all()
+    g1, g2 = torch.randn_like(Rr), torch.randn_like(Rc)
+    mine = torch.autograd.grad([Sr, Sc], [S2, rowt, colt], [g1.to(dt), g2.to(dt)])
+    ref = torch.autograd.grad([Rr, Rc], [S2, rowt, colt], [g1.to(dt).float(), g2.to(dt).float()])
+    for a, b, n in zip(mine, ref, ("dS2", "drow", "dcol")):
+        _close(a, b, 5 * tol, n)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_fused_elementwise_programs(dev, dt, tol):
+    """cross gate, sigmoid gate, 4-way CQ concat (models/layers.py:374,380,424) vs torch, fwd + bwd."""
+    ops = _ops()
+    torch.manual_seed(8)
+    N, D = 70, 64
+    t = lambda *s: torch.randn(*s, device=dev).to(dt).requires_grad_(True)
+    ss, sv, xs, xv = t(N, D), t(N, D), t(N, D), t(N, D)
+    out = ops.cross_gate(ss, sv, xs, xv)
+    refs = [x.detach().float().requires_grad_(True) for x in (ss, sv, xs, xv)]
+    ref = refs[0] * refs[3] + refs[2] * refs[1]
+    _close(out, ref, tol, "gate")
+    g = torch.randn(N, D, device=dev).to(dt)
+    for a, b in zip(torch.autograd.grad(out, [ss, sv, xs, xv], g), torch.autograd.grad(ref, refs, g.float())):
+        _close(a, b, tol, "gate grad")
+    sv2 = t(N, 2 * D)
+    rm = (torch.rand(N, device=dev) > 0.3).float()
+    out = ops.sigmoid_gate(sv2, rm)
+    r2 = sv2.detach().float().requires_grad_(True)
+    ref = torch.sigmoid(r2[:, :D] + -1e30 * (1 - rm[:, None])) * r2[:, D:]
+    _close(out, ref, tol, "siggate")
+    (a,) = torch.autograd.grad(out, sv2, g)
+    (b,) = torch.autograd.grad(ref, r2, g.float())
+    _close(a, b, tol, "siggate grad")
+    C_, c2q, q2c = t(N, D), t(N, D), t(N, D)
+    out = ops.cat4(C_, c2q, q2c)
+    rs = [x.detach().float().requires_grad_(True) for x in (C_, c2q, q2c)]
+    ref = torch.cat([rs[0], rs[1], rs[0] * rs[1], rs[0] * rs[2]], 1)
+    _close(out, ref, tol, "cat4")
+    g4 = torch.randn(N, 4 * D, device=dev).to(dt)
+    for a, b in zip(torch.autograd.grad(out, [C_, c2q, q2c], g4), torch.autograd.grad(ref, rs, g4.float())):
+        _close(a, b, 2 * tol, "cat4 grad")
+
+
+def test_embedding_gather_scatter(dev):
+    ops = _ops()
+    torch.manual_seed(9)
+    table = torch.randn(30, 100, device=dev, requires_grad=True)
+    idx = torch.randint(0, 30, (4, 6, 5), device=dev)
+    out = ops.embedding(idx, table, 0)
+    ref = torch.nn.functional.embedding(idx, table, padding_idx=0)
+    assert torch.equal(out, ref)
+    g = torch.randn_like(ref)
+    (a,) = torch.autograd.grad(out, table, g)
+    (b,) = torch.autograd.grad(ref, table, g)
+    _close(a, b, 1e-5, "embedding grad")
+    assert float(a[0].abs().max()) == 0.0       # padding_idx row gets no gradient

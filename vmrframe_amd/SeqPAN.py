@@ -326,16 +326,13 @@ class SeqPAN(nn.Module):
         if Lq <= Lc:
             qf = qd.float()
             bop = (qf * w4mlu + w4C.view(1, 1, D)).to(cdt)
-            S = ops.bmm(cd, bop, 0, 0, out_f32=True) + (qf @ w4Q).transpose(1, 2)
+            S2, rowterm, colterm = ops.bmm(cd, bop, 0, 0, out_f32=True), None, (qf @ w4Q).squeeze(2)
         else:
             cf = cd.float()
             aop = (cf * w4mlu + w4Q.view(1, 1, D)).to(cdt)
-            S = ops.bmm(aop, qd, 0, 0, out_f32=True) + (cf @ w4C)
-        S_ = torch.softmax(S + NEG * (1.0 - qmask[:, None, :]), dim=2)
-        S_t = torch.softmax(S + NEG * (1.0 - cmask[:, :, None]), dim=1)
-        pad = (-Lq) % 8
-        S_p = F.pad(S_.to(cdt), (0, pad))[..., :Lq]        # 16-byte aligned rows for the GEMM loads
-        S_tp = F.pad(S_t.to(cdt), (0, pad))[..., :Lq]
+            S2, rowterm, colterm = ops.bmm(aop, qd, 0, 0, out_f32=True), (cf @ w4C).squeeze(2), None
+        # both masked softmaxes in one HIP kernel; outputs are 8-padded so the GEMMs below use 16-byte loads
+        S_p, S_tp = ops.cq_softmax(S2, rowterm, colterm, cmask, qmask, cdt)
         c2q = ops.bmm(S_p, qry, 0, 1)                      # [B,Lc,D]
         mid = ops.bmm(S_tp, ctx, 1, 1)                     # S_t^T . C   [B,Lq,D]
         q2c = ops.bmm(S_p, mid, 0, 1)                      # [B,Lc,D]

@@ -166,3 +166,159 @@ extern "C" int vmr_softmax_bwd(const float* dP, const void* P, void* dS, int Z, 
   VMR_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------ CQ attention softmaxes
+// The two masked softmaxes of CQAttention (reference models/layers.py:419-421) over the
+// trilinear score S[b,c,q] = S2[b,c,q] + rowterm[b,c] + colterm[b,q]:
+//   S_row = softmax_q(S + (1-qmask[b,q]) * -1e30)      (context -> query weights)
+//   S_col = softmax_c(S + (1-cmask[b,c]) * -1e30)      (stored [b,c,q]; the reference transposes it)
+// One workgroup per sample: the [Lc, Lq] score tile lives in LDS (<= 64 KiB fp32), rows are
+// reduced by waves, columns by threads.  Outputs in the activation dtype with a padded leading
+// dimension ldP (zero filled) so the following batched GEMMs use 16-byte loads.
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void cq_softmax_fwd_kernel(const float* __restrict__ S2, const float* __restrict__ rowterm,
+                                                             const float* __restrict__ colterm,
+                                                             const float* __restrict__ cmask, const float* __restrict__ qmask,
+                                                             T* __restrict__ Srow, T* __restrict__ Scol, int Lc, int Lq,
+                                                             int ldS, int ldP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);   // [Lc][Lq]
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float* s2 = S2 + (int64_t)b * Lc * ldS;
+  for (int i = threadIdx.x; i < Lc * Lq; i += 256) {
+    const int c = i / Lq, q = i - c * Lq;
+    float v = s2[(int64_t)c * ldS + q];
+    if (rowterm) v += rowterm[(int64_t)b * Lc + c];
+    if (colterm) v += colterm[(int64_t)b * Lq + q];
+    tile[i] = v;
+  }
+  __syncthreads();
+  // rows: softmax over q with the query mask
+  for (int c = wid; c < Lc; c += 4) {
+    float mx = -INFINITY;
+    for (int q = lane; q < Lq; q += 64)
+      mx = fmaxf(mx, tile[c * Lq + q] + (1.0f - qmask[(int64_t)b * Lq + q]) * VMR_NEG_INF_MASK);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int q = lane; q < Lq; q += 64)
+      sum += __expf(tile[c * Lq + q] + (1.0f - qmask[(int64_t)b * Lq + q]) * VMR_NEG_INF_MASK - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    T* o = Srow + ((int64_t)b * Lc + c) * ldP;
+    for (int q = lane; q < ldP; q += 64)
+      o[q] = from_f<T>(q < Lq ? __expf(tile[c * Lq + q] + (1.0f - qmask[(int64_t)b * Lq + q]) * VMR_NEG_INF_MASK - mx) * inv
+                              : 0.f);
+  }
+  // columns: softmax over c with the context mask (one thread per column)
+  for (int q = threadIdx.x; q < ldP; q += 256) {
+    if (q >= Lq) {
+      for (int c = 0; c < Lc; ++c) Scol[((int64_t)b * Lc + c) * ldP + q] = from_f<T>(0.f);
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int c = 0; c < Lc; ++c)
+      mx = fmaxf(mx, tile[c * Lq + q] + (1.0f - cmask[(int64_t)b * Lc + c]) * VMR_NEG_INF_MASK);
+    float sum = 0.f;
+    for (int c = 0; c < Lc; ++c)
+      sum += __expf(tile[c * Lq + q] + (1.0f - cmask[(int64_t)b * Lc + c]) * VMR_NEG_INF_MASK - mx);
+    const float inv = 1.f / sum;
+    for (int c = 0; c < Lc; ++c)
+      Scol[((int64_t)b * Lc + c) * ldP + q] =
+          from_f<T>(__expf(tile[c * Lq + q] + (1.0f - cmask[(int64_t)b * Lc + c]) * VMR_NEG_INF_MASK - mx) * inv);
+  }
+}
+
+// dS = Srow*(dSrow - sum_q dSrow*Srow) + Scol*(dScol - sum_c dScol*Scol); drow[c] = sum_q dS, dcol[q] = sum_c dS
+template <typename T>
+__global__ __launch_bounds__(256) void cq_softmax_bwd_kernel(const T* __restrict__ dSrow, const T* __restrict__ dScol,
+                                                             const T* __restrict__ Srow, const T* __restrict__ Scol,
+                                                             float* __restrict__ dS2, float* __restrict__ drow,
+                                                             float* __restrict__ dcol, int Lc, int Lq, int ldS, int ldP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem);   // [Lc][Lq] accumulates dS
+  float* cdot = tile + Lc * Lq;                   // [Lq] column dots
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t base = (int64_t)b * Lc * ldP;
+  for (int q = threadIdx.x; q < Lq; q += 256) {
+    float d = 0.f;
+    for (int c = 0; c < Lc; ++c) d += to_f<T>(dScol[base + (int64_t)c * ldP + q]) * to_f<T>(Scol[base + (int64_t)c * ldP + q]);
+    cdot[q] = d;
+  }
+  __syncthreads();
+  for (int c = wid; c < Lc; c += 4) {
+    float d = 0.f;
+    for (int q = lane; q < Lq; q += 64) d += to_f<T>(dSrow[base + (int64_t)c * ldP + q]) * to_f<T>(Srow[base + (int64_t)c * ldP + q]);
+    d = wave_sum(d);
+    float rs = 0.f;
+    for (int q = lane; q < Lq; q += 64) {
+      const int64_t i = base + (int64_t)c * ldP + q;
+      const float g = to_f<T>(Srow[i]) * (to_f<T>(dSrow[i]) - d) + to_f<T>(Scol[i]) * (to_f<T>(dScol[i]) - cdot[q]);
+      tile[c * Lq + q] = g;
+      dS2[((int64_t)b * Lc + c) * ldS + q] = g;
+      rs += g;
+    }
+    rs = wave_sum(rs);
+    if (lane == 0 && drow) drow[(int64_t)b * Lc + c] = rs;
+  }
+  __syncthreads();
+  if (dcol)
+    for (int q = threadIdx.x; q < Lq; q += 256) {
+      float cs = 0.f;
+      for (int c = 0; c < Lc; ++c) cs += tile[c * Lq + q];
+      dcol[(int64_t)b * Lq + q] = cs;
+    }
+}
+
+}  // namespace
+
+extern "C" int vmr_cq_softmax_fwd(const float* S2, const float* rowterm, const float* colterm, const float* cmask,
+                                  const float* qmask, void* Srow, void* Scol, int B, int Lc, int Lq, int ldS, int ldP,
+                                  int dtype, void* stream) {
+  VMR_CHECK(S2 && cmask && qmask && Srow && Scol, "vmr_cq_softmax_fwd: null pointer");
+  VMR_CHECK(Lc >= 1 && Lq >= 1 && ldS >= Lq && ldP >= Lq && (size_t)Lc * Lq * 4 <= 96 * 1024,
+            "vmr_cq_softmax_fwd: score tile %dx%d does not fit LDS", Lc, Lq);
+  if (B == 0) return 0;
+  const size_t lds = (size_t)Lc * Lq * 4;
+  const void* fn = dtype == VMR_BF16 ? (const void*)cq_softmax_fwd_kernel<bf16_t> : (const void*)cq_softmax_fwd_kernel<float>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return vmr_fail(-5, "vmr_cq_softmax_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(cq_softmax_fwd_kernel<bf16_t>, dim3(B), dim3(256), lds, (hipStream_t)stream, S2, rowterm, colterm,
+                       cmask, qmask, (bf16_t*)Srow, (bf16_t*)Scol, Lc, Lq, ldS, ldP);
+  else
+    hipLaunchKernelGGL(cq_softmax_fwd_kernel<float>, dim3(B), dim3(256), lds, (hipStream_t)stream, S2, rowterm, colterm,
+                       cmask, qmask, (float*)Srow, (float*)Scol, Lc, Lq, ldS, ldP);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_cq_softmax_bwd(const void* dSrow, const void* dScol, const void* Srow, const void* Scol, float* dS2,
+                                  float* drow, float* dcol, int B, int Lc, int Lq, int ldS, int ldP, int dtype,
+                                  void* stream) {
+  VMR_CHECK(dSrow && dScol && Srow && Scol && dS2, "vmr_cq_softmax_bwd: null pointer");
+  VMR_CHECK(Lc >= 1 && Lq >= 1 && ldS >= Lq && ldP >= Lq && ((size_t)Lc * Lq + Lq) * 4 <= 96 * 1024,
+            "vmr_cq_softmax_bwd: score tile %dx%d does not fit LDS", Lc, Lq);
+  if (B == 0) return 0;
+  const size_t lds = ((size_t)Lc * Lq + Lq) * 4;
+  const void* fn = dtype == VMR_BF16 ? (const void*)cq_softmax_bwd_kernel<bf16_t> : (const void*)cq_softmax_bwd_kernel<float>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return vmr_fail(-5, "vmr_cq_softmax_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(cq_softmax_bwd_kernel<bf16_t>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dSrow,
+                       (const bf16_t*)dScol, (const bf16_t*)Srow, (const bf16_t*)Scol, dS2, drow, dcol, Lc, Lq, ldS, ldP);
+  else
+    hipLaunchKernelGGL(cq_softmax_bwd_kernel<float>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)dSrow,
+                       (const float*)dScol, (const float*)Srow, (const float*)Scol, dS2, drow, dcol, Lc, Lq, ldS, ldP);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}

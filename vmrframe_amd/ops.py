@@ -750,6 +750,57 @@ def dropout(x, drop):
 
 
 # ---------------------------------------------------------------------------
+# CQAttention: the two masked softmaxes of the trilinear score
+# ---------------------------------------------------------------------------
+class _CQSoftmax(torch.autograd.Function):
+    """(S_row, S_col) = softmaxes over q / over c of S2 + rowterm + colterm with the -1e30 masks
+    (reference models/layers.py:419-421).  S2: fp32 [B,Lc,>=Lq] view (last stride 1) from the
+    batched GEMM; outputs [B,Lc,Lq] views of 8-padded buffers in `dtype`."""
+
+    @staticmethod
+    def forward(ctx, S2, rowterm, colterm, cmask, qmask, dtype):
+        L.require_gpu(S2)
+        B, Lc, Lq = S2.shape
+        assert S2.stride(2) == 1 and S2.stride(0) == Lc * S2.stride(1)
+        ldS, ldP = S2.stride(1), _rup(Lq, 8)
+        Srow = torch.empty(B, Lc, ldP, device=S2.device, dtype=dtype)
+        Scol = torch.empty_like(Srow)
+        rt = None if rowterm is None else rowterm.contiguous().float()
+        ct = None if colterm is None else colterm.contiguous().float()
+        L.check(L.lib().vmr_cq_softmax_fwd(S2.data_ptr(), _ptr(rt), _ptr(ct), cmask.data_ptr(), qmask.data_ptr(),
+                                           Srow.data_ptr(), Scol.data_ptr(), B, Lc, Lq, ldS, ldP, L.dtype_code(Srow),
+                                           L.stream_ptr()), "vmr_cq_softmax_fwd")
+        ctx.save_for_backward(Srow, Scol)
+        ctx.meta = (B, Lc, Lq, ldP, rowterm is not None, colterm is not None,
+                    None if rowterm is None else tuple(rowterm.shape), None if colterm is None else tuple(colterm.shape))
+        return Srow[..., :Lq], Scol[..., :Lq]
+
+    @staticmethod
+    def backward(ctx, dSrow, dScol):
+        Srow, Scol = ctx.saved_tensors
+        B, Lc, Lq, ldP, has_r, has_c, rshape, cshape = ctx.meta
+        dev = Srow.device
+
+        def pad(g):   # gradients arrive as [B,Lc,Lq] (any strides): bring them to the padded layout
+            buf = torch.zeros(B, Lc, ldP, device=dev, dtype=Srow.dtype)
+            buf[..., :Lq] = g
+            return buf
+        dSr, dSc = pad(dSrow), pad(dScol)
+        dS2 = torch.zeros(B, Lc, ldP, device=dev, dtype=torch.float32)
+        drow = torch.empty(B, Lc, device=dev, dtype=torch.float32) if has_r else None
+        dcol = torch.empty(B, Lq, device=dev, dtype=torch.float32) if has_c else None
+        L.check(L.lib().vmr_cq_softmax_bwd(dSr.data_ptr(), dSc.data_ptr(), Srow.data_ptr(), Scol.data_ptr(),
+                                           dS2.data_ptr(), _ptr(drow), _ptr(dcol), B, Lc, Lq, ldP, ldP,
+                                           L.dtype_code(Srow), L.stream_ptr()), "vmr_cq_softmax_bwd")
+        return (dS2[..., :Lq], None if drow is None else drow.reshape(rshape),
+                None if dcol is None else dcol.reshape(cshape), None, None, None)
+
+
+def cq_softmax(S2, rowterm, colterm, cmask, qmask, dtype):
+    return _CQSoftmax.apply(S2, rowterm, colterm, cmask.contiguous(), qmask.contiguous(), dtype)
+
+
+# ---------------------------------------------------------------------------
 # fused elementwise programs (dual-attention gating, CQ concat)
 # ---------------------------------------------------------------------------
 def _elt(op, a, b, c, d, e, rowmask, outs, rows, D):
