@@ -24,6 +24,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 CFG2 = dict(B=64, T=128, L=20, D=1024, V=500, num_words=4002, num_chars=60, C=8, droprate=0.2)
+# BASELINE configs[3] ("next" row N1): BaseFast path, T=256, D=1024, V=1024 -- NOT the headline metric
+CFG4 = dict(B=64, T=256, L=20, D=1024, V=1024, num_words=4002, num_chars=60, C=8, droprate=0.2)
 TRAIN_GFLOP_PER_CLIP = 58.0      # 19.34 GFLOP fwd (FlopCounter on the reference) x 3
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
@@ -115,6 +117,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of whole-step hipGraph replay")
+    ap.add_argument("--workload", default="seqpan", choices=["seqpan", "basefast"],
+                    help="seqpan = BASELINE configs[1] (headline); basefast = configs[3] (T=256)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,13 +136,15 @@ def main():
         dp.init_process_group_from_env("nccl")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
-    a = CFG2
+    a = CFG2 if args.workload == "seqpan" else CFG4
+    Model, engine = (V.SeqPAN, V.train_engine_SeqPAN) if args.workload == "seqpan" else \
+        (V.BaseFast, V.train_engine_BaseFast)
     torch.manual_seed(1234)                      # reference main.py:41
     cfg = make_cfg(a, args.dtype)
     cfg.device = dev
     rng = np.random.default_rng(1234)
     glove = rng.standard_normal((a["num_words"] - 2, 300)).astype(np.float32)
-    model = V.SeqPAN(cfg, glove).to(dev)
+    model = Model(cfg, glove).to(dev)
     model.sync_timing = False                    # the reference's in-forward wall-clock syncs are instrumentation
     model.base_seed = 1234 + rank                # per-rank dropout / Gumbel streams
     torch.manual_seed(1234 + rank)
@@ -151,7 +157,7 @@ def main():
     model.train()
 
     def eager_step():
-        loss, out = V.train_engine_SeqPAN(model, batch, cfg, "train")
+        loss, out = engine(model, batch, cfg, "train")
         opt.zero_grad()
         loss.backward()
         reducer.finish()
@@ -165,7 +171,7 @@ def main():
     else:
         # one captured HIP graph per step (vmrframe_amd/trainer.py): the eager loop is launch-bound
         from vmrframe_amd.trainer import GraphedTrainStep
-        gstep = GraphedTrainStep(model, opt, V.train_engine_SeqPAN, cfg, reducer if world > 1 else None,
+        gstep = GraphedTrainStep(model, opt, engine, cfg, reducer if world > 1 else None,
                                  warmup=3, overlap_dw=os.environ.get("VMR_OVERLAP_DW", "0") != "0").capture(batch)
         step = gstep
         for _ in range(args.warmup):
@@ -219,18 +225,23 @@ def main():
                         "frac": round(gs["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                         "launches_per_step": gs["launches"] / timed_steps_for_hook, "avg_launch_us": round(gs["avg_us"], 2),
                         "flops_per_launch": gs["flops_per_launch"]}
-        out = {"metric": "clips/sec (train step) at BxT=64x128, D=1024", "value": round(value, 2),
+        out = {"metric": "clips/sec (train step) at BxT=64x128, D=1024" if args.workload == "seqpan"
+               else "clips/sec (train step), BaseFast at BxT=64x256, D=1024", "value": round(value, 2),
                "unit": "clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": "SeqPAN anet/C3D synthetic features (configs[1]): B=64 clips/GPU, T=128, "
-                                      "L=20, D=1024, V=500, droprate 0.2; full train step "
-                                      "(fwd+losses+bwd+allreduce+clip+AdamW+schedule)",
+               "config": {"workload": ("SeqPAN anet/C3D synthetic features (configs[1]): B=64 clips/GPU, T=128, "
+                                       "L=20, D=1024, V=500, droprate 0.2; full train step "
+                                       "(fwd+losses+bwd+allreduce+clip+AdamW+schedule)") if args.workload == "seqpan"
+                          else ("BaseFast path (configs[3], next-row N1): B=64 clips/GPU, T=256, L=20, D=1024, "
+                                "V=1024, droprate 0.2; full train step"),
                           "global_batch": a["B"] * world, "parallelism": f"dp{world}"},
                "step_mfma_frac": round(value * TRAIN_GFLOP_PER_CLIP * 1e9 / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
                "final_loss": round(final_loss, 4), "hipgraph": not args.no_graph,
                "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline:
+        if args.workload != "seqpan":
+            out["step_mfma_frac"] = None     # the 58 GFLOP/clip figure is SeqPAN's
+        if world == 1 and not args.no_cpu_baseline and args.workload == "seqpan":
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out), flush=True)
     if world > 1:

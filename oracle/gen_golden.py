@@ -35,12 +35,13 @@ def import_reference():
     seqpan = importlib.import_module("models.SeqPAN")
     loss = importlib.import_module("models.loss")
     engine = importlib.import_module("utils.engine")
+    import_reference.basefast = importlib.import_module("models.BaseFast")
     return seqpan, loss, engine
 
 
-def build_reference(seqpan_mod, cfg, weights):
+def build_reference(seqpan_mod, cfg, weights, variant="SeqPAN"):
     glove = weights["text_encoder.word_emb.glove_vec"]
-    model = seqpan_mod.SeqPAN(cfg, glove)
+    model = seqpan_mod.SeqPAN(cfg, glove) if variant == "SeqPAN" else import_reference.basefast.BaseFast(cfg, glove)
     sd = model.state_dict()
     assert list(sd.keys()) == list(weights.keys()), "state_dict key order differs from oracle.param_shapes"
     for k, v in sd.items():
@@ -66,9 +67,9 @@ class GumbelPatch:
         torch.nn.functional.gumbel_softmax = self.orig
 
 
-def run_reference(mods, cfg, weights, batch, g, train_mode_grads=True, hooks=False):
+def run_reference(mods, cfg, weights, batch, g, train_mode_grads=True, hooks=False, variant="SeqPAN"):
     seqpan_mod, loss_mod, engine_mod = mods
-    model = build_reference(seqpan_mod, cfg, weights)
+    model = build_reference(seqpan_mod, cfg, weights, variant)
     model.eval()  # dropout off; grads still flow (SURVEY.md 7 "Randomness")
     inter = {}
     handles = []
@@ -89,14 +90,19 @@ def run_reference(mods, cfg, weights, batch, g, train_mode_grads=True, hooks=Fal
             handles.append(mod.register_forward_hook(mk(name)))
     with GumbelPatch(g):
         cfg.device = "cpu"
-        loss, out = seqpan_mod.train_engine_SeqPAN(model, batch, cfg, "train")
+        if variant == "SeqPAN":
+            loss, out = seqpan_mod.train_engine_SeqPAN(model, batch, cfg, "train")
+        else:
+            loss, out = import_reference.basefast.train_engine_BaseFast(model, batch, cfg, "train")
     for h in handles:
         h.remove()
     res = {"slogits": out["slogits"].detach().numpy(), "elogits": out["elogits"].detach().numpy(),
            "match_score": out["match_score"].detach().numpy(), "loss": np.float32(loss.item())}
     lab = batch["label1ds"]
-    res["loss_loc"] = np.float32(loss_mod.lossfun_loc(out["slogits"], out["elogits"], lab[:, 0], lab[:, 1],
-                                                      batch["vmasks"]).item())
+    zs, ze = out["slogits"], out["elogits"]
+    if variant == "BaseFast":
+        zs, ze = torch.sigmoid(zs), torch.sigmoid(ze)
+    res["loss_loc"] = np.float32(loss_mod.lossfun_loc(zs, ze, lab[:, 0], lab[:, 1], batch["vmasks"]).item())
     res["loss_match"] = np.float32(loss_mod.lossfun_match(out["match_score"], out["label_embs"],
                                                           batch["NER_labels"], batch["vmasks"]).item())
     res["infer"] = seqpan_mod.infer_SeqPAN(out, cfg).astype(np.float32)
@@ -111,9 +117,9 @@ def run_reference(mods, cfg, weights, batch, g, train_mode_grads=True, hooks=Fal
     return res, inter, grads, model
 
 
-def run_oracle(cfg, weights, batch, g):
+def run_oracle(cfg, weights, batch, g, variant="SeqPAN"):
     P = R.to_params(weights, requires_grad=True)
-    loss, out, (loc, mat) = R.train_loss(P, cfg, batch, g)
+    loss, out, (loc, mat) = R.train_loss(P, cfg, batch, g, variant=variant)
     loss.backward()
     grads = {k: v.grad.numpy() for k, v in P.items() if v.grad is not None}
     return loss, out, grads
@@ -123,16 +129,17 @@ def maxdiff(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
 
 
-def case(mods, name, B, T, L, D, V, num_words, num_chars, C, seed, store_weights, hooks, mutate=None):
-    cfg = R.make_cfg(dim=D, vlen=T, vdim=V, num_words=num_words, num_chars=num_chars)
-    weights = R.make_weights(cfg, seed)
+def case(mods, name, B, T, L, D, V, num_words, num_chars, C, seed, store_weights, hooks, mutate=None,
+         variant="SeqPAN"):
+    cfg = R.make_cfg(dim=D, vlen=T, vdim=V, num_words=num_words, num_chars=num_chars, name=variant)
+    weights = R.make_weights(cfg, seed, enc_layers=2 if variant == "BaseFast" else 4)
     batch = R.synth_batch(B, T, L, V, num_words, num_chars, C=C, seed=seed)
     if mutate:
         mutate(batch)
     g = R.gumbel_noise(B, T, seed)
-    res, inter, grads, _ = run_reference(mods, cfg, weights, batch, g, hooks=hooks)
+    res, inter, grads, _ = run_reference(mods, cfg, weights, batch, g, hooks=hooks, variant=variant)
     # validate the restatement against the real reference right here
-    loss_o, out_o, grads_o = run_oracle(cfg, weights, batch, g)
+    loss_o, out_o, grads_o = run_oracle(cfg, weights, batch, g, variant)
     d = {k: maxdiff(res[k], out_o[k].detach().numpy()) for k in ("slogits", "elogits", "match_score")}
     d["loss"] = abs(float(res["loss"]) - float(loss_o.item()))
     gmax = max(float(np.max(np.abs(v))) for v in grads.values())
@@ -161,7 +168,8 @@ def case(mods, name, B, T, L, D, V, num_words, num_chars, C, seed, store_weights
         for k in ("label_embs", "match_conv1d.conv1d.bias", "predictor.start_dense.conv1d.weight",
                   "q2v_attn.w4mlu", "video_affine.v_layer_norm.weight",
                   "dual_attention_block_1.dual_multihead_attention.bilinear_1.bias_value"):
-            save["g." + k] = grads[k]
+            if k in grads:
+                save["g." + k] = grads[k]
         save["gnorms.keys"] = np.array(sorted(grads))
         save["gnorms.vals"] = np.array([np.sqrt((grads[k].astype(np.float64) ** 2).sum()) for k in sorted(grads)],
                                        np.float32)
@@ -232,6 +240,11 @@ def main():
     # g_cfg2_small_B: cfg2 shapes at a DP-shard-sized batch
     case(mods, "g_cfg2_small_B", B=8, T=128, L=20, D=1024, V=500, num_words=4002, num_chars=60, C=8, seed=15,
          store_weights=False, hooks=False)
+    # "next" row N1: BaseFast (models/BaseFast.py) -- tiny with everything stored, and a T=256-style shape
+    case(mods, "g_basefast_tiny", B=3, T=16, L=6, D=32, V=24, num_words=30, num_chars=12, C=5, seed=16,
+         store_weights=True, hooks=False, variant="BaseFast")
+    case(mods, "g_basefast", B=4, T=256, L=12, D=256, V=1024, num_words=300, num_chars=40, C=8, seed=17,
+         store_weights=False, hooks=False, variant="BaseFast")
     if args.time:
         time_both(mods)
 

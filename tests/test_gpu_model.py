@@ -175,3 +175,27 @@ def test_flat_arena_direct_accumulation_and_fused_adamw(dev):
         if p.grad is not None and float(p.grad.abs().max()) < 1e-5 * gmax:
             continue   # analytically-zero gradients (e.g. logit-shift biases): Adam turns fp32 noise into +-lr steps
         assert float((p.detach() - q.detach()).abs().max()) <= 2e-4 * max(1.0, float(p.detach().abs().max())), n
+
+
+@pytest.mark.parametrize("name", ["g_basefast_tiny", "g_basefast"])
+def test_basefast_fp32_vs_golden(dev, name):
+    """'next' row N1: BaseFast through the same HIP kernels, fp32, <= 1e-3."""
+    import vmrframe_amd as V
+    z, cfg, batch, g, weights = load_golden(name, enc_layers=2)
+    cfg.model.compute_dtype = "fp32"
+    cfg.device = dev
+    model = V.BaseFast(cfg, weights["text_encoder.word_emb.glove_vec"])
+    assert list(model.state_dict().keys()) == list(weights.keys())
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()})
+    model.to(dev).eval()
+    model.gumbel_override = g.to(dev)
+    loss, out = V.train_engine_BaseFast(model, batch, cfg, "train")
+    assert _md(out["slogits"].detach().cpu(), z["out.slogits"]) < TOL_F32
+    assert _md(out["elogits"].detach().cpu(), z["out.elogits"]) < TOL_F32
+    assert abs(loss.item() - float(z["out.loss"])) < TOL_F32 * max(1.0, abs(float(z["out.loss"])))
+    np.testing.assert_allclose(V.infer_BaseFast(out, cfg), z["out.infer"], atol=1e-6)
+    loss.backward()
+    if "gnorm" in z.files:
+        mine = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+        assert abs(mine - float(z["gnorm"])) < 3e-3 * float(z["gnorm"])
+    assert model.P("dual_attention_block_2.dense_2.conv1d.weight").grad is None

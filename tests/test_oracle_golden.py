@@ -96,3 +96,16 @@ def test_fully_masked_rows_are_finite():
                                batch["vmasks"], batch["tmasks"], g)
     for k in ("slogits", "elogits", "match_score"):
         assert torch.isfinite(out[k]).all()
+
+
+@pytest.mark.parametrize("name", ["g_basefast_tiny", "g_basefast"])
+def test_oracle_basefast_variant(name):
+    """'next' row N1: the BaseFast path (reference models/BaseFast.py) of the oracle vs its goldens."""
+    z, cfg, batch, g, weights = load_golden(name, enc_layers=2)
+    P = R.to_params(weights, requires_grad=True)
+    loss, out, _ = R.train_loss(P, cfg, batch, g, variant="BaseFast")
+    assert _md(out["slogits"].detach(), z["out.slogits"]) < TOL
+    assert _md(out["elogits"].detach(), z["out.elogits"]) < TOL
+    assert abs(float(loss) - float(z["out.loss"])) < TOL
+    loss.backward()
+    assert P["dual_attention_block_1.dense_1.conv1d.weight"].grad is None      # blocks constructed but skipped

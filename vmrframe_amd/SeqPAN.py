@@ -48,7 +48,7 @@ def _cfg_get(obj, name, default=None):
 # ---------------------------------------------------------------------------
 # parameter inventory: the reference's 192 state_dict entries
 # ---------------------------------------------------------------------------
-def seqpan_param_shapes(D, V, vlen, num_words, num_chars, word_dim=300, char_dim=100):
+def seqpan_param_shapes(D, V, vlen, num_words, num_chars, word_dim=300, char_dim=100, enc_layers=4):
     S = OrderedDict()
 
     def conv1d(p, cin, cout):
@@ -59,12 +59,12 @@ def seqpan_param_shapes(D, V, vlen, num_words, num_chars, word_dim=300, char_dim
         S[p + ".weight"] = (D,)
         S[p + ".bias"] = (D,)
 
-    def conv_block(p):
-        for l in range(4):
+    def conv_block(p, n=4):
+        for l in range(n):
             S[f"{p}.depthwise_separable_conv.{l}.0.weight"] = (D, 1, 7)
             S[f"{p}.depthwise_separable_conv.{l}.1.weight"] = (D, D, 1)
             S[f"{p}.depthwise_separable_conv.{l}.1.bias"] = (D,)
-        for l in range(4):
+        for l in range(n):
             ln(f"{p}.layer_norms.{l}")
 
     S["label_embs"] = (D, 4)
@@ -80,7 +80,7 @@ def seqpan_param_shapes(D, V, vlen, num_words, num_chars, word_dim=300, char_dim
     conv1d("video_affine.video_conv1d", V, D)
     ln("video_affine.v_layer_norm")
     S["vfeat_encoder.pos_embedding.position_embeddings.weight"] = (vlen, D)
-    conv_block("vfeat_encoder.conv_block")
+    conv_block("vfeat_encoder.conv_block", enc_layers)
     for blk in (1, 2):
         p = f"dual_attention_block_{blk}"
         ln(p + ".layer_norm_1"); ln(p + ".layer_norm_2"); ln(p + ".layer_norm_t")
@@ -171,6 +171,8 @@ def _init_param(name: str, shape, gen: torch.Generator) -> torch.Tensor:
 class SeqPAN(nn.Module):
     """Drop-in for reference models/SeqPAN.py:10-95 (same constructor, forward
     signature, output dict and state_dict keys)."""
+    ENC_LAYERS = 4          # vfeat_encoder depth (models/SeqPAN.py:29)
+    USE_DUAL_BLOCKS = True  # models/SeqPAN.py:64-70
 
     def __init__(self, configs, word_vectors):
         super().__init__()
@@ -184,7 +186,7 @@ class SeqPAN(nn.Module):
         self.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32}[str(cd)]
         assert self.dim % 8 == 0 and self.dim % self.num_heads == 0
         shapes = seqpan_param_shapes(self.dim, self.vdim, self.vlen, int(configs.num_words), int(configs.num_chars),
-                                     self.word_dim, self.char_dim)
+                                     self.word_dim, self.char_dim, self.ENC_LAYERS)
         gen = torch.Generator().manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF)
         self._pnames = []
         for name, shp in shapes.items():
@@ -241,11 +243,11 @@ class SeqPAN(nn.Module):
     def _ln(self, x, prefix, eps, **kw):
         return ops.layer_norm(x, self.P(prefix + ".weight"), self.P(prefix + ".bias"), eps, self._cache, **kw)
 
-    def _conv_block(self, x, prefix, segs, dc):
+    def _conv_block(self, x, prefix, segs, dc, nlayers=4):
         """DepthwiseSeparableConvBlock (reference layers.py:139-148): 4 x {LN -> dw conv k7 ->
         pw conv + bias -> ReLU -> dropout -> + residual}; LN+dw is one kernel, the rest is the
         GEMM epilogue."""
-        for l in range(4):
+        for l in range(nlayers):
             u, x = ops.ln_dwconv(x, self.P(f"{prefix}.layer_norms.{l}.weight"),
                                  self.P(f"{prefix}.layer_norms.{l}.bias"),
                                  self.P(f"{prefix}.depthwise_separable_conv.{l}.0.weight"), 1e-6, segs, tee=True)
@@ -379,9 +381,9 @@ class SeqPAN(nn.Module):
         xt = self._ln(tq, "text_encoder.q_layer_norm", 1e-6, pos=pos_p, S=Lq)
         X = torch.cat([xv, xt], 0)
         # the SAME encoder on both streams (reference models/SeqPAN.py:59-60)
-        X = self._conv_block(X, "vfeat_encoder.conv_block", segs, dc)
+        X = self._conv_block(X, "vfeat_encoder.conv_block", segs, dc, self.ENC_LAYERS)
         rowmask = torch.cat([vmask.reshape(-1), tmask.reshape(-1)])
-        for blk in (1, 2):
+        for blk in ((1, 2) if self.USE_DUAL_BLOCKS else ()):
             X = self._dual_block(X, f"dual_attention_block_{blk}", vmask, tmask, rowmask, B, T, Lq, dc)
         V3, T3 = X[:Nv].view(B, T, D), X[Nv:].view(B, Lq, D)
         t2v = self._cq_attention("q2v_attn", V3, T3, vmask, tmask, dc)            # [Nv, D]
@@ -459,4 +461,32 @@ def infer_basic(start_logits, end_logits, vmask):
 
 
 def infer_SeqPAN(output, configs):
+    return infer_basic(output["slogits"], output["elogits"], output["vmask"])
+
+
+# ---------------------------------------------------------------------------
+# "next" row N1: BaseFast -- the same kernels, fewer stages
+# ---------------------------------------------------------------------------
+class BaseFast(SeqPAN):
+    """Drop-in for reference models/BaseFast.py:10-97: SeqPAN with a 2-layer shared feature
+    encoder (:27) and the two DualAttentionBlocks constructed but skipped (:62-68) -- their
+    parameters exist in the state_dict and never receive a gradient."""
+    ENC_LAYERS = 2
+    USE_DUAL_BLOCKS = False
+
+
+def train_engine_BaseFast(model, data, configs, runtype):
+    """reference models/BaseFast.py:113-127: a SIGMOID on the logits before the boundary CE."""
+    data = {k: v.to(configs.device) for k, v in data.items()}
+    output = model(data["words_ids"], data["char_ids"], data["vfeats"], data["vmasks"], data["tmasks"])
+    lab = data["label1ds"]
+    loc_loss = lossfun_loc(torch.sigmoid(output["slogits"]), torch.sigmoid(output["elogits"]), lab[:, 0, :],
+                           lab[:, 1, :], data["vmasks"])
+    m_loss = lossfun_match(output["match_score"], output["label_embs"], data["NER_labels"], data["vmasks"].float())
+    return loc_loss + m_loss, output
+
+
+def infer_BaseFast(output, configs):
+    """reference models/BaseFast.py:130-136 (whose body computes `res` but forgets to return it;
+    we return it -- the caller main.py:99-101 indexes the result)."""
     return infer_basic(output["slogits"], output["elogits"], output["vmask"])

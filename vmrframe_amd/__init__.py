@@ -4,7 +4,8 @@ cross-modal matching hot path of renjie-liang/VMRFrame.
 Exports mirror what the reference's `main.py` resolves by name after
 `from models import *` (reference main.py:21,87,99; utils/DataLoader.py:5-6).
 """
-from .SeqPAN import (SeqPAN, infer_basic, infer_SeqPAN, lossfun_loc, lossfun_match,  # noqa: F401
-                     train_engine_SeqPAN)
+from .SeqPAN import (BaseFast, SeqPAN, infer_BaseFast, infer_basic, infer_SeqPAN, lossfun_loc,  # noqa: F401
+                     lossfun_match, train_engine_BaseFast, train_engine_SeqPAN)
 
-__all__ = ["SeqPAN", "train_engine_SeqPAN", "infer_SeqPAN", "infer_basic", "lossfun_loc", "lossfun_match"]
+__all__ = ["SeqPAN", "train_engine_SeqPAN", "infer_SeqPAN", "BaseFast", "train_engine_BaseFast", "infer_BaseFast",
+           "infer_basic", "lossfun_loc", "lossfun_match"]
