@@ -444,12 +444,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
       dma_operand<!TB, BK>(B, g.ldb, n0, k_begin + s * BK, smem + s * 2 * OPB + OPB, wid, lane);
     }
   }
+  // Software-pipelined fragment reads: the ds_reads of the next 32-deep k-substep are in flight while
+  // the 16 MFMAs of the current one issue (rotated loop: the MFMAs of substep (kt, last) run at the top
+  // of iteration kt+1, beside that iteration's first reads).
+  constexpr int NKK = BK / 32;
+  bf16x8 fa[2][4], fb[2][4];
+  auto mma = [&](int buf) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's loads of step kt must have landed; those of the later NST-2 steps stay in flight
     const int later = min(nk - 1 - kt, NST - 2);
     if (later >= 2) wait_vmcnt<2 * LPS>();
     else if (later == 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
+    // this wave's fragment reads of step kt-1 are complete before any wave's DMA may overwrite that buffer
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's part of step kt is in LDS; step kt-1's buffer is free
     if (kt + NST - 1 < nk) {
       unsigned char* dst = smem + ((kt + NST - 1) % NST) * 2 * OPB;
@@ -459,21 +475,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
     }
     const unsigned char* cur = smem + (kt % NST) * 2 * OPB;
 #pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      bf16x8 fa[4], fb[4];
+    for (int kk = 0; kk < NKK; ++kk) {
+      const int buf = kk & 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag<!TA, BK>(cur, wm * 4 + i, kk, lane);
+      for (int i = 0; i < 4; ++i) fa[buf][i] = read_frag<!TA, BK>(cur, wm * 4 + i, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag<!TB, BK>(cur + OPB, wn * 4 + j, kk, lane);
-      __builtin_amdgcn_s_setprio(1);   // keep the MFMA cluster together (compiler + arbitration hint)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+      for (int j = 0; j < 4; ++j) fb[buf][j] = read_frag<!TB, BK>(cur + OPB, wn * 4 + j, kk, lane);
+      // while those reads fly: the MFMAs of the PREVIOUS substep (the last one of step kt-1 when kk == 0)
+      if (kk > 0) mma((kk - 1) & 1);
+      else if (kt > 0) mma((NKK - 1) & 1);
     }
   }
+  if (nk > 0) mma((NKK - 1) & 1);
   __syncthreads();
   epilogue<bf16_t, true, true>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
                          (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM))

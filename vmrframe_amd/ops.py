@@ -110,7 +110,7 @@ def bmm4(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, ta: int, tb: int, *,
          sC=(c.stride(0), c.stride(1)), **kw)
 
 
-SPLITK_TARGET = int(os.environ.get("VMR_SPLITK_TARGET", "256"))   # workgroups to aim for in dW products
+SPLITK_TARGET = int(os.environ.get("VMR_SPLITK_TARGET", "512"))   # workgroups to aim for in dW products
 USE_SLABS = os.environ.get("VMR_SPLITK_SLABS", "1") != "0"
 
 
