@@ -125,6 +125,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    # rehearsal hook for a 1-GPU box: VMR_FORCE_DEVICE=0 + VMR_DIST_BACKEND=gloo runs N ranks on one card
+    local = int(os.environ.get("VMR_FORCE_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -133,7 +135,7 @@ def main():
     from vmrframe_amd import dp, ops
     from vmrframe_amd.optim import FlatAdamW
     if world > 1:
-        dp.init_process_group_from_env("nccl")
+        dp.init_process_group_from_env(os.environ.get("VMR_DIST_BACKEND", "nccl"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     a = CFG2 if args.workload == "seqpan" else CFG4
@@ -152,7 +154,7 @@ def main():
     total_steps = args.steps + args.warmup
     opt = FlatAdamW(model, lr=1e-4, weight_decay=0.01, max_norm=1.0, warmup_steps=0.0 * total_steps,
                     total_steps=10 * total_steps)
-    reducer = dp.GradReducer(model, opt)
+    reducer = dp.GradReducer(model, opt, use_hooks=args.no_graph)
     batch = {k: v.to(dev) for k, v in synth(a, 1234 + rank).items()}   # weak scaling: 64 clips per GPU
     model.train()
 
@@ -193,12 +195,11 @@ def main():
     # per-launch timing of the dominant kernel: HIP events on the launch stream around every NT bf16
     # GEMM of two more (eager) steps of the same workload -- events cannot be recorded inside a graph replay
     timer = GemmTimer() if rank == 0 else None
-    if timer is not None:
-        ops.GEMM_HOOK = timer
-        for _ in range(2):
-            eager_step()
-        torch.cuda.synchronize()
-        ops.GEMM_HOOK = None
+    ops.GEMM_HOOK = timer
+    for _ in range(2):          # every rank takes part (the steps contain the gradient all-reduce)
+        eager_step()
+    torch.cuda.synchronize()
+    ops.GEMM_HOOK = None
     timed_steps_for_hook = 2
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -49,7 +49,7 @@ class ToyOpt:
         self.arena.flat_p.add_(self.arena.flat_g, alpha=-0.1)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, use_hooks=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from vmrframe_amd import dp
     dp.init_process_group_from_env("gloo")
@@ -61,7 +61,7 @@ def _worker(rank, world, port, q):
     mine = dp.shard_batch(full, rank, world)
     assert mine["x"].shape[0] == 6
     opt = ToyOpt(model)
-    red = dp.GradReducer(model, opt, bucket_bytes=256)       # tiny buckets -> several of them
+    red = dp.GradReducer(model, opt, bucket_bytes=256, use_hooks=use_hooks)   # tiny buckets -> several of them
     ref = Toy(); ref.load_state_dict(model.state_dict())
     for it in range(4):
         loss = ((model(mine["x"]) - mine["y"]) ** 2).mean()
@@ -91,12 +91,13 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_two_rank_gradient_averaging_gloo():
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("use_hooks", [True, False])
+def test_two_rank_gradient_averaging_gloo(use_hooks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, use_hooks)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -104,4 +105,4 @@ def test_two_rank_gradient_averaging_gloo():
         assert p.exitcode == 0
     res = sorted(q.get() for _ in range(2))
     assert [r for r, _ in res] == [0, 1]
-    assert res[0][1] >= 2          # the arena really was cut into several buckets
+    assert res[0][1] >= 2 or not use_hooks   # (hook mode) the arena really was cut into several buckets

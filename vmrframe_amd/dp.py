@@ -51,8 +51,11 @@ class GradReducer:
     of whatever gradients exist.  Parameters whose grad is None are skipped (they stay None
     on every rank, as the reference's unused tensors do)."""
 
-    def __init__(self, model: torch.nn.Module, optimizer, bucket_bytes: int = 32 << 20):
-        self.model, self.opt, self.bucket_bytes = model, optimizer, bucket_bytes
+    def __init__(self, model: torch.nn.Module, optimizer, bucket_bytes: int = 32 << 20, use_hooks: bool = True):
+        # use_hooks=False: no autograd hooks at all -- finish() all-reduces the arena in bucket-sized
+        # chunks after backward.  Required when backward is replayed from a captured HIP graph (hooks do
+        # not run on replay, and a collective must never be issued while a graph is being captured).
+        self.model, self.opt, self.bucket_bytes, self.use_hooks = model, optimizer, bucket_bytes, use_hooks
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.buckets: List[dict] = []
         self.param_bucket = {}
@@ -103,6 +106,15 @@ class GradReducer:
                 if p.grad is not None:
                     dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
                     p.grad.div_(self.world)
+            return
+        if not self.use_hooks:
+            flat = self.opt.grad_arena
+            per = max(1, self.bucket_bytes // 4)
+            hs = [dist.all_reduce(flat[o:o + per], op=dist.ReduceOp.SUM, async_op=True)
+                  for o in range(0, flat.numel(), per)]
+            for h in hs:
+                h.wait()
+            flat.div_(self.world)
             return
         if not self.buckets:
             # arena was just built by the previous optimizer step but hooks were not armed for
