@@ -140,6 +140,23 @@ int vmr_softmax_bwd(const float* dP, const void* P, void* dS /*dtype, ld = ldP*/
                     int ldP, float scale, int dtype, float drop_p, uint32_t drop_seed,
                     const uint32_t* drop_step, void* stream);
 
+/* ------------------------------------------------- fused attention (forward)
+ * O = dropout(softmax(scale*Q.K^T + term)).V in ONE kernel (scores and context on MFMA, K/V of a
+ * (z1,z2) slice staged in LDS, P never leaves the chip except as the copy the backward needs).
+ * Replaces the three launches vmr_gemm + vmr_softmax_fwd + vmr_gemm for DualMultiAttention
+ * (layers.py:346-367, mode 0) and TopSelfAttention2 (layers.py:567-574, mode 1); `term`, the
+ * dropout stream and the zero-padded P/Pkeep layout are exactly vmr_softmax_fwd's, so
+ * vmr_softmax_bwd and the backward GEMMs consume its outputs unchanged.
+ * Q,K,V,O: bf16 4-D strided views [Z1,Z2,rows,hd] (unit stride along hd); strides[12] =
+ * {s1,s2,row} for Q,K,V,O in elements (multiples of 8).  Supported: bf16, hd in {128,256},
+ * 1 <= Lk <= 128 (vmr_attention_fwd_supported); anything else returns an error. */
+int vmr_attention_fwd_supported(int hd, int Lk, int dtype);
+int vmr_attention_fwd(const void* Q, const void* K, const void* V, void* O, void* P,
+                      void* Pkeep /*nullable*/, const int64_t* strides, const float* rmask,
+                      const float* cmask, int mode, int Z1, int Z2, int H, int Lq, int Lk, int hd,
+                      int ldP, int cm_stride, float scale, int dtype, float drop_p,
+                      uint32_t drop_seed, const uint32_t* drop_step, void* stream);
+
 /* ------------------------------------------------- CQAttention softmaxes
  * The two masked softmaxes of CQAttention (layers.py:419-421) over the trilinear
  * score S = S2 + rowterm[b,c] + colterm[b,q] (S2 from the batched MFMA GEMM, the

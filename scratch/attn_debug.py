@@ -1,0 +1,30 @@
+import math, sys, torch, ctypes as C
+sys.path.insert(0, "/root/repo")
+from vmrframe_amd import ops, _lib as L
+dev = "cuda"
+torch.manual_seed(0)
+def run(Z1, Z2, Lq, Lk, hd, H):
+    q = torch.randn(Z1, Z2, Lq, hd, device=dev).bfloat16()
+    k = torch.randn(Z1, Z2, Lk, hd, device=dev).bfloat16()
+    v = torch.randn(Z1, Z2, Lk, hd, device=dev).bfloat16()
+    o = torch.zeros(Z1, Z2, Lq, hd, device=dev).bfloat16()
+    rm = torch.ones(Z1, Lq, device=dev); cm = torch.ones(Z1, Lk, device=dev)
+    scale = 1 / math.sqrt(hd)
+    P, Pk = ops._attend_fwd(q, k, v, o, rm, cm, 0, H, 0, scale, ops.NO_DROP)
+    S = (q.float() @ k.float().transpose(-1, -2)) * scale
+    Pr = torch.softmax(S, -1)
+    Or = Pr.bfloat16().float() @ v.float()
+    eP = (P[..., :Lk].float() - Pr).abs()
+    eO = (o.float() - Or).abs()
+    print(f"Z=({Z1},{Z2}) Lq={Lq} Lk={Lk} hd={hd}: P err {eP.max().item():.4f}  O err {eO.max().item():.4f} (O scale {Or.abs().max().item():.2f})")
+    if eP.max() > 0.02:
+        bad = (eP > 0.02).nonzero()
+        print("  bad P idx sample", bad[:8].tolist(), "count", len(bad))
+    if eO.max() > 0.05:
+        bad = (eO > 0.05).nonzero()
+        print("  bad O idx sample", bad[:8].tolist(), "count", len(bad), "of", eO.numel())
+        # which columns / rows are bad
+        print("  bad cols", sorted(set(bad[:, 3].tolist()))[:40])
+        print("  bad rows", sorted(set(bad[:, 2].tolist()))[:40])
+for args in [(1, 1, 16, 32, 128, 1), (1, 1, 16, 32, 256, 1), (1, 1, 64, 128, 256, 1), (1, 1, 128, 128, 256, 1), (2, 4, 128, 20, 256, 4), (2, 4, 20, 128, 256, 4), (2, 4, 70, 70, 128, 4)]:
+    run(*args)

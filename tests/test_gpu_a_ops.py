@@ -197,7 +197,8 @@ def _ref_dual(qkv, kv, vmask, tmask, B, T, Lq, H):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 4e-2)])
-@pytest.mark.parametrize("dims", [(3, 16, 6, 32, 4), (2, 128, 20, 256, 4)])
+@pytest.mark.parametrize("dims", [(3, 16, 6, 32, 4), (2, 128, 20, 256, 4), (2, 128, 20, 1024, 4), (3, 70, 20, 512, 4),
+                                  (2, 40, 33, 512, 4), (2, 1, 1, 256, 2)])
 def test_dual_attention_fwd_bwd(dev, dt, tol, dims):
     ops = _ops()
     B, T, Lq, D, H = dims
@@ -220,12 +221,13 @@ def test_dual_attention_fwd_bwd(dev, dt, tol, dims):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 4e-2)])
-def test_batch_axis_attention_matches_torch_mha(dev, dt, tol):
+@pytest.mark.parametrize("dims", [(5, 12, 64, 4), (64, 9, 512, 2), (37, 5, 512, 4), (70, 3, 256, 1)])
+def test_batch_axis_attention_matches_torch_mha(dev, dt, tol, dims):
     """Against nn.MultiheadAttention itself, fed exactly like the reference
     (models/layers.py:567-574): seq-first on [B,T,D] with a float key_padding_mask."""
     ops = _ops()
     torch.manual_seed(4)
-    B, T, D, H = 5, 12, 64, 4
+    B, T, D, H = dims
     mha = torch.nn.MultiheadAttention(D, H).to(dev).eval()
     x = torch.randn(B, T, D, device=dev)
     vlen = torch.randint(1, T + 1, (B,), device=dev); vlen[0] = T
@@ -277,6 +279,52 @@ def test_attention_dropout_is_consistent(dev):
         fd = (f(qkv + eps * d1, kv + eps * d2) - f(qkv - eps * d1, kv - eps * d2)) / (2 * eps)
     an = (gq * d1).sum() + (gk * d2).sum()
     assert abs(fd.item() - an.item()) <= 2e-2 * max(1.0, abs(an.item())), (fd.item(), an.item())
+
+
+@pytest.mark.parametrize("dims", [(2, 128, 20, 1024, 4), (3, 70, 20, 512, 4), (2, 64, 64, 512, 4)])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_fused_attention_equals_composed_path(dev, dims, p):
+    """csrc/attention.hip against the three-launch path (GEMM + vmr_softmax_fwd + GEMM) on the same
+    inputs and the SAME dropout stream: identical keep pattern, probabilities and contexts to bf16
+    rounding; the backward consumes either's saved P unchanged."""
+    ops = _ops()
+    B, T, Lq, D, H = dims
+    torch.manual_seed(13)
+    N = B * (T + Lq)
+    qkv = torch.randn(N, 3 * D, device=dev).to(torch.bfloat16).requires_grad_(True)
+    kv = torch.randn(N, 2 * D, device=dev).to(torch.bfloat16).requires_grad_(True)
+    vlen = torch.randint(1, T + 1, (B,), device=dev); vlen[0] = T
+    tlen = torch.randint(1, Lq + 1, (B,), device=dev)
+    vmask = (torch.arange(T, device=dev)[None] < vlen[:, None]).float()
+    tmask = (torch.arange(Lq, device=dev)[None] < tlen[:, None]).float()
+    drops = [(p, 21 + i, None) for i in range(4)]
+    g1 = torch.randn(N, D, device=dev).to(torch.bfloat16)
+    g2 = torch.randn(N, D, device=dev).to(torch.bfloat16)
+    res = {}
+    old = ops.FUSED_ATTENTION
+    try:
+        for fused in (True, False):
+            ops.FUSED_ATTENTION = fused
+            so, xo = ops.dual_attention(qkv, kv, vmask, tmask, B, T, Lq, H, drops)
+            gq, gk = torch.autograd.grad([so, xo], [qkv, kv], [g1, g2])
+            res[fused] = (so, xo, gq, gk)
+    finally:
+        ops.FUSED_ATTENTION = old
+    assert ops.L.lib().vmr_attention_fwd_supported(D // H, T, 1)
+    for a, b, what in zip(res[True], res[False], ("self ctx", "cross ctx", "dqkv", "dkv")):
+        _close(a, b, 1.5e-2, "fused vs composed " + what)
+    if p > 0:   # same keep pattern: an element dropped by one path is dropped by the other
+        za, zb = res[True][0] == 0, res[False][0] == 0
+        assert (za == zb).float().mean().item() > 0.999
+
+
+def test_fused_attention_rejects_unsupported_shapes(dev):
+    ops = _ops()
+    lib = ops.L.lib()
+    assert lib.vmr_attention_fwd_supported(256, 128, 1) == 1
+    assert lib.vmr_attention_fwd_supported(256, 129, 1) == 0
+    assert lib.vmr_attention_fwd_supported(64, 20, 1) == 0
+    assert lib.vmr_attention_fwd_supported(256, 20, 0) == 0   # fp32 goes through the composed path
 
 
 def test_soft_ce_matches_torch(dev):

@@ -54,6 +54,8 @@ SIGNATURES = {
     "vmr_dwconv_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vmr_softmax_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _F, _U, _P, _P],
     "vmr_softmax_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U, _P, _P],
+    "vmr_attention_fwd_supported": [_I, _I, _I],
+    "vmr_attention_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _F, _U, _P, _P],
     "vmr_cq_softmax_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_cq_softmax_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_soft_ce_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],

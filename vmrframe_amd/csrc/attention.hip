@@ -1,0 +1,233 @@
+// attention.hip -- fused attention forward for gfx950: scores (MFMA) + mask + softmax + dropout
+// + context gather (MFMA) in ONE kernel, for the three attention forms of the SeqPAN path:
+//   * DualMultiAttention self / cross attention (reference models/layers.py:346-367): mode 0,
+//     z = (b,h), term = (1 - rmask[b,q] * cmask[b,k]) * -1e30;
+//   * TopSelfAttention2 (layers.py:567-574, attention over the BATCH axis per time step): mode 1,
+//     z = (t,h), term = cmask[k*cm_stride + t] (a float key-padding mask is ADDED).
+// Workgroup = (z, 64-query tile), 4 waves x 16 queries.  K and V of the (z) slice are staged in LDS
+// once per workgroup (<= 64 KiB each: Lk <= 128 keys x hd <= 256); each wave keeps its 16 x hd
+// query fragments in registers (loaded straight from HBM, read once).  Scores are computed
+// TRANSPOSED (S^T = K.Q^T) so a lane owns 4 consecutive keys of one query: the key-axis softmax
+// is an in-lane reduction plus two cross-lane steps, and P goes to the per-wave LDS image with
+// 8-byte writes.  The context is computed as O^T = V^T.P^T (V through ds_read_b64_tr_b16, P as the
+// k-contiguous operand) so a lane owns 4 consecutive output channels: 8-byte global stores.
+// P (dropped-out) and the pre-dropout probabilities are also written out for the backward pass.
+// bf16 only (fp32 / odd shapes use the batched-GEMM + softmax kernels).
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+  const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
+  bf16_t* P; bf16_t* Pk;                       // [Z, Lq, ldP]; Pk may be null (no dropout)
+  int64_t q_s1, q_s2, q_row, k_s1, k_s2, k_row, v_s1, v_s2, v_row, o_s1, o_s2, o_row;
+  const float* rmask; const float* cmask;
+  int mode, H, Z2, Lq, Lk, ldP, cm_stride;
+  float scale, drop_p; uint32_t seed; const uint32_t* step;
+};
+
+__device__ __forceinline__ int swz3(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+template <int HD, int LKP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int RB = HD * 2;            // bytes per K / V row
+  constexpr int NJ = LKP / 16;          // key tiles
+  constexpr int NT = HD / 16;           // output-channel tiles
+  constexpr int PRB = LKP * 2;          // bytes per row of the per-wave P image
+  constexpr int PM = (PRB / 16 - 1) & 15;  // swizzle mask: stay inside the row
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + LKP * RB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* Ps = smem + 2 * LKP * RB + wid * 16 * PRB;
+  const int z = blockIdx.x, z1 = z / a.Z2, z2 = z - z1 * a.Z2;
+  const int q0 = blockIdx.y * 64 + wid * 16;
+  const bf16_t* Kg = a.K + z1 * a.k_s1 + z2 * a.k_s2;
+  const bf16_t* Vg = a.V + z1 * a.v_s1 + z2 * a.v_s2;
+  const bf16_t* Qg = a.Q + z1 * a.q_s1 + z2 * a.q_s2;
+  // ---- stage K (k-contiguous rows, 16-B chunk ^= row&15) and V ([key][channel] rows, 32-B chunk ^= swz3(key))
+  constexpr int CPR = HD / 8;           // 16-B chunks per row
+  for (int id = tid; id < LKP * CPR; id += 256) {
+    const int row = id / CPR, c = id - row * CPR;
+    bf16x8 kv, vv;
+    if (row < a.Lk) {
+      kv = *reinterpret_cast<const bf16x8*>(Kg + (int64_t)row * a.k_row + c * 8);
+      vv = *reinterpret_cast<const bf16x8*>(Vg + (int64_t)row * a.v_row + c * 8);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { kv[e] = (bf16_t)0.f; vv[e] = (bf16_t)0.f; }
+    }
+    *reinterpret_cast<bf16x8*>(Ks + row * RB + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4)) = kv;
+    *reinterpret_cast<bf16x8*>(Vs + row * RB + ((((c >> 1) ^ swz3(row))) << 5) + ((c & 1) << 4)) = vv;
+  }
+  // ---- this wave's query fragments (B operand of S^T = K.Q^T): lane = (query lane&15, k-chunk lane>>4)
+  const int qi = min(q0 + (lane & 15), a.Lq - 1);   // clamped; rows >= Lq are never stored
+  bf16x8 qf[HD / 32];
+#pragma unroll
+  for (int ks = 0; ks < HD / 32; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)qi * a.q_row + ks * 32 + (lane >> 4) * 8);
+  __syncthreads();
+  if (q0 >= a.Lq) return;               // (after the barrier: whole wave is out of range)
+  // ---- S^T tiles: rows = keys, cols = queries
+  f32x4 st[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) st[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < HD / 32; ++ks) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int row = j * 16 + (lane & 15);
+      const int c = ks * 4 + (lane >> 4);
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * RB + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
+      st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[j], 0, 0, 0);
+    }
+  }
+  // lane owns query q = q0 + (lane&15) and keys j*16 + (lane>>4)*4 + r
+  const int q = q0 + (lane & 15);
+  const bool qok = q < a.Lq;
+  const int zo = z / a.H;
+  const float rm = (a.mode == 0 && qok) ? a.rmask[(int64_t)zo * a.Lq + q] : 1.f;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = j * 16 + (lane >> 4) * 4 + r;
+      float x = -INFINITY;
+      if (key < a.Lk) {
+        x = st[j][r] * a.scale;
+        if (a.mode == 0) x += (1.0f - rm * a.cmask[(int64_t)zo * a.Lk + key]) * VMR_NEG_INF_MASK;
+        else x += a.cmask[(int64_t)key * a.cm_stride + zo];
+      }
+      st[j][r] = x;
+      mx = fmaxf(mx, x);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = __expf(st[j][r] - mx);   // exp(-inf) = 0 for padded keys
+      st[j][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  const uint32_t seed = vmr_seed(a.seed, a.step);
+  const uint32_t thresh = vmr_drop_thresh(a.drop_p);
+  const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  // ---- P -> per-wave LDS image [query][key] (k-contiguous rows, 16-B chunk ^= query & PM), 8-byte writes
+  const int64_t prow = ((int64_t)z * a.Lq + q);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    float pk[4], pd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = j * 16 + (lane >> 4) * 4 + r;
+      pk[r] = st[j][r] * inv;
+      pd[r] = pk[r];
+      if (a.drop_p > 0.f) pd[r] = vmr_keep(seed, (uint64_t)prow * a.Lk + key, thresh) ? pk[r] * dscale : 0.f;
+    }
+    const int key0 = j * 16 + (lane >> 4) * 4;
+    const int c = key0 >> 3, half = (key0 >> 2) & 1;
+    Vec4<bf16_t>::store(reinterpret_cast<bf16_t*>(Ps + (lane & 15) * PRB + ((c ^ ((lane & 15) & PM)) << 4) + half * 8), pd);
+    if (qok) {   // global copies for the backward pass: 8-byte stores, key0 < ldP guards the padding
+      if (key0 < a.ldP) {
+        Vec4<bf16_t>::store(a.P + prow * a.ldP + key0, pd);
+        if (a.Pk) Vec4<bf16_t>::store(a.Pk + prow * a.ldP + key0, pk);
+      }
+    }
+  }
+  // (only this wave reads its own P image; LDS ops of one wave complete in order)
+  // ---- O^T = V^T . P^T : A = V^T via transposed reads of the [key][channel] image, B = P (k-contiguous)
+  f32x4 ot[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) ot[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+#pragma unroll
+  for (int ks = 0; ks < LKP / 32; ++ks) {
+    const int prow_l = lane & 15, pc = ks * 4 + (lane >> 4);
+    const bf16x8 pf = *reinterpret_cast<const bf16x8*>(Ps + prow_l * PRB + ((pc ^ (prow_l & PM)) << 4));
+    const int g = lane >> 4, ii = lane & 15, qq = ii >> 2, p = ii & 3;
+    const int r = ks * 32 + 8 * g + qq;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int a0 = r * RB + ((t ^ swz3(r)) << 5) + p * 8;
+      const int a1 = (r + 4) * RB + ((t ^ swz3(r + 4)) << 5) + p * 8;
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Vs + a0));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Vs + a1));
+      union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+      u.s.l = lo; u.s.h = hi;
+      ot[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf, ot[t], 0, 0, 0);
+    }
+  }
+  if (qok) {
+    bf16_t* Og = a.O + z1 * a.o_s1 + z2 * a.o_s2 + (int64_t)q * a.o_row;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float o4[4] = {ot[t][0], ot[t][1], ot[t][2], ot[t][3]};
+      Vec4<bf16_t>::store(Og + t * 16 + (lane >> 4) * 4, o4);
+    }
+  }
+}
+
+template <int HD, int LKP>
+int launch_attn(const AttnArgs& a, int Z, hipStream_t st) {
+  constexpr int smem = 2 * LKP * HD * 2 + 4 * 16 * LKP * 2;
+  const void* fn = (const void*)attn_fwd_kernel<HD, LKP>;
+  if (smem > 64 * 1024) {
+    static thread_local bool done = false;
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (e != hipSuccess) return vmr_fail(-5, "vmr_attention_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL((attn_fwd_kernel<HD, LKP>), dim3(Z, (a.Lq + 63) / 64), dim3(256), smem, st, a);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vmr_attention_fwd_supported(int hd, int Lk, int dtype) {
+  return dtype == VMR_BF16 && (hd == 128 || hd == 256) && Lk >= 1 && Lk <= 128;
+}
+
+extern "C" int vmr_attention_fwd(const void* Q, const void* K, const void* V, void* O, void* P, void* Pk,
+                                 const int64_t* strides /*q,k,v,o x (s1,s2,row)*/, const float* rmask,
+                                 const float* cmask, int mode, int Z1, int Z2, int H, int Lq, int Lk, int hd, int ldP,
+                                 int cm_stride, float scale, int dtype, float drop_p, uint32_t drop_seed,
+                                 const uint32_t* drop_step, void* stream) {
+  VMR_CHECK(Q && K && V && O && P && strides && cmask, "vmr_attention_fwd: null pointer");
+  VMR_CHECK(vmr_attention_fwd_supported(hd, Lk, dtype), "vmr_attention_fwd: unsupported shape hd=%d Lk=%d dtype=%d", hd, Lk,
+            dtype);
+  VMR_CHECK(mode == 0 || mode == 1, "vmr_attention_fwd: bad mode");
+  VMR_CHECK(mode != 0 || rmask, "vmr_attention_fwd: mode 0 needs rmask");
+  VMR_CHECK(ldP % 4 == 0 && ldP >= Lk, "vmr_attention_fwd: ldP must be a multiple of 4 and >= Lk");
+  for (int i = 0; i < 12; ++i) VMR_CHECK(strides[i] % 8 == 0, "vmr_attention_fwd: strides must be multiples of 8 elements");
+  VMR_CHECK((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)P) & 15) == 0, "vmr_attention_fwd: 16-byte alignment");
+  const int Z = Z1 * Z2;
+  if (Z == 0 || Lq == 0) return 0;
+  VMR_CHECK(Z <= 65535 * 32, "vmr_attention_fwd: too many batches");
+  AttnArgs a;
+  a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.O = (bf16_t*)O;
+  a.P = (bf16_t*)P; a.Pk = (bf16_t*)Pk;
+  a.q_s1 = strides[0]; a.q_s2 = strides[1]; a.q_row = strides[2];
+  a.k_s1 = strides[3]; a.k_s2 = strides[4]; a.k_row = strides[5];
+  a.v_s1 = strides[6]; a.v_s2 = strides[7]; a.v_row = strides[8];
+  a.o_s1 = strides[9]; a.o_s2 = strides[10]; a.o_row = strides[11];
+  a.rmask = rmask; a.cmask = cmask; a.mode = mode; a.H = H; a.Z2 = Z2; a.Lq = Lq; a.Lk = Lk; a.ldP = ldP;
+  a.cm_stride = cm_stride; a.scale = scale; a.drop_p = drop_p; a.seed = drop_seed; a.step = drop_step;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = 0;
+  const int lkp = Lk <= 32 ? 32 : (Lk <= 64 ? 64 : 128);
+  if (hd == 256) rc = lkp == 32 ? launch_attn<256, 32>(a, Z, st) : (lkp == 64 ? launch_attn<256, 64>(a, Z, st) : launch_attn<256, 128>(a, Z, st));
+  else rc = lkp == 32 ? launch_attn<128, 32>(a, Z, st) : (lkp == 64 ? launch_attn<128, 64>(a, Z, st) : launch_attn<128, 128>(a, Z, st));
+  if (rc) return rc;
+  VMR_LAUNCH_CHECK();
+  return 0;
+}

@@ -112,6 +112,7 @@ def bmm4(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, ta: int, tb: int, *,
 
 SPLITK_TARGET = int(os.environ.get("VMR_SPLITK_TARGET", "512"))   # workgroups to aim for in dW products
 USE_SLABS = os.environ.get("VMR_SPLITK_SLABS", "1") != "0"
+FUSED_ATTENTION = os.environ.get("VMR_FUSED_ATTN", "1") != "0"   # csrc/attention.hip forward (bf16, hd 128/256)
 
 
 def splitk_for(M: int, N: int, K: int) -> int:
@@ -532,9 +533,20 @@ def _softmax_bwd(dP, Pk, R, Cc, scale, drop):
 
 def _attend_fwd(q4, k4, v4, o4, rmask, cmask, mode, H, cm_stride, scale, drop):
     """o = softmax(q.k^T*scale + mask).v over 4-D strided views [Z1,Z2,rows,hd]."""
-    Z1, Z2, R, _ = q4.shape
+    Z1, Z2, R, hd = q4.shape
     Ck = k4.shape[2]
     ld = _rup(Ck, 8)
+    if FUSED_ATTENTION and L.lib().vmr_attention_fwd_supported(hd, Ck, L.dtype_code(q4)) and all(
+            t.stride(3) == 1 and all(s % 8 == 0 for s in t.stride()[:3]) for t in (q4, k4, v4, o4)):
+        # one kernel: scores + mask + softmax + dropout + context (csrc/attention.hip)
+        P = torch.empty(Z1, Z2, R, ld, device=q4.device, dtype=q4.dtype)
+        Pk = torch.empty_like(P) if drop[0] > 0 else None
+        strides = (C.c_int64 * 12)(*[s for t in (q4, k4, v4, o4) for s in t.stride()[:3]])
+        L.check(L.lib().vmr_attention_fwd(q4.data_ptr(), k4.data_ptr(), v4.data_ptr(), o4.data_ptr(), P.data_ptr(),
+                                          _ptr(Pk), strides, _ptr(rmask), cmask.data_ptr(), mode, Z1, Z2, H, R, Ck, hd,
+                                          ld, cm_stride, scale, L.dtype_code(q4), drop[0], drop[1], _ptr(drop[2]),
+                                          L.stream_ptr()), "vmr_attention_fwd")
+        return P, (Pk if Pk is not None else P)
     S = torch.empty(Z1, Z2, R, ld, device=q4.device, dtype=torch.float32)
     bmm4(q4, k4, S[..., :Ck], 0, 0)
     P, Pk = _softmax_fwd(S, R, Ck, ld, rmask, cmask, mode, H, cm_stride, scale, q4.dtype, drop)
