@@ -28,3 +28,24 @@ def run(Z1, Z2, Lq, Lk, hd, H):
         print("  bad rows", sorted(set(bad[:, 2].tolist()))[:40])
 for args in [(1, 1, 16, 32, 128, 1), (1, 1, 16, 32, 256, 1), (1, 1, 64, 128, 256, 1), (1, 1, 128, 128, 256, 1), (2, 4, 128, 20, 256, 4), (2, 4, 20, 128, 256, 4), (2, 4, 70, 70, 128, 4)]:
     run(*args)
+
+def timeit(Z1, Z2, Lq, Lk, hd, H, p=0.2, iters=20):
+    q = torch.randn(Z1, Z2, Lq, hd, device=dev).bfloat16()
+    k = torch.randn(Z1, Z2, Lk, hd, device=dev).bfloat16()
+    v = torch.randn(Z1, Z2, Lk, hd, device=dev).bfloat16()
+    o = torch.zeros(Z1, Z2, Lq, hd, device=dev).bfloat16()
+    rm = torch.ones(Z1, Lq, device=dev); cm = torch.ones(Z1, Lk, device=dev)
+    scale = 1 / math.sqrt(hd)
+    for fused in (True, False):
+        ops.FUSED_ATTENTION = fused
+        for _ in range(3): ops._attend_fwd(q, k, v, o, rm, cm, 0, H, 0, scale, (p, 5, None))
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters): ops._attend_fwd(q, k, v, o, rm, cm, 0, H, 0, scale, (p, 5, None))
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        print(f"  time Z=({Z1},{Z2}) Lq={Lq} Lk={Lk} hd={hd} fused={fused}: {e0.elapsed_time(e1)*1e3/iters:.1f} us")
+for args in [(64, 4, 128, 128, 256, 4), (64, 4, 128, 20, 256, 4), (64, 4, 20, 128, 256, 4), (64, 4, 20, 20, 256, 4), (128, 4, 64, 64, 256, 4)]:
+    timeit(*args)

@@ -4,9 +4,9 @@
 //     z = (b,h), term = (1 - rmask[b,q] * cmask[b,k]) * -1e30;
 //   * TopSelfAttention2 (layers.py:567-574, attention over the BATCH axis per time step): mode 1,
 //     z = (t,h), term = cmask[k*cm_stride + t] (a float key-padding mask is ADDED).
-// Workgroup = (z, 64-query tile), 4 waves x 16 queries.  K and V of the (z) slice are staged in LDS
-// once per workgroup (<= 64 KiB each: Lk <= 128 keys x hd <= 256); each wave keeps its 16 x hd
-// query fragments in registers (loaded straight from HBM, read once).  Scores are computed
+// Workgroup = (z, query tile of 32/64/128), one wave per 16 queries.  K and V of the (z) slice go
+// global -> LDS by DMA (global_load_lds, <= 64 KiB each: Lk <= 128 keys x hd <= 256; V lands while
+// the scores are computed); each wave keeps its 16 x hd query fragments in registers.  Scores are computed
 // TRANSPOSED (S^T = K.Q^T) so a lane owns 4 consecutive keys of one query: the key-axis softmax
 // is an in-lane reduction plus two cross-lane steps, and P goes to the per-wave LDS image with
 // 8-byte writes.  The context is computed as O^T = V^T.P^T (V through ds_read_b64_tr_b16, P as the
@@ -28,61 +28,86 @@ struct AttnArgs {
 
 __device__ __forceinline__ int swz3(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
-template <int HD, int LKP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+// One (z, query-tile) per workgroup of NW waves x 16 queries.
+template <int HD, int LKP, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
   constexpr int RB = HD * 2;            // bytes per K / V row
   constexpr int NJ = LKP / 16;          // key tiles
   constexpr int NT = HD / 16;           // output-channel tiles
   constexpr int PRB = LKP * 2;          // bytes per row of the per-wave P image
   constexpr int PM = (PRB / 16 - 1) & 15;  // swizzle mask: stay inside the row
+  constexpr int SPR = RB / 16;          // 16-B slots per K / V row (16 or 32)
+  constexpr int NBLK = LKP * RB / 1024; // 1-KiB DMA blocks per operand
+  static_assert(NBLK % NW == 0, "DMA blocks must divide over the waves");
+  static_assert(NW * 16 * PRB <= LKP * RB, "P images alias the K image");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + LKP * RB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned char* Ps = smem + 2 * LKP * RB + wid * 16 * PRB;
+  unsigned char* Ps = smem + wid * 16 * PRB;     // aliases Ks: written only after every wave left the S phase
   const int z = blockIdx.x, z1 = z / a.Z2, z2 = z - z1 * a.Z2;
-  const int q0 = blockIdx.y * 64 + wid * 16;
+  const int q0 = blockIdx.y * (NW * 16) + wid * 16;
+  const bool active = q0 < a.Lq;        // wave-uniform
   const bf16_t* Kg = a.K + z1 * a.k_s1 + z2 * a.k_s2;
   const bf16_t* Vg = a.V + z1 * a.v_s1 + z2 * a.v_s2;
   const bf16_t* Qg = a.Q + z1 * a.q_s1 + z2 * a.q_s2;
-  // ---- stage K (k-contiguous rows, 16-B chunk ^= row&15) and V ([key][channel] rows, 32-B chunk ^= swz3(key))
-  constexpr int CPR = HD / 8;           // 16-B chunks per row
-  for (int id = tid; id < LKP * CPR; id += 256) {
-    const int row = id / CPR, c = id - row * CPR;
-    bf16x8 kv, vv;
-    if (row < a.Lk) {
-      kv = *reinterpret_cast<const bf16x8*>(Kg + (int64_t)row * a.k_row + c * 8);
-      vv = *reinterpret_cast<const bf16x8*>(Vg + (int64_t)row * a.v_row + c * 8);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { kv[e] = (bf16_t)0.f; vv[e] = (bf16_t)0.f; }
-    }
-    *reinterpret_cast<bf16x8*>(Ks + row * RB + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4)) = kv;
-    *reinterpret_cast<bf16x8*>(Vs + row * RB + ((((c >> 1) ^ swz3(row))) << 5) + ((c & 1) << 4)) = vv;
-  }
   // ---- this wave's query fragments (B operand of S^T = K.Q^T): lane = (query lane&15, k-chunk lane>>4)
   const int qi = min(q0 + (lane & 15), a.Lq - 1);   // clamped; rows >= Lq are never stored
   bf16x8 qf[HD / 32];
 #pragma unroll
   for (int ks = 0; ks < HD / 32; ++ks)
     qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)qi * a.q_row + ks * 32 + (lane >> 4) * 8);
-  __syncthreads();
-  if (q0 >= a.Lq) return;               // (after the barrier: whole wave is out of range)
+  // ---- K and V of this (z) slice: global -> LDS DMA, 1 KiB per wave-instruction, images swizzled through
+  // the per-lane SOURCE address.  K: k-contiguous rows, 16-B slot = chunk ^ (row&15) within 256 B;
+  // V: [key][channel] rows, 32-B slot = channel-tile ^ swz3(key).  Rows >= Lk re-read row Lk-1 (their
+  // probabilities are exactly 0).
+#pragma unroll
+  for (int jj = 0; jj < NBLK / NW; ++jj) {
+    const int j = jj * NW + wid;
+    const int row = (64 / SPR) * j + lane / SPR, sl = lane % SPR;
+    const int c = (sl & ~15) | ((sl & 15) ^ (row & 15));
+    const bf16_t* src = Kg + (int64_t)min(row, a.Lk - 1) * a.k_row + c * 8;
+    __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)(Ks + j * 1024), 16, 0, 0);
+  }
+#pragma unroll
+  for (int jj = 0; jj < NBLK / NW; ++jj) {
+    const int j = jj * NW + wid;
+    const int row = (64 / SPR) * j + lane / SPR, sl = lane % SPR;
+    const int c = (((sl >> 1) ^ swz3(row)) << 1) | (sl & 1);
+    const bf16_t* src = Vg + (int64_t)min(row, a.Lk - 1) * a.v_row + c * 8;
+    __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)(Vs + j * 1024), 16, 0, 0);
+  }
+  // K (issued before V) has landed when at most the V blocks are still in flight
+  if (NBLK / NW == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if (NBLK / NW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (NBLK / NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (NBLK / NW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   // ---- S^T tiles: rows = keys, cols = queries
   f32x4 st[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) st[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (active) {
 #pragma unroll
-  for (int ks = 0; ks < HD / 32; ++ks) {
+    for (int ks = 0; ks < HD / 32; ++ks) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int row = j * 16 + (lane & 15);
-      const int c = ks * 4 + (lane >> 4);
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * RB + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
-      st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j) {
+        const int row = j * 16 + (lane & 15);
+        const int c = ks * 4 + (lane >> 4);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * RB + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
+        st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[j], 0, 0, 0);
+      }
     }
   }
+  // every wave is done reading K (its space becomes the P images) and every wave's V blocks have landed
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (!active) return;
   // lane owns query q = q0 + (lane&15) and keys j*16 + (lane>>4)*4 + r
   const int q = q0 + (lane & 15);
   const bool qok = q < a.Lq;
@@ -135,11 +160,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int key0 = j * 16 + (lane >> 4) * 4;
     const int c = key0 >> 3, half = (key0 >> 2) & 1;
     Vec4<bf16_t>::store(reinterpret_cast<bf16_t*>(Ps + (lane & 15) * PRB + ((c ^ ((lane & 15) & PM)) << 4) + half * 8), pd);
-    if (qok) {   // global copies for the backward pass: 8-byte stores, key0 < ldP guards the padding
-      if (key0 < a.ldP) {
-        Vec4<bf16_t>::store(a.P + prow * a.ldP + key0, pd);
-        if (a.Pk) Vec4<bf16_t>::store(a.Pk + prow * a.ldP + key0, pk);
-      }
+    if (qok && key0 < a.ldP) {   // global copies for the backward pass (zero filled up to ldP)
+      Vec4<bf16_t>::store(a.P + prow * a.ldP + key0, pd);
+      if (a.Pk) Vec4<bf16_t>::store(a.Pk + prow * a.ldP + key0, pk);
     }
   }
   // (only this wave reads its own P image; LDS ops of one wave complete in order)
@@ -175,10 +198,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
-template <int HD, int LKP>
-int launch_attn(const AttnArgs& a, int Z, hipStream_t st) {
-  constexpr int smem = 2 * LKP * HD * 2 + 4 * 16 * LKP * 2;
-  const void* fn = (const void*)attn_fwd_kernel<HD, LKP>;
+template <int HD, int LKP, int NW>
+int launch_attn_nw(const AttnArgs& a, int Z, hipStream_t st) {
+  constexpr int smem = 2 * LKP * HD * 2;
+  const void* fn = (const void*)attn_fwd_kernel<HD, LKP, NW>;
   if (smem > 64 * 1024) {
     static thread_local bool done = false;
     if (!done) {
@@ -187,8 +210,16 @@ int launch_attn(const AttnArgs& a, int Z, hipStream_t st) {
       done = true;
     }
   }
-  hipLaunchKernelGGL((attn_fwd_kernel<HD, LKP>), dim3(Z, (a.Lq + 63) / 64), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<HD, LKP, NW>), dim3(Z, (a.Lq + NW * 16 - 1) / (NW * 16)), dim3(NW * 64), smem, st, a);
   return 0;
+}
+
+template <int HD, int LKP>
+int launch_attn(const AttnArgs& a, int Z, hipStream_t st) {
+  // waves per workgroup: 8 (128 queries) for long query axes so K/V are staged once per slice
+  if (a.Lq > 64) return launch_attn_nw<HD, LKP, 8>(a, Z, st);
+  if (a.Lq > 32) return launch_attn_nw<HD, LKP, 4>(a, Z, st);
+  return launch_attn_nw<HD, LKP, 2>(a, Z, st);
 }
 
 }  // namespace

@@ -159,7 +159,7 @@ __device__ __forceinline__ void epilogue_half(const vmr_gemm_t& g, const float* 
 }
 
 // caller has passed the barrier that ends the K loop
-template <typename T, bool ALIGNED, bool FULL = false>
+template <typename T, bool ALIGNED, bool FULL = false, bool TRANSPOSED = false>
 __device__ __forceinline__ void epilogue(const vmr_gemm_t& g, float* cst, const f32x4 (&acc)[4][4], int wm, int wn,
                                          int lane, int m0, int n0, int zb, T* __restrict__ C,
                                          const T* __restrict__ Rsd, T* __restrict__ Aux) {
@@ -167,10 +167,16 @@ __device__ __forceinline__ void epilogue(const vmr_gemm_t& g, float* cst, const 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+        if (TRANSPOSED) {   // acc[i][j][r] = C[i*16 + (lane&15)][j*16 + (lane>>4)*4 + r]: one 16-byte LDS write
+          *reinterpret_cast<f32x4*>(&cst[(wm * 64 + i * 16 + (lane & 15)) * CST_LD + wn * 64 + j * 16 + (lane >> 4) * 4]) =
+              acc[i][j];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          cst[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * CST_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+          for (int r = 0; r < 4; ++r)
+            cst[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * CST_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+        }
+      }
     __syncthreads();
     epilogue_half<T, ALIGNED, 256, 128>(g, cst, m0, n0, zb, C, Rsd, Aux);
     return;
@@ -409,6 +415,60 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N == 0 || N == 4 || N == 8 || N == 16, "add the immediate");
 }
 
+// Register-direct epilogue of the LDS-DMA kernel (bf16 output, interior tiles).  The MFMAs are issued
+// with the operands swapped (C^T = W.x^T), so a lane owns FOUR CONSECUTIVE COLUMNS of one output row:
+// bias / residual / aux / C move as 8-byte accesses straight from the accumulators -- no LDS staging,
+// no workgroup barrier (a wave's stores overlap the other waves' and the co-resident workgroup's
+// MFMAs), and one dropout hash serves exactly the lane's 4 elements.
+__device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4 (&acc)[4][4], int wm, int wn, int lane,
+                                                int m0, int n0, int zb, bf16_t* __restrict__ C,
+                                                const bf16x4 (&rres)[4][4], bf16_t* __restrict__ Aux) {
+  const int flags = g.flags;
+  const int rbase = m0 + wm * 64 + (lane & 15);
+  const int cbase = n0 + wn * 64 + (lane >> 4) * 4;
+  f32x4 bias4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    bias4[j] = (flags & VMR_EPI_BIAS) ? *reinterpret_cast<const f32x4*>(g.bias + cbase + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  const uint32_t thresh = vmr_drop_thresh(g.drop_p);
+  const float dscale = (flags & VMR_EPI_DROPOUT) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+  const uint32_t seed = vmr_seed(g.drop_seed, g.drop_step);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = rbase + i * 16;
+    const float rs = (flags & VMR_EPI_ROWSCALE) ? g.rowscale[gm] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = cbase + j * 16;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = acc[i][j][e] * g.alpha + bias4[j][e];
+        if (flags & VMR_EPI_RELU) x = fmaxf(x, 0.0f);
+        v[e] = x;
+      }
+      if (flags & VMR_EPI_DROPOUT) {
+        const uint64_t idx0 = ((uint64_t)zb * g.M + gm + g.drop_row0) * (uint64_t)g.N + (uint64_t)gn;  // multiple of 4
+        const uint2 h = vmr_hash4(seed, idx0 >> 2);
+        v[0] = (h.x & 0xFFFFu) >= thresh ? v[0] * dscale : 0.f;
+        v[1] = (h.x >> 16) >= thresh ? v[1] * dscale : 0.f;
+        v[2] = (h.y & 0xFFFFu) >= thresh ? v[2] * dscale : 0.f;
+        v[3] = (h.y >> 16) >= thresh ? v[3] * dscale : 0.f;
+      }
+      if (flags & VMR_EPI_AUX) Vec4<bf16_t>::store(Aux + (int64_t)gm * g.ldr + gn, v);
+      if (flags & VMR_EPI_RESIDUAL) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rres[i][j][e];
+      }
+      if (flags & VMR_EPI_ROWSCALE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= rs;
+      }
+      Vec4<bf16_t>::store(C + (int64_t)gm * g.ldc + gn, v);
+    }
+  }
+}
+
 template <bool TA, bool TB, int BK, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -436,6 +496,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nk = k_end > k_begin ? (k_end - k_begin) / BK : 0;
+  // The residual quads of the register-direct epilogue are requested FIRST (oldest in the vmcnt
+  // order, so every counted wait below also covers them): their HBM latency hides under the whole
+  // K loop instead of being exposed once per tile.
+  bf16x4 rres[4][4];
+  const bool direct = !(g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM | VMR_EPI_SLAB));
+  if (direct && (g.flags & VMR_EPI_RESIDUAL)) {
+    const bf16_t* Rsd = reinterpret_cast<const bf16_t*>(g.residual) + coff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        rres[i][j] = *reinterpret_cast<const bf16x4*>(Rsd + (int64_t)(m0 + wm * 64 + (lane & 15) + i * 16) * g.ldr + n0 +
+                                                      wn * 64 + (lane >> 4) * 4 + j * 16);
+  }
 
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) {
@@ -455,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0);  // C^T tile
     __builtin_amdgcn_s_setprio(0);
   };
   for (int kt = 0; kt < nk; ++kt) {
@@ -487,8 +561,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
     }
   }
   if (nk > 0) mma((NKK - 1) & 1);
+  if (direct) {
+    epilogue_direct(g, acc, wm, wn, lane, m0, n0, tc.zb, reinterpret_cast<bf16_t*>(g.C) + coff, rres,
+                    reinterpret_cast<bf16_t*>(g.aux) + coff);
+    return;
+  }
   __syncthreads();
-  epilogue<bf16_t, true, true>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
+  epilogue<bf16_t, true, true, true>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
                          (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM))
                              ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
                              : reinterpret_cast<bf16_t*>(g.C) + coff,
@@ -866,7 +945,8 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   Pick pk = al ? pick_trans<true>(g.transA, g.transB, g.dtype, g_gemm_bk)
                : pick_trans<false>(g.transA, g.transB, g.dtype, g_gemm_bk);
   const bool dma_ok = g_gemm_dma && al && g.dtype == VMR_BF16 && g.M % BM == 0 && g.N % BN == 0 && g.K % 64 == 0 &&
-                      g.K >= 128 * g.splitk;
+                      g.K >= 128 * g.splitk &&
+                      (!(g.flags & VMR_EPI_BIAS) || aligned16(g.bias));   // the direct epilogue loads bias as float4
   if (dma_ok && g_gemm_dma >= 3 && g.M >= 256) {
     // 256x128 tiles for the rows that fill whole rounds of the 256 CUs; the ragged remainder (e.g. the
     // 1280 query-token rows of a packed [8192 | 1280] matrix) goes to the 128x128 kernel instead of
