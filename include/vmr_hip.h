@@ -78,6 +78,11 @@ typedef struct {
   uint32_t drop_seed;
   uint32_t drop_row0; /* added to the row index of the dropout counter (a GEMM split by rows) */
   const uint32_t* drop_step; /* nullable device counter mixed into the seed (hipGraph replay) */
+  /* second bias term: with VMR_EPI_BIAS the epilogue adds bias_scale*bias[n] + bias2[n] (bias2 nullable;
+   * bias_scale 0 is read as 1).  BiLinear (layers.py:257-263): dense_1(a)+dense_1(b)+bias_value
+   * = dense_1.W.(a+b) + 2*dense_1.bias + bias_value, fed straight from the parameter arena. */
+  const float* bias2;
+  float bias_scale;
 } vmr_gemm_t;
 
 int vmr_gemm(const vmr_gemm_t* g, void* stream);
@@ -192,10 +197,11 @@ int vmr_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t r
  *          post-dropout ReLU output, scale = 1/(1-p))
  *  mode 2: dz = dy*scale*keep(seed, r*D+c), db += colsum(dz) (dropout without ReLU; the mask
  *          is regenerated from the seed the forward GEMM epilogue used)
- * db may be NULL in modes 1/2. */
+ * db may be NULL in modes 1/2.  The column sums are ACCUMULATED: db += db_scale*colsum and, when
+ * db2 is given, db2 += colsum (the two bias terms of vmr_gemm_t.bias/bias2; db_scale 0 reads as 1). */
 int vmr_relu_bwd_bias(int mode, const void* dy, const void* h, void* dz, float* db, int64_t rows,
                       int D, int64_t ld, float scale, int dtype, float drop_p, uint32_t drop_seed,
-                      const uint32_t* drop_step, void* stream);
+                      const uint32_t* drop_step, float* db2, float db_scale, void* stream);
 /* out[i,:] = table[idx[i],:] (fp32): WordEmbedding / CharacterEmbedding lookups
  * (layers.py:42-48,66).  bwd: dtable[idx[i],:] += dout[i,:] for idx != padding_idx
  * (dtable accumulated with float atomics; the caller zeroes it). */
@@ -229,8 +235,11 @@ int vmr_splitk_reduce(const float* slab, float* dst, int nsplit, int64_t n, void
 int vmr_sumsq(const float* g, float* out /*[1], accumulated*/, int64_t n, void* stream);
 int vmr_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay, void* p_bf16,
               const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
-              float wd, int step, const float* lr_dev /*nullable: overrides lr*/,
+              float wd, int step,
               const int* step_dev /*nullable: 0-based step count on the device, overrides step*/,
+              float warmup_steps, float total_steps /* with step_dev and total_steps > 0: lr is scaled
+              by transformers' linear warm-up/decay multiplier of step_dev[0] (utils/utils.py:95-96),
+              evaluated on the device so a captured hipGraph replays the schedule */,
               int64_t n, void* stream);
 
 #ifdef __cplusplus

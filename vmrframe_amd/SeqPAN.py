@@ -228,7 +228,19 @@ class SeqPAN(nn.Module):
             out.append([f"{m}.{n}.conv1d.weight" for n in ("query", "f_key", "f_value")])
             out.append([f"{m}.{n}.conv1d.weight" for n in ("t_key", "t_value")])
             out.append([f"{m}.bilinear_{b}.dense_1.conv1d.weight" for b in (1, 2)])
+            # the biases of those grouped GEMMs, so each group is ONE view of the arena (ops.group_view)
+            out.append([f"{m}.{n}.conv1d.bias" for n in ("query", "f_key", "f_value")])
+            out.append([f"{m}.{n}.conv1d.bias" for n in ("t_key", "t_value")])
+            out.append([f"{m}.bilinear_{b}.dense_1.conv1d.bias" for b in (1, 2)])
+            out.append([f"{m}.bilinear_{b}.bias_value" for b in (1, 2)])
         return out
+
+    def _group_bias(self, names):
+        """Concatenated bias of a grouped GEMM: a zero-copy view of the flat arena when the optimizer
+        laid the group out back to back (gradients then accumulate in place), else torch.cat."""
+        ps = [self.P(n) for n in names]
+        v = ops.group_view(ps)
+        return v if v is not None else torch.cat(ps)
 
     def P(self, name):
         mod = self
@@ -290,8 +302,9 @@ class SeqPAN(nn.Module):
         n1, Xr = self._ln(X, prefix + ".layer_norm_1", 1e-6, drop=dc.next(prefix + ".ln1"), tee=True)
         nt = self._ln(X, prefix + ".layer_norm_t", 1e-6)
         qkv = ops.linear(n1, [W("query"), W("f_key"), W("f_value")],
-                         torch.cat([Bv("query"), Bv("f_key"), Bv("f_value")]), c)
-        kv = ops.linear(nt, [W("t_key"), W("t_value")], torch.cat([Bv("t_key"), Bv("t_value")]), c)
+                         self._group_bias([f"{m}.{n}.conv1d.bias" for n in ("query", "f_key", "f_value")]), c)
+        kv = ops.linear(nt, [W("t_key"), W("t_value")],
+                        self._group_bias([f"{m}.{n}.conv1d.bias" for n in ("t_key", "t_value")]), c)
         so, xo = ops.dual_attention(qkv, kv, vmask, tmask, B, T, Lq, H,
                                     [dc.next(prefix + f".attn{i}") for i in range(4)])
         sval = ops.linear(so, W("s_dense"), Bv("s_dense"), c)
@@ -303,10 +316,9 @@ class SeqPAN(nn.Module):
         bl_in = ops.linear(gated, W("guided_dense"), Bv("guided_dense"), c, residual=n1)
         # BiLinear x2: dense_1(a)+dense_1(b)+bias_value == dense_1(a+b) + 2*b1 + bias_value (:257-263)
         b1, b2 = m + ".bilinear_1", m + ".bilinear_2"
-        bias = torch.cat([2.0 * self.P(b1 + ".dense_1.conv1d.bias") + self.P(b1 + ".bias_value"),
-                          2.0 * self.P(b2 + ".dense_1.conv1d.bias") + self.P(b2 + ".bias_value")])
         sv = ops.linear(bl_in, [self.P(b1 + ".dense_1.conv1d.weight"), self.P(b2 + ".dense_1.conv1d.weight")],
-                        bias, c)
+                        self._group_bias([b1 + ".dense_1.conv1d.bias", b2 + ".dense_1.conv1d.bias"]), c,
+                        bias2=self._group_bias([b1 + ".bias_value", b2 + ".bias_value"]), bias_scale=2.0)
         out = ops.sigmoid_gate(sv, rowmask)                                     # (:380)
         o1 = self._lin(out, prefix + ".dense_1", drop=dc.next(prefix + ".d1"), residual=Xr)
         o2, o1r = self._ln(o1, prefix + ".layer_norm_2", 1e-6, drop=dc.next(prefix + ".ln2"), tee=True)

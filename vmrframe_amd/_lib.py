@@ -39,7 +39,8 @@ class GemmDesc(C.Structure):
                 ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64),
                 ("sC1", C.c_int64), ("sC2", C.c_int64),
                 ("splitk", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
-                ("drop_row0", C.c_uint32), ("drop_step", C.c_void_p)]
+                ("drop_row0", C.c_uint32), ("drop_step", C.c_void_p),
+                ("bias2", C.c_void_p), ("bias_scale", C.c_float)]
 
 
 _lib = None
@@ -61,14 +62,14 @@ SIGNATURES = {
     "vmr_soft_ce_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vmr_soft_ce_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vmr_cast": [_P, _I, _P, _I, _L, _I, _L, _L, _F, _U, _P, _P],
-    "vmr_relu_bwd_bias": [_I, _P, _P, _P, _P, _L, _I, _L, _F, _I, _F, _U, _P, _P],
+    "vmr_relu_bwd_bias": [_I, _P, _P, _P, _P, _L, _I, _L, _F, _I, _F, _U, _P, _P, _F, _P],
     "vmr_dropout_mask": [_P, _L, _F, _U, _P],
     "vmr_embedding_fwd": [_P, _P, _P, _L, _I, _L, _P],
     "vmr_embedding_bwd": [_P, _P, _P, _L, _I, _L, _L, _P],
     "vmr_eltwise": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "vmr_splitk_reduce": [_P, _P, _I, _L, _P],
     "vmr_sumsq": [_P, _P, _L, _P],
-    "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P, _P, _L, _P],
+    "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P, _F, _F, _L, _P],
 }
 
 

@@ -121,7 +121,7 @@ __device__ __forceinline__ void epilogue_half(const vmr_gemm_t& g, const float* 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float x = v[e] * g.alpha;
-      if ((flags & VMR_EPI_BIAS) && e < nvalid) x += g.bias[gn + e];
+      if ((flags & VMR_EPI_BIAS) && e < nvalid) x += g.bias_scale * g.bias[gn + e] + (g.bias2 ? g.bias2[gn + e] : 0.f);
       if (flags & VMR_EPI_RELU) x = fmaxf(x, 0.0f);
       if (flags & VMR_EPI_DROPOUT) x = ((keep >> e) & 1) ? x * dscale : 0.0f;
       v[e] = x;
@@ -429,7 +429,13 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
   f32x4 bias4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    bias4[j] = (flags & VMR_EPI_BIAS) ? *reinterpret_cast<const f32x4*>(g.bias + cbase + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    bias4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (flags & VMR_EPI_BIAS) {
+      bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + cbase + j * 16) * g.bias_scale;
+      if (g.bias2) bias4[j] += *reinterpret_cast<const f32x4*>(g.bias2 + cbase + j * 16);
+    }
+  }
   const uint32_t thresh = vmr_drop_thresh(g.drop_p);
   const float dscale = (flags & VMR_EPI_DROPOUT) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
   const uint32_t seed = vmr_seed(g.drop_seed, g.drop_step);
@@ -464,7 +470,10 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= rs;
       }
-      Vec4<bf16_t>::store(C + (int64_t)gm * g.ldc + gn, v);
+      if (flags & VMR_EPI_OUT_F32)   // fp32 result / split-K slab: one 16-byte store per quad
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (int64_t)gm * g.ldc + gn) = (f32x4){v[0], v[1], v[2], v[3]};
+      else
+        Vec4<bf16_t>::store(C + (int64_t)gm * g.ldc + gn, v);
     }
   }
 }
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
   // order, so every counted wait below also covers them): their HBM latency hides under the whole
   // K loop instead of being exposed once per tile.
   bf16x4 rres[4][4];
-  const bool direct = !(g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM | VMR_EPI_SLAB));
+  const bool direct = !(g.flags & VMR_EPI_ACCUM);   // atomics keep the LDS-staged, 256-B-per-wave shape
   if (direct && (g.flags & VMR_EPI_RESIDUAL)) {
     const bf16_t* Rsd = reinterpret_cast<const bf16_t*>(g.residual) + coff;
 #pragma unroll
@@ -562,8 +571,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
   }
   if (nk > 0) mma((NKK - 1) & 1);
   if (direct) {
-    epilogue_direct(g, acc, wm, wn, lane, m0, n0, tc.zb, reinterpret_cast<bf16_t*>(g.C) + coff, rres,
-                    reinterpret_cast<bf16_t*>(g.aux) + coff);
+    epilogue_direct(g, acc, wm, wn, lane, m0, n0, tc.zb,
+                    (g.flags & VMR_EPI_OUT_F32) ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
+                                                : reinterpret_cast<bf16_t*>(g.C) + coff,
+                    rres, reinterpret_cast<bf16_t*>(g.aux) + coff);
     return;
   }
   __syncthreads();
@@ -912,6 +923,7 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   VMR_CHECK(g.splitk == 1 || (g.flags & (VMR_EPI_ACCUM | VMR_EPI_SLAB)), "vmr_gemm: splitk>1 needs VMR_EPI_ACCUM or VMR_EPI_SLAB");
   if (g.flags & VMR_EPI_SLAB) g.flags |= VMR_EPI_OUT_F32;
   VMR_CHECK(!(g.flags & VMR_EPI_BIAS) || g.bias, "vmr_gemm: bias flag without pointer");
+  if (g.bias_scale == 0.f) g.bias_scale = 1.f;
   VMR_CHECK(!(g.flags & VMR_EPI_RESIDUAL) || g.residual, "vmr_gemm: residual flag without pointer");
   VMR_CHECK(!(g.flags & VMR_EPI_AUX) || g.aux, "vmr_gemm: aux flag without pointer");
   VMR_CHECK(!(g.flags & VMR_EPI_ROWSCALE) || g.rowscale, "vmr_gemm: rowscale flag without pointer");
@@ -946,7 +958,7 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
                : pick_trans<false>(g.transA, g.transB, g.dtype, g_gemm_bk);
   const bool dma_ok = g_gemm_dma && al && g.dtype == VMR_BF16 && g.M % BM == 0 && g.N % BN == 0 && g.K % 64 == 0 &&
                       g.K >= 128 * g.splitk &&
-                      (!(g.flags & VMR_EPI_BIAS) || aligned16(g.bias));   // the direct epilogue loads bias as float4
+                      (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));   // the direct epilogue loads bias as float4
   if (dma_ok && g_gemm_dma >= 3 && g.M >= 256) {
     // 256x128 tiles for the rows that fill whole rounds of the 256 CUs; the ragged remainder (e.g. the
     // 1280 query-token rows of a packed [8192 | 1280] matrix) goes to the 128x128 kernel instead of

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const T* __restrict_
                                                             T* __restrict__ dz, float* __restrict__ db, int64_t rows,
                                                             int D, int64_t ld, float scale, int rows_per_block,
                                                             float drop_p, uint32_t seed0,
-                                                            const uint32_t* __restrict__ step) {
+                                                            const uint32_t* __restrict__ step,
+                                                            float* __restrict__ db2, float db_scale) {
   __shared__ float red[8][256];
   const uint32_t seed = vmr_seed(seed0, step);
   const uint32_t thresh = vmr_drop_thresh(drop_p);
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const T* __restrict_
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
-    atomicAdd(&db[c], s);
+    atomicAdd(&db[c], s * db_scale);
+    if (db2) atomicAdd(&db2[c], s);
   }
 }
 
@@ -192,13 +194,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     const uint8_t* __restrict__ decay, bf16_t* __restrict__ pb,
                                                     const float* __restrict__ gnorm_sq, float max_norm, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1,
-                                                    float bc2, const float* __restrict__ lr_dev,
-                                                    const int* __restrict__ step_dev, int64_t n) {
-  if (lr_dev) lr = lr_dev[0];                 // device-resident schedule: a captured hipGraph replays
-  if (step_dev) {                             // with the current lr / bias corrections
-    const float t = (float)(step_dev[0] + 1);
+                                                    float bc2, const int* __restrict__ step_dev,
+                                                    float warmup_steps, float total_steps, int64_t n) {
+  if (step_dev) {   // device-resident step: a captured hipGraph replays with the current lr / bias corrections
+    const float s = (float)step_dev[0];
+    const float t = s + 1.f;
     bc1 = 1.f - powf(beta1, t);
     bc2 = 1.f - powf(beta2, t);
+    if (total_steps > 0.f)
+      lr *= s < warmup_steps ? s / fmaxf(1.f, warmup_steps)
+                             : fmaxf(0.f, total_steps - s) / fmaxf(1.f, total_steps - warmup_steps);
   }
   float clip = 1.f;
   if (gnorm_sq && max_norm > 0.f) {
@@ -251,22 +256,24 @@ extern "C" int vmr_cast(const void* src, int src_dtype, void* dst, int dst_dtype
 template <typename T>
 static void launch_rbb(int mode, dim3 grid, hipStream_t st, const void* dy, const void* h, void* dz, float* db,
                        int64_t rows, int D, int64_t ld, float scale, int rpb, float drop_p, uint32_t seed,
-                       const uint32_t* step) {
+                       const uint32_t* step, float* db2, float db_scale) {
   if (mode == 0)
     hipLaunchKernelGGL((relu_bwd_bias_kernel<T, 0>), grid, dim3(256), 0, st, (const T*)dy, (const T*)h, (T*)dz, db, rows,
-                       D, ld, scale, rpb, drop_p, seed, step);
+                       D, ld, scale, rpb, drop_p, seed, step, db2, db_scale);
   else if (mode == 1)
     hipLaunchKernelGGL((relu_bwd_bias_kernel<T, 1>), grid, dim3(256), 0, st, (const T*)dy, (const T*)h, (T*)dz, db, rows,
-                       D, ld, scale, rpb, drop_p, seed, step);
+                       D, ld, scale, rpb, drop_p, seed, step, db2, db_scale);
   else
     hipLaunchKernelGGL((relu_bwd_bias_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)dy, (const T*)h, (T*)dz, db, rows,
-                       D, ld, scale, rpb, drop_p, seed, step);
+                       D, ld, scale, rpb, drop_p, seed, step, db2, db_scale);
 }
 
 extern "C" int vmr_relu_bwd_bias(int mode, const void* dy, const void* h, void* dz, float* db, int64_t rows, int D,
                                  int64_t ld, float scale, int dtype, float drop_p, uint32_t drop_seed,
-                                 const uint32_t* drop_step, void* stream) {
+                                 const uint32_t* drop_step, float* db2, float db_scale, void* stream) {
   VMR_CHECK(mode >= 0 && mode <= 2, "vmr_relu_bwd_bias: bad mode %d", mode);
+  VMR_CHECK(!db2 || db, "vmr_relu_bwd_bias: db2 without db");
+  if (db_scale == 0.f) db_scale = 1.f;
   VMR_CHECK(dy && (db || mode != 0), "vmr_relu_bwd_bias: null pointer");
   VMR_CHECK(D % 8 == 0 && ld % 8 == 0, "vmr_relu_bwd_bias: D and ld must be multiples of 8 (D=%d)", D);
   VMR_CHECK(mode != 1 || h, "vmr_relu_bwd_bias: mode 1 needs h");
@@ -278,10 +285,10 @@ extern "C" int vmr_relu_bwd_bias(int mode, const void* dy, const void* h, void* 
   gy = (int)((rows + rpb - 1) / rpb);
   if (dtype == VMR_BF16)
     launch_rbb<bf16_t>(mode, dim3(gx, gy), (hipStream_t)stream, dy, h, dz, db, rows, D, ld, scale, rpb, drop_p,
-                       drop_seed, drop_step);
+                       drop_seed, drop_step, db2, db_scale);
   else
     launch_rbb<float>(mode, dim3(gx, gy), (hipStream_t)stream, dy, h, dz, db, rows, D, ld, scale, rpb, drop_p,
-                      drop_seed, drop_step);
+                      drop_seed, drop_step, db2, db_scale);
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -327,14 +334,15 @@ extern "C" int vmr_sumsq(const float* g, float* out, int64_t n, void* stream) {
 
 extern "C" int vmr_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay, void* p_bf16,
                          const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
-                         float wd, int step, const float* lr_dev, const int* step_dev, int64_t n, void* stream) {
+                         float wd, int step, const int* step_dev, float warmup_steps, float total_steps, int64_t n,
+                         void* stream) {
   VMR_CHECK(p && g && m && v && decay, "vmr_adamw: null pointer");
   VMR_CHECK(step >= 1 || step_dev, "vmr_adamw: step starts at 1");
   if (n == 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3((int)min((int64_t)4096, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     p, g, m, v, decay, (bf16_t*)p_bf16, gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, lr_dev,
-                     step_dev, n);
+                     p, g, m, v, decay, (bf16_t*)p_bf16, gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, step_dev,
+                     warmup_steps, total_steps, n);
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -60,7 +60,8 @@ class DropCtx:
 # raw GEMM launch
 # ---------------------------------------------------------------------------
 def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=None, residual=None, aux=None,
-         ldr=0, rowscale=None, alpha=1.0, Z1=1, Z2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, drop=NO_DROP):
+         ldr=0, rowscale=None, alpha=1.0, Z1=1, Z2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, drop=NO_DROP,
+         bias2=None, bias_scale=1.0):
     d = L.GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cmat.data_ptr()
     d.bias, d.residual, d.aux, d.rowscale = _ptr(bias), _ptr(residual), _ptr(aux), _ptr(rowscale)
@@ -74,6 +75,7 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
     d.splitk = splitk
     d.drop_p, d.drop_seed = drop[0], drop[1]
     d.drop_step = _ptr(drop[2])
+    d.bias2, d.bias_scale = _ptr(bias2), bias_scale
     if GEMM_HOOK is not None:
         GEMM_HOOK(lambda: L.check(L.lib().vmr_gemm(C.byref(d), L.stream_ptr()), "vmr_gemm"), M, N, K, ta, tb,
                   Z1 * Z2, dtype)
@@ -254,7 +256,7 @@ class _Linear(torch.autograd.Function):
     the compute-dtype copy comes from the WeightCache."""
 
     @staticmethod
-    def forward(ctx, x, bias, residual, cache, relu, drop, rowscale, *weights):
+    def forward(ctx, x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, *weights):
         L.require_gpu(x)
         assert x.dim() == 2 and x.stride(1) == 1
         W = cache.get(weights, x.dtype)
@@ -282,11 +284,13 @@ class _Linear(torch.autograd.Function):
         if rowscale is not None:
             flags |= L.EPI_ROWSCALE
         gemm(x, W, ybuf, M, N, Kp, 0, 0, x.stride(0), W.stride(0), Np, dtype=dt, flags=flags, bias=bias,
-             residual=residual, aux=aux, ldr=N, rowscale=rowscale, drop=drop)
+             residual=residual, aux=aux, ldr=N, rowscale=rowscale, drop=drop, bias2=bias2, bias_scale=bias_scale)
         ctx.save_for_backward(x, W, aux if aux is not None else (ybuf if relu else None), rowscale)
         ctx.meta = (relu, drop, bias is not None, residual is not None, [tuple(w.shape) for w in weights])
         ctx.weights = weights
         ctx.bias_param = bias
+        ctx.bias2_param, ctx.bias_scale = bias2, bias_scale
+        assert bias2 is None or (bias is not None and Np == N)
         return y
 
     @staticmethod
@@ -310,21 +314,26 @@ class _Linear(torch.autograd.Function):
         lib, st = L.lib(), L.stream_ptr()
         scale = 1.0 / (1.0 - drop[0]) if drop[0] > 0 else 1.0
         bgrad = main_grad(ctx.bias_param) if (has_bias and Np == N) else None
+        has_b2 = ctx.bias2_param is not None
+        if has_b2 and (bgrad is None or main_grad(ctx.bias2_param) is None):
+            bgrad = None                      # both bias terms go through autograd or neither
         db = (bgrad if bgrad is not None else torch.zeros(Np, device=dy.device, dtype=torch.float32)) \
             if has_bias else None
+        db2 = main_grad(ctx.bias2_param) if (has_b2 and bgrad is not None) else None
+        dbs = ctx.bias_scale if bgrad is not None else 1.0   # (autograd path: scaled below)
         if relu:
             dzb = torch.empty_like(dyb)
             L.check(lib.vmr_relu_bwd_bias(1, dyb.data_ptr(), h.data_ptr(), dzb.data_ptr(), _ptr(db), M, Np, Np, scale,
-                                          dt, 0.0, 0, None, st), "vmr_relu_bwd_bias")
+                                          dt, 0.0, 0, None, _ptr(db2), dbs, st), "vmr_relu_bwd_bias")
         elif drop[0] > 0:
             dzb = torch.empty_like(dyb)
             L.check(lib.vmr_relu_bwd_bias(2, dyb.data_ptr(), None, dzb.data_ptr(), _ptr(db), M, Np, Np, scale, dt,
-                                          drop[0], drop[1], _ptr(drop[2]), st), "vmr_relu_bwd_bias")
+                                          drop[0], drop[1], _ptr(drop[2]), _ptr(db2), dbs, st), "vmr_relu_bwd_bias")
         else:
             dzb = dyb
             if has_bias:
                 L.check(lib.vmr_relu_bwd_bias(0, dyb.data_ptr(), None, None, db.data_ptr(), M, Np, Np, 1.0, dt, 0.0, 0,
-                                              None, st), "vmr_relu_bwd_bias")
+                                              None, _ptr(db2), dbs, st), "vmr_relu_bwd_bias")
         dz = dzb[:, :N] if Np != N else dzb
         dx = None
         if ctx.needs_input_grad[0]:
@@ -359,7 +368,8 @@ class _Linear(torch.autograd.Function):
                     r += n
             if db is not None and Np != N:
                 db = db[:N]
-            return (dx, None if bgrad is not None else db, dres, None, None, None, None, *([None] * len(wshapes)))
+            return (dx, *_bias_grads(db, bgrad, has_b2, ctx.bias_scale), None, dres, None, None, None, None,
+                    *([None] * len(wshapes)))
         if sk > 1:
             dW = torch.zeros(N, Kp, device=dy.device, dtype=torch.float32)
             gemm(dz, x, dW, N, Kp, M, 1, 1, dz.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_ACCUM, splitk=sk)
@@ -376,13 +386,40 @@ class _Linear(torch.autograd.Function):
             r += n
         if db is not None and Np != N:
             db = db[:N]
-        return (dx, None if bgrad is not None else db, dres, None, None, None, None, *grads)
+        return (dx, *_bias_grads(db, bgrad, has_b2, ctx.bias_scale), None, dres, None, None, None, None, *grads)
 
 
-def linear(x, weights, bias, cache, *, relu=False, drop=NO_DROP, residual=None, rowscale=None):
+def _bias_grads(db, bgrad, has_b2, bias_scale):
+    """(d bias, d bias2) handed back to autograd: nothing when the kernel accumulated into the arena."""
+    if db is None or bgrad is not None:
+        return None, None
+    return (db * bias_scale if has_b2 else db), (db if has_b2 else None)
+
+
+def linear(x, weights, bias, cache, *, relu=False, drop=NO_DROP, residual=None, rowscale=None, bias2=None,
+           bias_scale=1.0):
+    """y = drop(act(x.W^T + bias_scale*bias + bias2)) + residual."""
     if isinstance(weights, torch.Tensor):
         weights = [weights]
-    return _Linear.apply(x, bias, residual, cache, relu, drop, rowscale, *weights)
+    return _Linear.apply(x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, *weights)
+
+
+def group_view(params):
+    """ONE flat fp32 view over parameters laid out back to back in the flat arena (optim.FlatArena
+    places the members of model.weight_groups() consecutively), carrying the matching view of the
+    gradient arena so bias-gradient kernels accumulate in place.  None if the parameters are not
+    contiguous (no arena yet): callers fall back to torch.cat."""
+    grads = [main_grad(p) for p in params]
+    if any(g is None for g in grads):
+        return None
+    for seq in (params, grads):
+        for a_, b_ in zip(seq[:-1], seq[1:]):
+            if a_.data_ptr() + a_.numel() * 4 != b_.data_ptr():
+                return None
+    n = sum(p.numel() for p in params)
+    v = torch.as_strided(params[0].detach(), (n,), (1,))
+    v._vmr_main_grad = torch.as_strided(grads[0], (n,), (1,))
+    return v
 
 
 # ---------------------------------------------------------------------------
@@ -753,7 +790,7 @@ class _Dropout(torch.autograd.Function):
         dx = torch.empty_like(dy)
         L.check(L.lib().vmr_relu_bwd_bias(2, dy.data_ptr(), None, dx.data_ptr(), None, rows, D, D,
                                           1.0 / (1.0 - drop[0]), L.dtype_code(dy), drop[0], drop[1], _ptr(drop[2]),
-                                          L.stream_ptr()), "vmr_relu_bwd_bias")
+                                          None, 1.0, L.stream_ptr()), "vmr_relu_bwd_bias")
         return dx, None
 
 

@@ -83,7 +83,7 @@ class FlatAdamW:
         self.arena = None
         self.m = self.v = self.gnorm_sq = None
         self.warmup_steps, self.total_steps = float(warmup_steps), int(total_steps)
-        self.step_t = self.lr_t = None   # device-resident step / lr (hipGraph-replayable schedule)
+        self.step_t = None   # device-resident step count: the kernel evaluates the lr schedule from it
 
     # -- arena -----------------------------------------------------------------
     def _build(self):
@@ -94,18 +94,6 @@ class FlatAdamW:
         dev = self.arena.flat_p.device
         self.gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.step_t = torch.full((1,), self.t, device=dev, dtype=torch.int32)
-        self.lr_t = torch.zeros(1, device=dev, dtype=torch.float32)
-
-    def _device_lr(self):
-        """lr_t = base_lr * linear-warmup(step_t), computed on the device (no host read)."""
-        s = self.step_t.float()
-        if self.total_steps <= 0:
-            f = torch.ones_like(s)
-        else:
-            warm = s / max(1.0, self.warmup_steps)
-            decay = (self.total_steps - s).clamp_min(0.0) / max(1.0, self.total_steps - self.warmup_steps)
-            f = torch.where(s < self.warmup_steps, warm, decay)
-        self.lr_t.copy_(f * self.base_lr)
 
     @property
     def grad_arena(self):
@@ -137,12 +125,11 @@ class FlatAdamW:
         self.gnorm_sq.zero_()
         n = A.flat_p.numel()
         L.check(lib.vmr_sumsq(A.flat_g.data_ptr(), self.gnorm_sq.data_ptr(), n, st), "vmr_sumsq")
-        self._device_lr()
         L.check(lib.vmr_adamw(A.flat_p.data_ptr(), A.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                               A.decay.data_ptr(), None if A.flat_w is None else A.flat_w.data_ptr(),
-                              self.gnorm_sq.data_ptr(), self.max_norm, 0.0,
-                              self.betas[0], self.betas[1], self.eps, self.wd, 0, self.lr_t.data_ptr(),
-                              self.step_t.data_ptr(), n, st), "vmr_adamw")
+                              self.gnorm_sq.data_ptr(), self.max_norm, self.base_lr,
+                              self.betas[0], self.betas[1], self.eps, self.wd, 0, self.step_t.data_ptr(),
+                              self.warmup_steps, float(self.total_steps), n, st), "vmr_adamw")
         self.step_t += 1             # scheduler.step() of the reference loop
         self.t += 1
         if hasattr(self.model, "_cache"):   # the masters changed under the compute-dtype weight cache
