@@ -83,6 +83,10 @@ typedef struct {
    * = dense_1.W.(a+b) + 2*dense_1.bias + bias_value, fed straight from the parameter arena. */
   const float* bias2;
   float bias_scale;
+  /* residual row broadcast: with res_div > 1 row m adds residual[(m / res_div)*ldr + n], i.e. one
+   * residual row per group of res_div consecutive rows (a per-clip term added to all T tokens of the
+   * clip: the pooled-query half of CQConcatenate, layers.py:462-468, without materialising the cat). */
+  int32_t res_div;
 } vmr_gemm_t;
 
 int vmr_gemm(const vmr_gemm_t* g, void* stream);
@@ -223,9 +227,21 @@ int vmr_dropout_mask(float* m, int64_t n, float drop_p, uint32_t seed, void* str
 int vmr_eltwise(int op, const void* a, const void* b, const void* c, const void* d, const void* e,
                 const float* rowmask, void* o0, void* o1, void* o2, void* o3, int64_t rows, int D,
                 int dtype, void* stream);
-/* dst[i] += sum_k slab[k*n + i] (fp32): second stage of a split-K GEMM whose splits were
- * written as plain slabs (VMR_EPI_SLAB) instead of float atomics. */
-int vmr_splitk_reduce(const float* slab, float* dst, int nsplit, int64_t n, void* stream);
+/* dst += sum_k slab[k] (fp32): second stage of a split-K GEMM whose splits were written as plain
+ * slabs (VMR_EPI_SLAB) instead of float atomics.  slab: [nsplit][n] contiguous; dst: n elements,
+ * contiguous when cols == 0, else rows of `cols` elements with leading dimension ld_dst (the
+ * gradient of a column slice of a weight matrix inside the arena). */
+int vmr_splitk_reduce(const float* slab, float* dst, int nsplit, int64_t n, int cols, int64_t ld_dst,
+                      void* stream);
+
+/* ------------------------------------------------------------ WeightedPool
+ * reference models/layers.py:440-453: alpha = softmax_l(x[b,l,:].w + (1-mask[b,l])*-1e30),
+ * pooled[b,:] = sum_l alpha[b,l]*x[b,l,:].  x: [B,L,D] dtype; w, mask, alpha fp32; pooled [B,D] dtype.
+ * bwd: dx [B,L,D]; dw[D] is ACCUMULATED (float atomics). */
+int vmr_weighted_pool_fwd(const void* x, const float* w, const float* mask, float* alpha, void* pooled,
+                          int B, int L, int D, int dtype, void* stream);
+int vmr_weighted_pool_bwd(const void* dpooled, const void* x, const float* w, const float* alpha,
+                          void* dx, float* dw, int B, int L, int D, int dtype, void* stream);
 
 /* --------------------------------------------------------------- optimizer
  * fused AdamW over a flat fp32 parameter arena (utils/utils.py:87-97:

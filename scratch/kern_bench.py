@@ -33,9 +33,9 @@ def dwb():
     lib.vmr_dwconv_bwd(dy[8192:].data_ptr(),x[8192:].data_ptr(),g.data_ptr(),b.data_ptr(),mean[8192:].data_ptr(),rstd[8192:].data_ptr(),w.data_ptr(),dx[8192:].data_ptr(),dw.data_ptr(),ws.data_ptr(),64,20,D,1,st())
 timeit("dwconv_bwd (v+t)", dwb, 3*N*D*2)
 h=torch.randn(N,D,device=dev).to(dt)
-timeit("relu_bwd_bias mode0", lambda: lib.vmr_relu_bwd_bias(0,dy.data_ptr(),None,None,db.data_ptr(),N,D,D,1.0,1,0.0,0,None,st()), N*D*2)
-timeit("relu_bwd_bias mode1", lambda: lib.vmr_relu_bwd_bias(1,dy.data_ptr(),h.data_ptr(),dx.data_ptr(),db.data_ptr(),N,D,D,1.25,1,0.0,0,None,st()), 3*N*D*2)
-timeit("relu_bwd_bias mode2", lambda: lib.vmr_relu_bwd_bias(2,dy.data_ptr(),None,dx.data_ptr(),db.data_ptr(),N,D,D,1.25,1,0.2,5,None,st()), 2*N*D*2)
+timeit("relu_bwd_bias mode0", lambda: lib.vmr_relu_bwd_bias(0,dy.data_ptr(),None,None,db.data_ptr(),N,D,D,1.0,1,0.0,0,None,None,1.0,st()), N*D*2)
+timeit("relu_bwd_bias mode1", lambda: lib.vmr_relu_bwd_bias(1,dy.data_ptr(),h.data_ptr(),dx.data_ptr(),db.data_ptr(),N,D,D,1.25,1,0.0,0,None,None,1.0,st()), 3*N*D*2)
+timeit("relu_bwd_bias mode2", lambda: lib.vmr_relu_bwd_bias(2,dy.data_ptr(),None,dx.data_ptr(),db.data_ptr(),N,D,D,1.25,1,0.2,5,None,None,1.0,st()), 2*N*D*2)
 B,H,T=64,4,128
 S=torch.randn(B,H,T,T,device=dev); P=torch.empty(B,H,T,T,device=dev,dtype=dt); Pk=torch.empty_like(P); vm=torch.ones(B,T,device=dev)
 timeit("softmax_fwd self (no drop)", lambda: lib.vmr_softmax_fwd(S.data_ptr(),P.data_ptr(),None,vm.data_ptr(),vm.data_ptr(),0,B*H,H,T,T,T,T,0,0.0625,1,0.0,0,None,st()), B*H*T*T*6)
@@ -44,4 +44,4 @@ dS=torch.empty_like(P)
 timeit("softmax_bwd self (drop)", lambda: lib.vmr_softmax_bwd(S.data_ptr(),Pk.data_ptr(),dS.data_ptr(),B*H,T,T,T,T,0.0625,1,0.2,7,None,st()), B*H*T*T*8)
 pm=torch.zeros(65_000_000,device=dev); gg=torch.randn_like(pm); m1=torch.zeros_like(pm); v1=torch.zeros_like(pm); dec=torch.ones(pm.numel(),device=dev,dtype=torch.uint8); gs=torch.zeros(1,device=dev)
 timeit("sumsq 65M", lambda: lib.vmr_sumsq(gg.data_ptr(),gs.data_ptr(),pm.numel(),st()), pm.numel()*4, iters=5)
-timeit("adamw 65M", lambda: lib.vmr_adamw(pm.data_ptr(),gg.data_ptr(),m1.data_ptr(),v1.data_ptr(),dec.data_ptr(),None,gs.data_ptr(),1.0,1e-4,0.9,0.999,1e-8,0.01,1,None,None,pm.numel(),st()), pm.numel()*(7*4+1), iters=5)
+timeit("adamw 65M", lambda: lib.vmr_adamw(pm.data_ptr(),gg.data_ptr(),m1.data_ptr(),v1.data_ptr(),dec.data_ptr(),None,gs.data_ptr(),1.0,1e-4,0.9,0.999,1e-8,0.01,1,None,0.0,0.0,pm.numel(),st()), pm.numel()*(7*4+1), iters=5)

@@ -327,6 +327,57 @@ def test_fused_attention_rejects_unsupported_shapes(dev):
     assert lib.vmr_attention_fwd_supported(256, 20, 0) == 0   # fp32 goes through the composed path
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dims", [(5, 20, 64), (3, 1, 8), (2, 300, 1024)])
+def test_weighted_pool_fwd_bwd(dev, dt, tol, dims):
+    """vmr_weighted_pool_fwd/bwd against the reference formulation (models/layers.py:440-453)."""
+    ops = _ops()
+    B, Ls, D = dims
+    torch.manual_seed(17)
+    x = torch.randn(B, Ls, D, device=dev).to(dt).requires_grad_(True)
+    w = (torch.randn(D, 1, device=dev) / math.sqrt(D)).requires_grad_(True)
+    lens = torch.randint(1, Ls + 1, (B,), device=dev); lens[0] = Ls
+    mask = (torch.arange(Ls, device=dev)[None] < lens[:, None]).float()
+    out = ops.weighted_pool(x, w, mask)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().clone().requires_grad_(True)
+    alpha = torch.softmax(torch.tensordot(xr, wr, dims=1) + (1.0 - mask.unsqueeze(2)) * -1e30, dim=1)
+    ref = torch.matmul(xr.transpose(1, 2), alpha).squeeze(2)
+    _close(out, ref, tol, "pooled")
+    g = torch.randn_like(ref)
+    gx, gw = torch.autograd.grad(out, [x, w], g.to(dt))
+    rx, rw = torch.autograd.grad(ref, [xr, wr], g.to(dt).float())
+    _close(gx, rx, tol, "dx"); _close(gw, rw, tol, "dw")
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+def test_linear_column_slices_and_row_broadcast_residual(dev, dt, tol):
+    """Conv1D(cat([a, pooled.expand], -1)) (reference CQConcatenate, layers.py:462-468) as two GEMMs on
+    column slices of the one weight, the pooled half broadcast over each clip's rows by the epilogue."""
+    ops = _ops()
+    torch.manual_seed(19)
+    B, T, D, N = 3, 128, 256, 128
+    cache = ops.WeightCache()
+    a = torch.randn(B * T, D, device=dev).to(dt).requires_grad_(True)
+    pooled = torch.randn(B, D, device=dev).to(dt).requires_grad_(True)
+    W = (torch.randn(N, 2 * D, 1, device=dev) / math.sqrt(2 * D)).requires_grad_(True)
+    bias = torch.randn(N, device=dev, requires_grad=True)
+    pq = ops.linear(pooled, W, bias, cache, kslice=(D, 2 * D))
+    y = ops.linear(a, W, None, cache, kslice=(0, D), residual=pq, res_div=T)
+    ar, pr = a.detach().float().requires_grad_(True), pooled.detach().float().requires_grad_(True)
+    Wr, br = W.detach().clone().requires_grad_(True), bias.detach().clone().requires_grad_(True)
+    cat = torch.cat([ar.view(B, T, D), pr[:, None, :].expand(B, T, D)], 2).reshape(B * T, 2 * D)
+    Wm = Wr.view(N, 2 * D)
+    if dt == torch.bfloat16:
+        Wm = Wm + (Wm.to(dt).float() - Wm).detach()
+    ref = cat @ Wm.t() + br
+    _close(y, ref, tol, "y")
+    g = torch.randn_like(ref)
+    ga, gp, gW, gb = torch.autograd.grad(y, [a, pooled, W, bias], g.to(dt))
+    ra, rp, rW, rb = torch.autograd.grad(ref, [ar, pr, Wr, br], g.to(dt).float())
+    _close(ga, ra, tol, "da"); _close(gp, rp, tol, "dpooled"); _close(gW, rW, tol, "dW"); _close(gb, rb, tol, "db")
+
+
 def test_soft_ce_matches_torch(dev):
     ops = _ops()
     torch.manual_seed(6)

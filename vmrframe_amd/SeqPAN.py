@@ -252,6 +252,13 @@ class SeqPAN(nn.Module):
     def _lin(self, x, prefix, **kw):
         return ops.linear(x, self.P(prefix + ".conv1d.weight"), self.P(prefix + ".conv1d.bias"), self._cache, **kw)
 
+    def _lin_cat2(self, a, b, prefix):
+        """Conv1D(cat([a, b], 1)) without the concat: a.W[:, :D]^T + b.W[:, D:]^T + bias."""
+        W, bias = self.P(prefix + ".conv1d.weight"), self.P(prefix + ".conv1d.bias")
+        D = a.shape[1]
+        first = ops.linear(a, W, bias, self._cache, kslice=(0, D))
+        return ops.linear(b, W, None, self._cache, kslice=(D, D + b.shape[1]), residual=first)
+
     def _ln(self, x, prefix, eps, **kw):
         return ops.layer_norm(x, self.P(prefix + ".weight"), self.P(prefix + ".bias"), eps, self._cache, **kw)
 
@@ -401,11 +408,13 @@ class SeqPAN(nn.Module):
         t2v = self._cq_attention("q2v_attn", V3, T3, vmask, tmask, dc)            # [Nv, D]
         v2t = self._cq_attention("v2q_attn", T3, V3, tmask, vmask, dc)            # [Nt, D]
         # CQConcatenate (reference layers.py:462-468)
-        v2t3 = v2t.view(B, Lq, D).float()
-        alpha = torch.softmax(v2t3 @ self.P("cq_cat.weighted_pool.weight") + NEG * (1.0 - tmask[:, :, None]), dim=1)
-        pooled = (v2t3 * alpha).sum(1).to(cdt)                                    # [B, D]
-        cat2 = torch.cat([t2v.view(B, T, D), pooled[:, None, :].expand(B, T, D)], dim=2).reshape(Nv, 2 * D)
-        fuse = self._lin(cat2, "cq_cat.conv1d")
+        # conv1d([context | pooled_query]) = context.W[:, :D]^T + (pooled.W[:, D:]^T + b)[clip]: the
+        # [Nv, 2D] concat is never built -- the pooled half is a tiny [B, D] GEMM whose rows the main GEMM's
+        # epilogue broadcasts over the T tokens of each clip (res_div), halving that GEMM's K
+        pooled = ops.weighted_pool(v2t.view(B, Lq, D), self.P("cq_cat.weighted_pool.weight"), tmask)   # [B, D]
+        Wc, bc = self.P("cq_cat.conv1d.conv1d.weight"), self.P("cq_cat.conv1d.conv1d.bias")
+        pq = ops.linear(pooled, Wc, bc, self._cache, kslice=(D, 2 * D))           # [B, D]
+        fuse = ops.linear(t2v, Wc, None, self._cache, kslice=(0, D), residual=pq, res_div=T)
         # match head (reference models/SeqPAN.py:78-82)
         mlogits = self._lin(fuse, "match_conv1d").float().reshape(B, T, 4)
         if self.gumbel_override is not None:
@@ -422,8 +431,10 @@ class SeqPAN(nn.Module):
         efeat = self._predict_encoder(sfeat, vmask, B, T, dc, "pred.e")
         sn = self._ln(sfeat, "predictor.start_layer_norm", 1e-6)
         en = self._ln(efeat, "predictor.end_layer_norm", 1e-6)
-        sh = self._lin(torch.cat([sn, fuse2], 1), "predictor.start_hidden")
-        eh = self._lin(torch.cat([en, fuse2], 1), "predictor.end_hidden")
+        # start/end_hidden(cat[features, fuse2]) as two K=D GEMMs on column slices of the weight (the second
+        # accumulates through the residual input): no [Nv, 2D] concat copies
+        sh = self._lin_cat2(sn, fuse2, "predictor.start_hidden")
+        eh = self._lin_cat2(en, fuse2, "predictor.end_hidden")
         slogits = self._lin(sh, "predictor.start_dense").float().reshape(B, T)
         elogits = self._lin(eh, "predictor.end_dense").float().reshape(B, T)
         self.last_drop_sites = dc.sites

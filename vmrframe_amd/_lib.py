@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
                 ("sC1", C.c_int64), ("sC2", C.c_int64),
                 ("splitk", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
                 ("drop_row0", C.c_uint32), ("drop_step", C.c_void_p),
-                ("bias2", C.c_void_p), ("bias_scale", C.c_float)]
+                ("bias2", C.c_void_p), ("bias_scale", C.c_float), ("res_div", C.c_int32)]
 
 
 _lib = None
@@ -57,6 +57,8 @@ SIGNATURES = {
     "vmr_softmax_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _U, _P, _P],
     "vmr_attention_fwd_supported": [_I, _I, _I],
     "vmr_attention_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _F, _U, _P, _P],
+    "vmr_weighted_pool_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vmr_weighted_pool_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vmr_cq_softmax_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_cq_softmax_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_soft_ce_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
@@ -67,7 +69,7 @@ SIGNATURES = {
     "vmr_embedding_fwd": [_P, _P, _P, _L, _I, _L, _P],
     "vmr_embedding_bwd": [_P, _P, _P, _L, _I, _L, _L, _P],
     "vmr_eltwise": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
-    "vmr_splitk_reduce": [_P, _P, _I, _L, _P],
+    "vmr_splitk_reduce": [_P, _P, _I, _L, _I, _L, _P],
     "vmr_sumsq": [_P, _P, _L, _P],
     "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P, _F, _F, _L, _P],
 }

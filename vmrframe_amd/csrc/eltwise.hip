@@ -83,18 +83,21 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const T* __restrict__ a, c
   }
 }
 
-// dst[i] += sum_k slab[k][i]   (split-K second stage: fp32, 16-byte accesses)
+// dst[i] += sum_k slab[k][i]   (split-K second stage: fp32, 16-byte accesses); dst rows of cols4
+// quads with leading dimension ld4 (quads)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dst,
-                                                            int nsplit, int64_t n4, int64_t stride4) {
+                                                            int nsplit, int64_t n4, int64_t stride4, int cols4,
+                                                            int64_t ld4) {
   const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
   f32x4* d4 = reinterpret_cast<f32x4*>(dst);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 acc = d4[i];
+    const int64_t o = cols4 ? (i / cols4) * ld4 + (i % cols4) : i;
+    f32x4 acc = d4[o];
     for (int k = 0; k < nsplit; ++k) {
       const f32x4 v = s4[k * stride4 + i];
       acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
     }
-    d4[i] = acc;
+    d4[o] = acc;
   }
 }
 
@@ -133,13 +136,17 @@ extern "C" int vmr_eltwise(int op, const void* a, const void* b, const void* c, 
   return 0;
 }
 
-extern "C" int vmr_splitk_reduce(const float* slab, float* dst, int nsplit, int64_t n, void* stream) {
+extern "C" int vmr_splitk_reduce(const float* slab, float* dst, int nsplit, int64_t n, int cols, int64_t ld_dst,
+                                 void* stream) {
   VMR_CHECK(slab && dst && nsplit >= 1, "vmr_splitk_reduce: bad arguments");
   VMR_CHECK(n % 4 == 0 && ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0,
             "vmr_splitk_reduce: needs 16-byte aligned buffers and n %% 4 == 0");
+  if (cols == ld_dst) cols = 0;
+  VMR_CHECK(cols == 0 || (cols % 4 == 0 && ld_dst % 4 == 0 && ld_dst >= cols && n % cols == 0),
+            "vmr_splitk_reduce: cols / ld_dst must be multiples of 4");
   if (n == 0) return 0;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((int64_t)4096, (n / 4 + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, slab, dst, nsplit, n / 4, n / 4);
+                     (hipStream_t)stream, slab, dst, nsplit, n / 4, n / 4, cols / 4, ld_dst / 4);
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -92,7 +92,7 @@ __device__ __forceinline__ void epilogue_half(const vmr_gemm_t& g, const float* 
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
       const int gm = min(m0 + pass * (NT / 16) + (tid >> 4), g.M - 1);   // clamped: the load is unconditional
-      Vec8<T>::load(Rsd + (int64_t)gm * g.ldr + n0 + (tid & 15) * 8, rres[pass]);
+      Vec8<T>::load(Rsd + (int64_t)(gm / g.res_div) * g.ldr + n0 + (tid & 15) * 8, rres[pass]);
     }
   }
 #pragma unroll
@@ -137,7 +137,7 @@ __device__ __forceinline__ void epilogue_half(const vmr_gemm_t& g, const float* 
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += rres[pass][e];
       } else {
-        const T* rp = Rsd + (int64_t)gm * g.ldr + gn;
+        const T* rp = Rsd + (int64_t)(gm / g.res_div) * g.ldr + gn;
         for (int e = 0; e < nvalid; ++e) v[e] += to_f<T>(rp[e]);
       }
     }
@@ -516,8 +516,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        rres[i][j] = *reinterpret_cast<const bf16x4*>(Rsd + (int64_t)(m0 + wm * 64 + (lane & 15) + i * 16) * g.ldr + n0 +
-                                                      wn * 64 + (lane >> 4) * 4 + j * 16);
+        rres[i][j] = *reinterpret_cast<const bf16x4*>(Rsd + (int64_t)((m0 + wm * 64 + (lane & 15) + i * 16) / g.res_div) * g.ldr +
+                                                      n0 + wn * 64 + (lane >> 4) * 4 + j * 16);
   }
 
 #pragma unroll
@@ -924,6 +924,8 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   if (g.flags & VMR_EPI_SLAB) g.flags |= VMR_EPI_OUT_F32;
   VMR_CHECK(!(g.flags & VMR_EPI_BIAS) || g.bias, "vmr_gemm: bias flag without pointer");
   if (g.bias_scale == 0.f) g.bias_scale = 1.f;
+  if (g.res_div <= 0) g.res_div = 1;
+  VMR_CHECK(g.res_div == 1 || !(g.flags & VMR_EPI_AUX), "vmr_gemm: res_div with aux (aux shares ldr) is not supported");
   VMR_CHECK(!(g.flags & VMR_EPI_RESIDUAL) || g.residual, "vmr_gemm: residual flag without pointer");
   VMR_CHECK(!(g.flags & VMR_EPI_AUX) || g.aux, "vmr_gemm: aux flag without pointer");
   VMR_CHECK(!(g.flags & VMR_EPI_ROWSCALE) || g.rowscale, "vmr_gemm: rowscale flag without pointer");
@@ -959,7 +961,7 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   const bool dma_ok = g_gemm_dma && al && g.dtype == VMR_BF16 && g.M % BM == 0 && g.N % BN == 0 && g.K % 64 == 0 &&
                       g.K >= 128 * g.splitk &&
                       (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));   // the direct epilogue loads bias as float4
-  if (dma_ok && g_gemm_dma >= 3 && g.M >= 256) {
+  if (dma_ok && g_gemm_dma >= 3 && g.M >= 256 && g.res_div == 1) {
     // 256x128 tiles for the rows that fill whole rounds of the 256 CUs; the ragged remainder (e.g. the
     // 1280 query-token rows of a packed [8192 | 1280] matrix) goes to the 128x128 kernel instead of
     // costing a second, nearly empty round of big tiles.

@@ -121,26 +121,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar branches
   const uint32_t thresh = vmr_drop_thresh(drop_p);
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  const int64_t r0 = (int64_t)blockIdx.x * LNB_ROWS + wid * 2;
-  float xv[2][MAXC][8], gv[2][MAXC][8];
-  bool ok[2];
+  // Persistent waves: wave w of workgroup g walks rows g*4+w, +4*gridDim, ... ; the three operand rows of
+  // the NEXT row (x, dy and the residual-branch gradient) are requested -- unconditionally, clamped --
+  // before the current row is reduced, and stay in the STORAGE type (4 VGPRs per bf16 chunk) until then,
+  // so every wave keeps one full row set in flight while it computes and the register count leaves
+  // 4-5 workgroups per CU.  dgamma/dbeta accumulate in registers over all the wave's rows.
+  typedef __attribute__((ext_vector_type(8))) T TV8;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  TV8 cx[MAXC], cg[MAXC], cr[MAXC];
+  {
+    const int64_t rc = min(row, rows - 1);
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    ok[u] = r0 + u < rows;
-    const int64_t rc = min(r0 + u, rows - 1);   // clamped: both rows' loads issue unconditionally
-    load_row<T, MAXC>(x + rc * D, D, lane, xv[u]);
-    load_row<T, MAXC>(dy + rc * D, D, lane, gv[u]);
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = (c * 64 + lane) * 8;
+      if (i < D) {
+        cx[c] = *reinterpret_cast<const TV8*>(x + rc * D + i);
+        cg[c] = *reinterpret_cast<const TV8*>(dy + rc * D + i);
+        if (dres) cr[c] = *reinterpret_cast<const TV8*>(dres + rc * D + i);
+      }
+    }
   }
   float ag[MAXC][8], ab[MAXC][8];
 #pragma unroll
   for (int c = 0; c < MAXC; ++c)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
+  while (row < rows) {
+    TV8 nx[MAXC], ng[MAXC], nr[MAXC];
+    {
+      const int64_t rc = min(row + stride, rows - 1);
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (!ok[u]) continue;
-    const int64_t row = r0 + u;
+      for (int c = 0; c < MAXC; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i < D) {
+          nx[c] = *reinterpret_cast<const TV8*>(x + rc * D + i);
+          ng[c] = *reinterpret_cast<const TV8*>(dy + rc * D + i);
+          if (dres) nr[c] = *reinterpret_cast<const TV8*>(dres + rc * D + i);
+        }
+      }
+    }
     const float mean = mean_i[row], rstd = rstd_i[row];
+    uint32_t keep[MAXC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
@@ -148,20 +170,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       if (i >= D) continue;
       float g[8];
       Vec8<float>::load(gamma + i, g);
-      const uint32_t keep = drop_p > 0.f ? vmr_keep8(seed, (uint64_t)row * D + i, thresh) : 0xFFu;
+      keep[c] = drop_p > 0.f ? vmr_keep8(seed, (uint64_t)row * D + i, thresh) : 0xFFu;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float d = gv[u][c][e];
-        if (drop_p > 0.f) d = ((keep >> e) & 1) ? d * dscale : 0.f;
-        const float xh = (xv[u][c][e] - mean) * rstd;
-        ag[c][e] += d * xh;
+        float d = (float)cg[c][e];
+        if (drop_p > 0.f) d = ((keep[c] >> e) & 1) ? d * dscale : 0.f;
+        const float h = ((float)cx[c][e] - mean) * rstd;
+        ag[c][e] += d * h;
         ab[c][e] += d;
         if (dpos) atomicAdd(&dpos[(int64_t)(row % S) * D + i + e], d);
-        const float dxh = d * g[e];
-        s1 += dxh;
-        s2 += dxh * xh;
-        xv[u][c][e] = xh;
-        gv[u][c][e] = dxh;
+        const float dh = d * g[e];
+        s1 += dh;
+        s2 += dh * h;
       }
     }
     s1 = wave_sum(s1) / (float)D;
@@ -170,17 +190,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int c = 0; c < MAXC; ++c) {
       const int i = (c * 64 + lane) * 8;
       if (i >= D) continue;
-      float o[8];
+      float g[8], o[8];
+      Vec8<float>::load(gamma + i, g);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[u][c][e] - s1 - xv[u][c][e] * s2);
-      if (dres) {
-        float r[8];
-        Vec8<T>::load(dres + row * D + i, r);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += r[e];
+      for (int e = 0; e < 8; ++e) {   // (xhat and dxhat are recomputed rather than kept: 32 VGPRs less)
+        float d = (float)cg[c][e];
+        if (drop_p > 0.f) d = ((keep[c] >> e) & 1) ? d * dscale : 0.f;
+        const float h = ((float)cx[c][e] - mean) * rstd;
+        o[e] = rstd * (d * g[e] - s1 - h * s2);
+        if (dres) o[e] += (float)cr[c][e];
       }
       Vec8<T>::store(dx + row * D + i, o);
     }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) { cx[c] = nx[c]; cg[c] = ng[c]; cr[c] = nr[c]; }
+    row += stride;
   }
   if (!part) return;
   constexpr int SLOTS = MAXC * 8 * 64;   // permuted row: slot (c*8+e)*64 + lane  <->  column (c*64+lane)*8 + e
@@ -446,9 +470,13 @@ extern "C" int vmr_layernorm_bwd(const void* dy, const void* x, const float* gam
   VMR_CHECK((dgamma == nullptr) == (dbeta == nullptr), "vmr_layernorm_bwd: dgamma/dbeta must come together");
   VMR_CHECK(!dgamma || workspace, "vmr_layernorm_bwd: dgamma/dbeta need the workspace (VMR_LN_BWD_WS_FLOATS(rows, D))");
   if (rows == 0) return 0;
-  const int grid = (int)((rows + LNB_ROWS - 1) / LNB_ROWS);
-  VMR_CHECK(grid <= VMR_LN_BWD_MAX_BLOCKS || !dgamma, "vmr_layernorm_bwd: more than %d row blocks (rows=%lld): split the call",
-            VMR_LN_BWD_MAX_BLOCKS, (long long)rows);
+  // persistent grid: at most g_lnb_grid workgroups (never more than ceil(rows/8): the workspace bound)
+  static int g_lnb_grid = 0;
+  if (g_lnb_grid == 0) {
+    const char* e = getenv("VMR_LNB_GRID");
+    g_lnb_grid = e && atoi(e) > 0 ? atoi(e) : 768;   // 3 resident workgroups x 256 CUs at D = 1024
+  }
+  const int grid = (int)min((int64_t)min(g_lnb_grid, VMR_LN_BWD_MAX_BLOCKS), (rows + LNB_ROWS - 1) / LNB_ROWS);
   float* part = dgamma ? workspace : nullptr;
   const int maxc = D <= 512 ? 1 : (D <= 1024 ? 2 : 4);
   const int slots = maxc * 8 * 64;

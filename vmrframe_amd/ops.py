@@ -61,7 +61,7 @@ class DropCtx:
 # ---------------------------------------------------------------------------
 def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=None, residual=None, aux=None,
          ldr=0, rowscale=None, alpha=1.0, Z1=1, Z2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, drop=NO_DROP,
-         bias2=None, bias_scale=1.0):
+         bias2=None, bias_scale=1.0, res_div=1):
     d = L.GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cmat.data_ptr()
     d.bias, d.residual, d.aux, d.rowscale = _ptr(bias), _ptr(residual), _ptr(aux), _ptr(rowscale)
@@ -75,7 +75,7 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
     d.splitk = splitk
     d.drop_p, d.drop_seed = drop[0], drop[1]
     d.drop_step = _ptr(drop[2])
-    d.bias2, d.bias_scale = _ptr(bias2), bias_scale
+    d.bias2, d.bias_scale, d.res_div = _ptr(bias2), bias_scale, res_div
     if GEMM_HOOK is not None:
         GEMM_HOOK(lambda: L.check(L.lib().vmr_gemm(C.byref(d), L.stream_ptr()), "vmr_gemm"), M, N, K, ta, tb,
                   Z1 * Z2, dtype)
@@ -256,10 +256,13 @@ class _Linear(torch.autograd.Function):
     the compute-dtype copy comes from the WeightCache."""
 
     @staticmethod
-    def forward(ctx, x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, *weights):
+    def forward(ctx, x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, kslice, res_div, *weights):
         L.require_gpu(x)
         assert x.dim() == 2 and x.stride(1) == 1
         W = cache.get(weights, x.dtype)
+        if kslice is not None:               # y = x . W[:, k0:k1]^T : a column slice of ONE weight, used in place
+            assert len(weights) == 1 and kslice[0] % 8 == 0 and kslice[1] % 8 == 0
+            W = W[:, kslice[0]:kslice[1]]
         M, Kp = x.shape
         N = W.shape[0]
         assert W.shape[1] == Kp, f"input K {Kp} vs weight K {W.shape[1]} (pad inputs to a multiple of 8)"
@@ -276,7 +279,7 @@ class _Linear(torch.autograd.Function):
         if drop[0] > 0:
             flags |= L.EPI_DROPOUT
         if residual is not None:
-            assert residual.shape == y.shape and residual.is_contiguous()
+            assert residual.is_contiguous() and residual.shape[1] == N and residual.shape[0] * res_div == M
             flags |= L.EPI_RESIDUAL
         if relu and (residual is not None) and any(t.requires_grad for t in (x, *weights)):
             aux = torch.empty_like(y)   # post-dropout ReLU output: the backward's mask
@@ -284,12 +287,15 @@ class _Linear(torch.autograd.Function):
         if rowscale is not None:
             flags |= L.EPI_ROWSCALE
         gemm(x, W, ybuf, M, N, Kp, 0, 0, x.stride(0), W.stride(0), Np, dtype=dt, flags=flags, bias=bias,
-             residual=residual, aux=aux, ldr=N, rowscale=rowscale, drop=drop, bias2=bias2, bias_scale=bias_scale)
+             residual=residual, aux=aux, ldr=N, rowscale=rowscale, drop=drop, bias2=bias2, bias_scale=bias_scale,
+             res_div=res_div)
         ctx.save_for_backward(x, W, aux if aux is not None else (ybuf if relu else None), rowscale)
         ctx.meta = (relu, drop, bias is not None, residual is not None, [tuple(w.shape) for w in weights])
         ctx.weights = weights
         ctx.bias_param = bias
         ctx.bias2_param, ctx.bias_scale = bias2, bias_scale
+        ctx.kslice, ctx.res_div = kslice, res_div
+        assert res_div == 1 or aux is None
         assert bias2 is None or (bias is not None and Np == N)
         return y
 
@@ -309,6 +315,8 @@ class _Linear(torch.autograd.Function):
         if rowscale is not None:
             dyb = dyb * rowscale[:, None].to(dyb.dtype)
         dres = dyb if has_res else None      # (has_res implies Np == N)
+        if has_res and ctx.res_div > 1:      # broadcast residual: its gradient is the sum over each row group
+            dres = dyb.view(M // ctx.res_div, ctx.res_div, Np).sum(1, dtype=torch.float32).to(dyb.dtype)
         Kp = x.shape[1]
         dt = L.dtype_code(dyb)
         lib, st = L.lib(), L.stream_ptr()
@@ -341,7 +349,9 @@ class _Linear(torch.autograd.Function):
         # dW = dz^T . x  -> fp32 [N,Kp], split-K over the M (token) dimension
         sk = splitk_for(N, Kp, M)
         slots = [main_grad(w) for w in ctx.weights]
-        if all(g is not None for g in slots) and all(int(np.prod(shp[1:])) == Kp for shp in wshapes):
+        ks = ctx.kslice
+        kfull = [int(np.prod(shp[1:])) for shp in wshapes]
+        if all(g is not None for g in slots) and (ks is not None or all(k == Kp for k in kfull)):
             # accumulate straight into the flat gradient arena: no zero-fill, no autograd add
             side = DW_SIDE_STREAM
             if side is not None:
@@ -350,25 +360,27 @@ class _Linear(torch.autograd.Function):
                 x.record_stream(side)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 r = 0
-                for g_, shp in zip(slots, wshapes):
+                for g_, shp, kf in zip(slots, wshapes, kfull):
                     n = shp[0]
                     a = dz[:, r:r + n]
                     sk_ = splitk_for(n, Kp, M)
+                    if ks is not None:       # gradient of the column slice, in place inside the full matrix
+                        g_ = g_.view(n, kf)[:, ks[0]:ks[1]]
                     if sk_ > 1 and USE_SLABS:
                         # split-K partials as plain fp32 slabs + one reduce pass: float atomics from
                         # every workgroup of a single-round grid land together and run far below HBM speed
                         ws = torch.empty(sk_, n, Kp, device=dy.device, dtype=torch.float32)
                         gemm(a, x, ws, n, Kp, M, 1, 1, a.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_SLAB,
                              splitk=sk_)
-                        L.check(lib.vmr_splitk_reduce(ws.data_ptr(), g_.data_ptr(), sk_, n * Kp, L.stream_ptr()),
-                                "vmr_splitk_reduce")
+                        L.check(lib.vmr_splitk_reduce(ws.data_ptr(), g_.data_ptr(), sk_, n * Kp, Kp, kf,
+                                                      L.stream_ptr()), "vmr_splitk_reduce")
                     else:
-                        gemm(a, x, g_, n, Kp, M, 1, 1, a.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_ACCUM,
+                        gemm(a, x, g_, n, Kp, M, 1, 1, a.stride(0), x.stride(0), kf, dtype=dt, flags=L.EPI_ACCUM,
                              splitk=sk_)
                     r += n
             if db is not None and Np != N:
                 db = db[:N]
-            return (dx, *_bias_grads(db, bgrad, has_b2, ctx.bias_scale), None, dres, None, None, None, None,
+            return (dx, *_bias_grads(db, bgrad, has_b2, ctx.bias_scale), None, dres, None, None, None, None, None, None,
                     *([None] * len(wshapes)))
         if sk > 1:
             dW = torch.zeros(N, Kp, device=dy.device, dtype=torch.float32)
@@ -382,11 +394,17 @@ class _Linear(torch.autograd.Function):
             k = 1
             for s_ in shp[1:]:
                 k *= s_
-            grads.append(dW[r:r + n, :k].reshape(shp))
+            if ks is not None:
+                full = torch.zeros(n, k, device=dy.device, dtype=torch.float32)
+                full[:, ks[0]:ks[1]] = dW[r:r + n, :ks[1] - ks[0]]
+                grads.append(full.reshape(shp))
+            else:
+                grads.append(dW[r:r + n, :k].reshape(shp))
             r += n
         if db is not None and Np != N:
             db = db[:N]
-        return (dx, *_bias_grads(db, bgrad, has_b2, ctx.bias_scale), None, dres, None, None, None, None, *grads)
+        return (dx, *_bias_grads(db, bgrad, has_b2, ctx.bias_scale), None, dres, None, None, None, None, None, None,
+                *grads)
 
 
 def _bias_grads(db, bgrad, has_b2, bias_scale):
@@ -397,11 +415,46 @@ def _bias_grads(db, bgrad, has_b2, bias_scale):
 
 
 def linear(x, weights, bias, cache, *, relu=False, drop=NO_DROP, residual=None, rowscale=None, bias2=None,
-           bias_scale=1.0):
-    """y = drop(act(x.W^T + bias_scale*bias + bias2)) + residual."""
+           bias_scale=1.0, kslice=None, res_div=1):
+    """y = drop(act(x.W[:, kslice]^T + bias_scale*bias + bias2)) + residual[row // res_div]."""
     if isinstance(weights, torch.Tensor):
         weights = [weights]
-    return _Linear.apply(x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, *weights)
+    return _Linear.apply(x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, kslice, res_div, *weights)
+
+
+class _WeightedPool(torch.autograd.Function):
+    """WeightedPool (reference models/layers.py:440-453) in one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x, w, mask):
+        L.require_gpu(x, w, mask)
+        B, Ls, D = x.shape
+        x = x.contiguous()
+        alpha = torch.empty(B, Ls, device=x.device, dtype=torch.float32)
+        pooled = torch.empty(B, D, device=x.device, dtype=x.dtype)
+        L.check(L.lib().vmr_weighted_pool_fwd(x.data_ptr(), w.data_ptr(), mask.data_ptr(), alpha.data_ptr(),
+                                              pooled.data_ptr(), B, Ls, D, L.dtype_code(x), L.stream_ptr()),
+                "vmr_weighted_pool_fwd")
+        ctx.save_for_backward(x, w, alpha)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, w, alpha = ctx.saved_tensors
+        B, Ls, D = x.shape
+        dp = dp.contiguous()
+        dx = torch.empty_like(x)
+        mg = main_grad(w)
+        dw = mg if mg is not None else torch.zeros(w.numel(), device=x.device, dtype=torch.float32)
+        L.check(L.lib().vmr_weighted_pool_bwd(dp.data_ptr(), x.data_ptr(), w.data_ptr(), alpha.data_ptr(), dx.data_ptr(),
+                                              dw.data_ptr(), B, Ls, D, L.dtype_code(x), L.stream_ptr()),
+                "vmr_weighted_pool_bwd")
+        return dx, (None if mg is not None else dw.view(w.shape)), None
+
+
+def weighted_pool(x, w, mask):
+    """x [B,L,D] (compute dtype), w [D,1] fp32 parameter, mask [B,L] fp32 -> pooled [B,D]."""
+    return _WeightedPool.apply(x, w, mask.contiguous())
 
 
 def group_view(params):
