@@ -243,6 +243,17 @@ int vmr_weighted_pool_fwd(const void* x, const float* w, const float* mask, floa
 int vmr_weighted_pool_bwd(const void* dpooled, const void* x, const float* w, const float* alpha,
                           void* dx, float* dw, int B, int L, int D, int dtype, void* stream);
 
+/* ------------------------------------------------- inference head + IoU metrics
+ * vmr_infer_basic (reference utils/engine.py:28-44): per clip, the masked softmax of the start and
+ * end logits, and the first indices (i*, j*) of max_{i<=j} sp[i]*ep[j] by rows and by columns;
+ * frac[b] = (i*, j*) / sum(vmask[b]) (fp32 [B,2]), idx[b] = (i*, j*) (int32 [B,2]).  The [B,T,T] outer
+ * product of the reference is never materialised; results are bit-identical to it.
+ * vmr_iou_metrics (utils/utils.py:161-185, models/loss.py:83-109): ious[i] = IoU(props[i], gts[i])
+ * (nullable output) and acc[5] (fp64, ACCUMULATED) += {#iou>=0.3, #iou>=0.5, #iou>=0.7, n, sum iou}. */
+int vmr_infer_basic(const float* slogits, const float* elogits, const float* vmask, float* frac, int* idx,
+                    int B, int T, void* stream);
+int vmr_iou_metrics(const float* props, const float* gts, float* ious, double* acc, int n, void* stream);
+
 /* --------------------------------------------------------------- optimizer
  * fused AdamW over a flat fp32 parameter arena (utils/utils.py:87-97:
  * AdamW, weight_decay 0.01 except names containing bias/layer_norm) with the

@@ -219,12 +219,51 @@ def time_both(mods):
         print(f"cfg1 fwd+bwd {nm}: {(time.time() - t0) / 5 * 1e3:.1f} ms/step ({torch.get_num_threads()} threads)")
 
 
+def metrics_case(mods):
+    """Next row N4: reference infer_basic (utils/engine.py:28-44) on crafted logits (ties, single valid
+    frame, peaked and flat distributions) and reference append_ious / get_i345_mi
+    (models/loss.py:83-109) on random proposals -> tests/golden/g_metrics.npz."""
+    _, loss_mod, engine = mods
+    rng = np.random.default_rng(4242)
+    B, T = 16, 40
+    sl = rng.standard_normal((B, T)).astype(np.float32) * 3
+    el = rng.standard_normal((B, T)).astype(np.float32) * 3
+    lens = rng.integers(1, T + 1, size=B); lens[0] = T; lens[1] = 1
+    vmask = (np.arange(T)[None] < lens[:, None]).astype(np.float32)
+    sl[2] = 0.0; el[2] = 0.0                      # flat: every product ties -> first indices
+    sl[3, 5] = sl[3, 9] = 20.0; el[3, 7] = el[3, 30] = 20.0   # exact two-way ties
+    sl[4, 20] = 30.0; el[4, 3] = 30.0             # end peak BEFORE start peak: the triu constraint decides
+    infer = engine.infer_basic(torch.from_numpy(sl), torch.from_numpy(el), torch.from_numpy(vmask)).astype(np.float32)
+    n = 257
+    props = np.sort(rng.random((n, 2)).astype(np.float32), axis=1)
+    gts = np.sort(rng.random((n, 2)).astype(np.float32), axis=1)
+    props[0] = gts[0]                              # IoU 1
+    props[1] = [0.1, 0.2]; gts[1] = [0.5, 0.9]     # disjoint -> 0
+    props[2] = [0.3, 0.3]; gts[2] = [0.3, 0.3]     # zero-length union -> 0.0 branch
+    props[3] = [0.0, 0.5]; gts[3] = [0.0, 1.0]     # exactly 0.5
+    ious = loss_mod.append_ious([], gts, props)
+    r = loss_mod.get_i345_mi(ious)
+    np.savez_compressed(os.path.join(GOLD, "g_metrics.npz"), slogits=sl, elogits=el, vmask=vmask, infer=infer,
+                        props=props, gts=gts, ious=np.asarray(ious, np.float64), summary=np.asarray(r, np.float64))
+    # the oracle restatement must agree before the fixture is trusted
+    o_inf = R.infer_basic(torch.from_numpy(sl), torch.from_numpy(el), torch.from_numpy(vmask))
+    assert np.array_equal(o_inf.astype(np.float32), infer), "oracle infer_basic != reference"
+    o_ious = R.append_ious([], gts, props)
+    assert np.allclose(o_ious, ious, rtol=0, atol=0), "oracle append_ious != reference"
+    assert np.allclose(R.get_i345_mi(o_ious), r, rtol=0, atol=1e-12), "oracle get_i345_mi != reference"
+    print("g_metrics: infer", infer[:5].tolist(), "summary", r)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true")
+    ap.add_argument("--only-metrics", action="store_true")
     args = ap.parse_args()
     torch.manual_seed(0)
     mods = import_reference()
+    metrics_case(mods)
+    if args.only_metrics:
+        return
     # g_tiny: everything stored (weights, intermediates, per-parameter grads)
     case(mods, "g_tiny", B=3, T=16, L=6, D=32, V=24, num_words=30, num_chars=12, C=5, seed=11,
          store_weights=True, hooks=True)

@@ -109,3 +109,15 @@ def test_oracle_basefast_variant(name):
     assert abs(float(loss) - float(z["out.loss"])) < TOL
     loss.backward()
     assert P["dual_attention_block_1.dense_1.conv1d.weight"].grad is None      # blocks constructed but skipped
+
+
+def test_oracle_infer_and_iou_metrics_match_reference_fixture():
+    """Next row N4: the oracle restatements of infer_basic / append_ious / get_i345_mi against the
+    reference's own outputs (g_metrics.npz)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g_metrics.npz"))
+    inf = R.infer_basic(torch.from_numpy(g["slogits"]), torch.from_numpy(g["elogits"]), torch.from_numpy(g["vmask"]))
+    assert np.array_equal(inf.astype(np.float32), g["infer"])
+    ious = R.append_ious([], g["gts"], g["props"])
+    assert np.array_equal(np.asarray(ious, np.float64), g["ious"])
+    assert np.allclose(R.get_i345_mi(ious), g["summary"], rtol=0, atol=1e-12)

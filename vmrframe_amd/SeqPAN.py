@@ -472,15 +472,24 @@ def train_engine_SeqPAN(model, data, configs, runtype):
     return loc_loss + m_loss, output
 
 
+def infer_basic_device(start_logits, end_logits, vmask):
+    """reference utils/engine.py:28-44 in ONE kernel (vmr_infer_basic): (fractions fp32 [B,2],
+    indices int32 [B,2]) as device tensors -- no [B,T,T] outer product, no host sync."""
+    L.require_gpu(start_logits, end_logits, vmask)
+    B, T = start_logits.shape
+    sl, el = start_logits.detach().float().contiguous(), end_logits.detach().float().contiguous()
+    vm = vmask.float().contiguous()
+    frac = torch.empty(B, 2, device=sl.device, dtype=torch.float32)
+    idx = torch.empty(B, 2, device=sl.device, dtype=torch.int32)
+    L.check(L.lib().vmr_infer_basic(sl.data_ptr(), el.data_ptr(), vm.data_ptr(), frac.data_ptr(), idx.data_ptr(), B, T,
+                                    L.stream_ptr()), "vmr_infer_basic")
+    return frac, idx
+
+
 def infer_basic(start_logits, end_logits, vmask):
-    """reference utils/engine.py:28-44."""
-    sp = torch.softmax(start_logits + NEG * (1.0 - vmask), dim=1)
-    ep = torch.softmax(end_logits + NEG * (1.0 - vmask), dim=1)
-    outer = torch.triu(sp[:, :, None] * ep[:, None, :], diagonal=0)
-    sidx = outer.max(dim=2).values.max(dim=1).indices
-    eidx = outer.max(dim=1).values.max(dim=1).indices
-    n = vmask.sum(dim=1)
-    return np.stack([(sidx / n).cpu().numpy(), (eidx / n).cpu().numpy()]).T
+    """Drop-in for reference utils/engine.py:28-44: float ndarray [B,2] of (start, end) fractions
+    (one [B,2] device-to-host copy instead of two, and no [B,T,T] temporary)."""
+    return infer_basic_device(start_logits, end_logits, vmask)[0].cpu().numpy()
 
 
 def infer_SeqPAN(output, configs):
