@@ -72,6 +72,18 @@ def test_gemm_lds_dma_kernels_exact(dev, shape):
     acc = torch.ones(M, N, device=dev)
     ops.gemm(A, B, acc, M, N, K, 0, 0, K, K, N, dtype=L.BF16, flags=L.EPI_ACCUM, splitk=2 if K >= 256 else 1)
     assert torch.equal(acc - 1, A.float() @ B.float().t())
+    # the register-direct bf16 epilogue (and, at [9472 x 1024], the 160-row tile with its ragged last
+    # row tile): bias + ReLU + dropout + aux + residual, both B layouts
+    bias = torch.randn(N, device=dev)
+    mask = ops.dropout_mask(M * N, 0.25, 9, dev).view(M, N)
+    for tb, Bm in ((0, B), (1, B.t().contiguous())):
+        out = torch.empty(M, N, device=dev, dtype=dt)
+        aux = torch.empty_like(out)
+        ops.gemm(A, Bm, out, M, N, K, 0, tb, K, Bm.stride(0), N, dtype=L.BF16, bias=bias, residual=res, aux=aux, ldr=N,
+                 flags=L.EPI_BIAS | L.EPI_RELU | L.EPI_DROPOUT | L.EPI_RESIDUAL | L.EPI_AUX, drop=(0.25, 9, None))
+        h = torch.relu(A.float() @ B.float().t() + bias) * mask
+        assert torch.equal(aux, h.to(dt)), (shape, tb)
+        assert torch.equal(out, (h + res.float()).to(dt)), (shape, tb)
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])

@@ -379,10 +379,13 @@ typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
 // one operand tile (128 rows x BK, or BK x 128 for the transposed image) = 128*BK*2 bytes = NB 1-KiB blocks
-template <bool KC, int BK>
+// (ROWS = 160 for the 160-row A tile of the ragged-M variant: rows past rmax re-read row rmax)
+template <bool KC, int BK, int ROWS = 128>
 __device__ __forceinline__ void dma_operand(const bf16_t* __restrict__ P, int64_t ld, int r0, int k0,
-                                            unsigned char* lds, int wid, int lane) {
-  constexpr int NB = 128 * BK * 2 / 1024;  // 8 (BK=32) or 16 (BK=64) blocks, NB/4 per wave
+                                            unsigned char* lds, int wid, int lane, int rmax = 0x7fffffff) {
+  constexpr int NB = ROWS * BK * 2 / 1024;  // 8 (BK=32) or 16 (BK=64) blocks, NB/4 per wave
+  static_assert(NB % 4 == 0, "operand blocks must divide over the 4 waves");
+  static_assert(ROWS == 128 || (KC && BK == 64), "tall tiles: k-contiguous BK=64 image only");
 #pragma unroll
   for (int jj = 0; jj < NB / 4; ++jj) {
     const int j = wid * (NB / 4) + jj;
@@ -391,7 +394,7 @@ __device__ __forceinline__ void dma_operand(const bf16_t* __restrict__ P, int64_
       if (BK == 64) {       // 128-B rows: one wave-instruction = 8 whole rows = 8 full cache lines
         const int row = 8 * j + (lane >> 3);
         const int c = (lane & 7) ^ (row & 7);
-        src = P + (int64_t)(r0 + row) * ld + k0 + c * 8;
+        src = P + (int64_t)min(r0 + row, rmax) * ld + k0 + c * 8;
       } else {              // 64-B rows
         const int row = 16 * j + (lane >> 2);
         const int c = (lane & 3) ^ swz_kc32(row);
@@ -411,8 +414,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   else if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else static_assert(N == 0 || N == 4 || N == 8 || N == 16, "add the immediate");
+  else if (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else static_assert(N == 0 || N == 4 || N == 8 || N == 9 || N == 16 || N == 18, "add the immediate");
 }
 
 // Register-direct epilogue of the LDS-DMA kernel (bf16 output, interior tiles).  The MFMAs are issued
@@ -420,11 +425,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // bias / residual / aux / C move as 8-byte accesses straight from the accumulators -- no LDS staging,
 // no workgroup barrier (a wave's stores overlap the other waves' and the co-resident workgroup's
 // MFMAs), and one dropout hash serves exactly the lane's 4 elements.
-__device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4 (&acc)[4][4], int wm, int wn, int lane,
+template <int MT>
+__device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4 (&acc)[MT][4], int wm, int wn, int lane,
                                                 int m0, int n0, int zb, bf16_t* __restrict__ C,
-                                                const bf16x4 (&rres)[4][4], bf16_t* __restrict__ Aux) {
+                                                const bf16x4 (&rres)[MT][4], bf16_t* __restrict__ Aux) {
   const int flags = g.flags;
-  const int rbase = m0 + wm * 64 + (lane & 15);
+  const int rbase = m0 + wm * (MT * 16) + (lane & 15);
   const int cbase = n0 + wn * 64 + (lane >> 4) * 4;
   f32x4 bias4[4];
 #pragma unroll
@@ -440,8 +446,9 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
   const float dscale = (flags & VMR_EPI_DROPOUT) ? 1.0f / (1.0f - g.drop_p) : 1.0f;
   const uint32_t seed = vmr_seed(g.drop_seed, g.drop_step);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MT; ++i) {
     const int gm = rbase + i * 16;
+    if (MT != 4 && gm >= g.M) continue;   // ragged last tile of the 160-row variant
     const float rs = (flags & VMR_EPI_ROWSCALE) ? g.rowscale[gm] : 1.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -478,16 +485,22 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
   }
 }
 
-template <bool TA, bool TB, int BK, int NST>
+// MT = 16-row MFMA tiles per wave along M: 4 -> the 128x128 tile; 5 -> a 160x128 tile (A not
+// transposed, register-direct epilogue only, ragged last row tile allowed) that turns the 592-tile,
+// 1.16-round grids of the packed [9472 x 1024] products into ONE round of 480 workgroups.
+template <bool TA, bool TB, int BK, int NST, int MT = 4>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int OPB = 128 * BK * 2;
-  constexpr int LPS = 2 * (OPB / 1024) / 4;  // loads per wave per K-step (A + B)
+  static_assert(MT == 4 || (!TA && BK == 64), "tall tile: A row-major, BK = 64");
+  constexpr int TBM = MT * 32;               // tile rows
+  constexpr int OPA = TBM * BK * 2;          // A operand bytes per stage
+  constexpr int OPB = 128 * BK * 2;          // B operand bytes per stage
+  constexpr int LPS = (OPA + OPB) / 1024 / 4;  // loads per wave per K-step (A + B)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
   const TileCoord tc = tile_coord(g, tiles_m, tiles_n);
-  const int m0 = tc.tm * BM, n0 = tc.tn * BN;
+  const int m0 = tc.tm * TBM, n0 = tc.tn * BN;
   const int z1 = tc.zb / g.Z2, z2 = tc.zb - z1 * g.Z2;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
@@ -499,43 +512,44 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
     k_begin = tc.ks * chunk;
     k_end = min(g.K, k_begin + chunk);
   }
-  f32x4 acc[4][4];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nk = k_end > k_begin ? (k_end - k_begin) / BK : 0;
   // The residual quads of the register-direct epilogue are requested FIRST (oldest in the vmcnt
   // order, so every counted wait below also covers them): their HBM latency hides under the whole
   // K loop instead of being exposed once per tile.
-  bf16x4 rres[4][4];
-  const bool direct = !(g.flags & VMR_EPI_ACCUM);   // atomics keep the LDS-staged, 256-B-per-wave shape
+  bf16x4 rres[MT][4];
+  const bool direct = MT != 4 || !(g.flags & VMR_EPI_ACCUM);   // atomics keep the LDS-staged, 256-B-per-wave shape
   if (direct && (g.flags & VMR_EPI_RESIDUAL)) {
     const bf16_t* Rsd = reinterpret_cast<const bf16_t*>(g.residual) + coff;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        rres[i][j] = *reinterpret_cast<const bf16x4*>(Rsd + (int64_t)((m0 + wm * 64 + (lane & 15) + i * 16) / g.res_div) * g.ldr +
-                                                      n0 + wn * 64 + (lane >> 4) * 4 + j * 16);
+        rres[i][j] = *reinterpret_cast<const bf16x4*>(
+            Rsd + (int64_t)(min(m0 + wm * (MT * 16) + (lane & 15) + i * 16, g.M - 1) / g.res_div) * g.ldr + n0 + wn * 64 +
+            (lane >> 4) * 4 + j * 16);
   }
 
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) {
     if (s < nk) {
-      dma_operand<!TA, BK>(A, g.lda, m0, k_begin + s * BK, smem + s * 2 * OPB, wid, lane);
-      dma_operand<!TB, BK>(B, g.ldb, n0, k_begin + s * BK, smem + s * 2 * OPB + OPB, wid, lane);
+      dma_operand<!TA, BK, TBM>(A, g.lda, m0, k_begin + s * BK, smem + s * (OPA + OPB), wid, lane, g.M - 1);
+      dma_operand<!TB, BK>(B, g.ldb, n0, k_begin + s * BK, smem + s * (OPA + OPB) + OPA, wid, lane);
     }
   }
   // Software-pipelined fragment reads: the ds_reads of the next 32-deep k-substep are in flight while
   // the 16 MFMAs of the current one issue (rotated loop: the MFMAs of substep (kt, last) run at the top
   // of iteration kt+1, beside that iteration's first reads).
   constexpr int NKK = BK / 32;
-  bf16x8 fa[2][4], fb[2][4];
+  bf16x8 fa[2][MT], fb[2][4];
   auto mma = [&](int buf) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0);  // C^T tile
@@ -551,19 +565,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's part of step kt is in LDS; step kt-1's buffer is free
     if (kt + NST - 1 < nk) {
-      unsigned char* dst = smem + ((kt + NST - 1) % NST) * 2 * OPB;
+      unsigned char* dst = smem + ((kt + NST - 1) % NST) * (OPA + OPB);
       const int k0 = k_begin + (kt + NST - 1) * BK;
-      dma_operand<!TA, BK>(A, g.lda, m0, k0, dst, wid, lane);
-      dma_operand<!TB, BK>(B, g.ldb, n0, k0, dst + OPB, wid, lane);
+      dma_operand<!TA, BK, TBM>(A, g.lda, m0, k0, dst, wid, lane, g.M - 1);
+      dma_operand<!TB, BK>(B, g.ldb, n0, k0, dst + OPA, wid, lane);
     }
-    const unsigned char* cur = smem + (kt % NST) * 2 * OPB;
+    const unsigned char* cur = smem + (kt % NST) * (OPA + OPB);
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
       const int buf = kk & 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[buf][i] = read_frag<!TA, BK>(cur, wm * 4 + i, kk, lane);
+      for (int i = 0; i < MT; ++i) fa[buf][i] = read_frag<!TA, BK>(cur, wm * MT + i, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[buf][j] = read_frag<!TB, BK>(cur + OPB, wn * 4 + j, kk, lane);
+      for (int j = 0; j < 4; ++j) fb[buf][j] = read_frag<!TB, BK>(cur + OPA, wn * 4 + j, kk, lane);
       // while those reads fly: the MFMAs of the PREVIOUS substep (the last one of step kt-1 when kk == 0)
       if (kk > 0) mma((kk - 1) & 1);
       else if (kt > 0) mma((NKK - 1) & 1);
@@ -571,12 +585,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
   }
   if (nk > 0) mma((NKK - 1) & 1);
   if (direct) {
-    epilogue_direct(g, acc, wm, wn, lane, m0, n0, tc.zb,
+    epilogue_direct<MT>(g, acc, wm, wn, lane, m0, n0, tc.zb,
                     (g.flags & VMR_EPI_OUT_F32) ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
                                                 : reinterpret_cast<bf16_t*>(g.C) + coff,
                     rres, reinterpret_cast<bf16_t*>(g.aux) + coff);
     return;
   }
+  if constexpr (MT == 4) {
   __syncthreads();
   epilogue<bf16_t, true, true, true>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
                          (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM))
@@ -584,6 +599,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
                              : reinterpret_cast<bf16_t*>(g.C) + coff,
                          reinterpret_cast<const bf16_t*>(g.residual) + coff,
                          reinterpret_cast<bf16_t*>(g.aux) + coff);
+  }
 }
 
 // ------------------------------------------- bf16 LDS-DMA kernel, 256x128 tile
@@ -900,6 +916,16 @@ gemm_fn pick_dma_t(int ta, int tb) {
   if (ta && !tb) return (gemm_fn)gemm_bf16_dma_kernel<true, false, BK, NST>;
   return (gemm_fn)gemm_bf16_dma_kernel<true, true, BK, NST>;
 }
+constexpr int TALL_SMEM = 2 * (160 * 64 * 2 + 128 * 64 * 2);   // 73,728 B: two workgroups per CU
+gemm_fn pick_tall(int tb) {
+  return tb ? (gemm_fn)gemm_bf16_dma_kernel<false, true, 64, 2, 5> : (gemm_fn)gemm_bf16_dma_kernel<false, false, 64, 2, 5>;
+}
+// rounds of the 512 resident workgroups (2 per CU) a grid needs, in units of one full 128x128 round:
+// a last round that leaves every CU at most one workgroup runs about twice as fast
+inline double rounds_cost(int64_t tiles, double tile_weight) {
+  const int64_t full = tiles / 512, rem = tiles % 512;
+  return ((double)full + (rem == 0 ? 0.0 : (rem <= 256 ? 0.5 : 1.0))) * tile_weight;
+}
 Pick pick_dma(int ta, int tb, int variant) {
   // 64 KiB of stages; 67,584 B so the epilogue can stage the whole fp32 tile in one pass (still 2 / CU)
   if (variant == 2) return {pick_dma_t<64, 2>(ta, tb), 128 * CST_LD * 4};
@@ -1003,6 +1029,34 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
     return 0;
   }
   if (dma_ok) pk = pick_dma(g.transA, g.transB, g_gemm_dma >= 2 ? 2 : 1);
+  // 160-row tiles when they save a (partial) round: e.g. [9472 x 1024]: 592 tiles = 1.16 rounds of 128x128
+  // -> 480 tiles = one round of 160x128
+  static int g_tall = -1;
+  if (g_tall < 0) {
+    const char* e = getenv("VMR_GEMM_TALL");
+    g_tall = e ? atoi(e) : 1;
+  }
+  if (g_tall && g_gemm_dma >= 2 && al && g.dtype == VMR_BF16 && !g.transA && g.N % BN == 0 && g.K % 64 == 0 && g.K >= 128 &&
+      g.splitk == 1 && !(g.flags & VMR_EPI_ACCUM) && g.M % 8 == 0 &&
+      (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)))) {
+    const int tm160 = cdiv(g.M, 160);
+    const double c128 = dma_ok ? rounds_cost((int64_t)tiles_m * tiles_n * Z, 1.0) : 1e30;
+    const double c160 = rounds_cost((int64_t)tm160 * tiles_n * Z, 1.25);
+    if (dma_ok && c160 < c128 - 1e-9) {
+      gemm_fn tf = pick_tall(g.transB);
+      static thread_local bool tall_set[2] = {false, false};
+      if (!tall_set[g.transB ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           TALL_SMEM);
+        if (e != hipSuccess) return vmr_fail(-5, "vmr_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        tall_set[g.transB ? 1 : 0] = true;
+      }
+      hipLaunchKernelGGL(tf, dim3((unsigned)(tm160 * tiles_n), 1, (unsigned)Z), dim3(256), TALL_SMEM, (hipStream_t)stream,
+                         g, tm160, tiles_n);
+      VMR_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (pk.smem > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into once per kernel
     static thread_local const void* done[32];
     static thread_local int ndone = 0;
