@@ -414,7 +414,7 @@ def test_product_path_rejects_cpu_tensors(dev):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("dims", [(3, 16, 6), (2, 128, 20), (2, 20, 128), (1, 1, 1)])
+@pytest.mark.parametrize("dims", [(3, 16, 6), (2, 128, 20), (2, 20, 128), (1, 1, 1), (2, 7, 300), (2, 300, 3)])
 def test_cq_softmax_fwd_bwd(dev, dt, tol, dims):
     """The two masked softmaxes of CQAttention (models/layers.py:419-421) incl. fully masked rows/columns."""
     ops = _ops()

@@ -213,22 +213,57 @@ __global__ __launch_bounds__(256) void cq_softmax_fwd_kernel(const float* __rest
       o[q] = from_f<T>(q < Lq ? __expf(tile[c * Lq + q] + (1.0f - qmask[(int64_t)b * Lq + q]) * VMR_NEG_INF_MASK - mx) * inv
                               : 0.f);
   }
-  // columns: softmax over c with the context mask (one thread per column)
-  for (int q = threadIdx.x; q < ldP; q += 256) {
-    if (q >= Lq) {
-      for (int c = 0; c < Lc; ++c) Scol[((int64_t)b * Lc + c) * ldP + q] = from_f<T>(0.f);
-      continue;
+  // columns: softmax over c with the context mask.  256/Lq' threads share a column (each takes a
+  // stripe of c), so a short query axis (Lq = 20) does not leave 236 threads idle.
+  if (Lq > 256) {   // long query axis: a thread per column keeps every thread busy already
+    for (int q = threadIdx.x; q < ldP; q += 256) {
+      if (q >= Lq) {
+        for (int c = 0; c < Lc; ++c) Scol[((int64_t)b * Lc + c) * ldP + q] = from_f<T>(0.f);
+        continue;
+      }
+      float mx = -INFINITY;
+      for (int c = 0; c < Lc; ++c)
+        mx = fmaxf(mx, tile[c * Lq + q] + (1.0f - cmask[(int64_t)b * Lc + c]) * VMR_NEG_INF_MASK);
+      float sum = 0.f;
+      for (int c = 0; c < Lc; ++c)
+        sum += __expf(tile[c * Lq + q] + (1.0f - cmask[(int64_t)b * Lc + c]) * VMR_NEG_INF_MASK - mx);
+      const float inv = 1.f / sum;
+      for (int c = 0; c < Lc; ++c)
+        Scol[((int64_t)b * Lc + c) * ldP + q] =
+            from_f<T>(__expf(tile[c * Lq + q] + (1.0f - cmask[(int64_t)b * Lc + c]) * VMR_NEG_INF_MASK - mx) * inv);
     }
+  } else {
+    float* part = tile + Lc * Lq;                      // [NS][Lq] partial max, then partial sums
+    const int NS = max(1, min(256 / Lq, Lc));          // stripes per column
+    const int q = threadIdx.x % Lq, st = threadIdx.x / Lq;
+    const bool act = st < NS;
     float mx = -INFINITY;
-    for (int c = 0; c < Lc; ++c)
-      mx = fmaxf(mx, tile[c * Lq + q] + (1.0f - cmask[(int64_t)b * Lc + c]) * VMR_NEG_INF_MASK);
+    if (act)
+      for (int c = st; c < Lc; c += NS)
+        mx = fmaxf(mx, tile[c * Lq + q] + (1.0f - cmask[(int64_t)b * Lc + c]) * VMR_NEG_INF_MASK);
+    if (act) part[st * Lq + q] = mx;
+    __syncthreads();
+    if (act)
+      for (int k = 0; k < NS; ++k) mx = fmaxf(mx, part[k * Lq + q]);
+    __syncthreads();
     float sum = 0.f;
-    for (int c = 0; c < Lc; ++c)
-      sum += __expf(tile[c * Lq + q] + (1.0f - cmask[(int64_t)b * Lc + c]) * VMR_NEG_INF_MASK - mx);
-    const float inv = 1.f / sum;
-    for (int c = 0; c < Lc; ++c)
-      Scol[((int64_t)b * Lc + c) * ldP + q] =
-          from_f<T>(__expf(tile[c * Lq + q] + (1.0f - cmask[(int64_t)b * Lc + c]) * VMR_NEG_INF_MASK - mx) * inv);
+    if (act)
+      for (int c = st; c < Lc; c += NS)
+        sum += __expf(tile[c * Lq + q] + (1.0f - cmask[(int64_t)b * Lc + c]) * VMR_NEG_INF_MASK - mx);
+    if (act) part[st * Lq + q] = sum;
+    __syncthreads();
+    if (act) {
+      sum = 0.f;
+      for (int k = 0; k < NS; ++k) sum += part[k * Lq + q];
+      const float inv = 1.f / sum;
+      for (int c = st; c < Lc; c += NS)
+        Scol[((int64_t)b * Lc + c) * ldP + q] =
+            from_f<T>(__expf(tile[c * Lq + q] + (1.0f - cmask[(int64_t)b * Lc + c]) * VMR_NEG_INF_MASK - mx) * inv);
+    }
+    for (int i = threadIdx.x; i < Lc * (ldP - Lq); i += 256) {   // zero the padding columns
+      const int c = i / (ldP - Lq), qq = Lq + i % (ldP - Lq);
+      Scol[((int64_t)b * Lc + c) * ldP + qq] = from_f<T>(0.f);
+    }
   }
 }
 
@@ -245,10 +280,28 @@ __global__ __launch_bounds__(256) void cq_softmax_bwd_kernel(const T* __restrict
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t base = (int64_t)b * Lc * ldP;
-  for (int q = threadIdx.x; q < Lq; q += 256) {
-    float d = 0.f;
-    for (int c = 0; c < Lc; ++c) d += to_f<T>(dScol[base + (int64_t)c * ldP + q]) * to_f<T>(Scol[base + (int64_t)c * ldP + q]);
-    cdot[q] = d;
+  float* part = cdot + Lq;                           // [NS][Lq] partials
+  const bool striped = Lq <= 256;                    // 256/Lq threads share a column (a stripe of c each)
+  const int NS = striped ? max(1, min(256 / Lq, Lc)) : 1;
+  const int pq = threadIdx.x % Lq, pst = threadIdx.x / Lq;
+  if (striped) {
+    if (pst < NS) {
+      float d = 0.f;
+      for (int c = pst; c < Lc; c += NS) d += to_f<T>(dScol[base + (int64_t)c * ldP + pq]) * to_f<T>(Scol[base + (int64_t)c * ldP + pq]);
+      part[pst * Lq + pq] = d;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < Lq; q += 256) {
+      float d = 0.f;
+      for (int k = 0; k < NS; ++k) d += part[k * Lq + q];
+      cdot[q] = d;
+    }
+  } else {
+    for (int q = threadIdx.x; q < Lq; q += 256) {
+      float d = 0.f;
+      for (int c = 0; c < Lc; ++c) d += to_f<T>(dScol[base + (int64_t)c * ldP + q]) * to_f<T>(Scol[base + (int64_t)c * ldP + q]);
+      cdot[q] = d;
+    }
   }
   __syncthreads();
   for (int c = wid; c < Lc; c += 4) {
@@ -267,12 +320,27 @@ __global__ __launch_bounds__(256) void cq_softmax_bwd_kernel(const T* __restrict
     if (lane == 0 && drow) drow[(int64_t)b * Lc + c] = rs;
   }
   __syncthreads();
-  if (dcol)
-    for (int q = threadIdx.x; q < Lq; q += 256) {
-      float cs = 0.f;
-      for (int c = 0; c < Lc; ++c) cs += tile[c * Lq + q];
-      dcol[(int64_t)b * Lq + q] = cs;
+  if (dcol) {
+    if (striped) {
+      if (pst < NS) {
+        float cs = 0.f;
+        for (int c = pst; c < Lc; c += NS) cs += tile[c * Lq + pq];
+        part[pst * Lq + pq] = cs;
+      }
+      __syncthreads();
+      for (int q = threadIdx.x; q < Lq; q += 256) {
+        float cs = 0.f;
+        for (int k = 0; k < NS; ++k) cs += part[k * Lq + q];
+        dcol[(int64_t)b * Lq + q] = cs;
+      }
+    } else {
+      for (int q = threadIdx.x; q < Lq; q += 256) {
+        float cs = 0.f;
+        for (int c = 0; c < Lc; ++c) cs += tile[c * Lq + q];
+        dcol[(int64_t)b * Lq + q] = cs;
+      }
     }
+  }
 }
 
 }  // namespace
@@ -281,10 +349,10 @@ extern "C" int vmr_cq_softmax_fwd(const float* S2, const float* rowterm, const f
                                   const float* qmask, void* Srow, void* Scol, int B, int Lc, int Lq, int ldS, int ldP,
                                   int dtype, void* stream) {
   VMR_CHECK(S2 && cmask && qmask && Srow && Scol, "vmr_cq_softmax_fwd: null pointer");
-  VMR_CHECK(Lc >= 1 && Lq >= 1 && ldS >= Lq && ldP >= Lq && (size_t)Lc * Lq * 4 <= 96 * 1024,
+  VMR_CHECK(Lc >= 1 && Lq >= 1 && ldS >= Lq && ldP >= Lq && ((size_t)Lc * Lq + 256 + Lq) * 4 <= 96 * 1024,
             "vmr_cq_softmax_fwd: score tile %dx%d does not fit LDS", Lc, Lq);
   if (B == 0) return 0;
-  const size_t lds = (size_t)Lc * Lq * 4;
+  const size_t lds = ((size_t)Lc * Lq + 256 + Lq) * 4;   // tile + column-stripe partials
   const void* fn = dtype == VMR_BF16 ? (const void*)cq_softmax_fwd_kernel<bf16_t> : (const void*)cq_softmax_fwd_kernel<float>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -304,10 +372,10 @@ extern "C" int vmr_cq_softmax_bwd(const void* dSrow, const void* dScol, const vo
                                   float* drow, float* dcol, int B, int Lc, int Lq, int ldS, int ldP, int dtype,
                                   void* stream) {
   VMR_CHECK(dSrow && dScol && Srow && Scol && dS2, "vmr_cq_softmax_bwd: null pointer");
-  VMR_CHECK(Lc >= 1 && Lq >= 1 && ldS >= Lq && ldP >= Lq && ((size_t)Lc * Lq + Lq) * 4 <= 96 * 1024,
+  VMR_CHECK(Lc >= 1 && Lq >= 1 && ldS >= Lq && ldP >= Lq && ((size_t)Lc * Lq + 2 * Lq + 256) * 4 <= 96 * 1024,
             "vmr_cq_softmax_bwd: score tile %dx%d does not fit LDS", Lc, Lq);
   if (B == 0) return 0;
-  const size_t lds = ((size_t)Lc * Lq + Lq) * 4;
+  const size_t lds = ((size_t)Lc * Lq + 2 * Lq + 256) * 4;   // dS tile + column dots + column-stripe partials
   const void* fn = dtype == VMR_BF16 ? (const void*)cq_softmax_bwd_kernel<bf16_t> : (const void*)cq_softmax_bwd_kernel<float>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
