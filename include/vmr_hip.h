@@ -166,6 +166,18 @@ int vmr_attention_fwd(const void* Q, const void* K, const void* V, void* O, void
                       int ldP, int cm_stride, float scale, int dtype, float drop_p,
                       uint32_t drop_seed, const uint32_t* drop_step, void* stream);
 
+/* ------------------------------------------------- fused attention (backward)
+ * dQ (+=), dK, dV of vmr_attention_fwd's O in ONE kernel per (z1,z2) slice: dP = dO.V^T, the softmax and
+ * dropout backward (mask regenerated from the forward's counter stream, Pkeep = the forward's
+ * pre-dropout probabilities), dQ = dS.K, dK = dS^T.Q, dV = P^T.dO -- replaces four batched vmr_gemm
+ * launches + vmr_softmax_bwd and the fp32 dP round trip.  strides[21] = {s1,s2,row} for
+ * Q,K,V,dO,dQ,dK,dV (elements, multiples of 8).  Supported: bf16, hd in {128,256}, Lq,Lk <= 128. */
+int vmr_attention_bwd_supported(int hd, int Lq, int Lk, int dtype);
+int vmr_attention_bwd(const void* dO, const void* Q, const void* K, const void* V, const void* Pkeep,
+                      void* dQ, void* dK, void* dV, const int64_t* strides, int Z1, int Z2, int Lq,
+                      int Lk, int hd, int ldP, float scale, int accumulate_dq, int dtype,
+                      float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream);
+
 /* ------------------------------------------------- CQAttention softmaxes
  * The two masked softmaxes of CQAttention (layers.py:419-421) over the trilinear
  * score S = S2 + rowterm[b,c] + colterm[b,q] (S2 from the batched MFMA GEMM, the

@@ -313,15 +313,15 @@ def test_fused_attention_equals_composed_path(dev, dims, p):
     g1 = torch.randn(N, D, device=dev).to(torch.bfloat16)
     g2 = torch.randn(N, D, device=dev).to(torch.bfloat16)
     res = {}
-    old = ops.FUSED_ATTENTION
+    old = ops.FUSED_ATTENTION, ops.FUSED_ATTENTION_BWD
     try:
-        for fused in (True, False):
-            ops.FUSED_ATTENTION = fused
+        for fused in (True, False):      # fused forward AND backward kernels vs the GEMM + softmax launches
+            ops.FUSED_ATTENTION = ops.FUSED_ATTENTION_BWD = fused
             so, xo = ops.dual_attention(qkv, kv, vmask, tmask, B, T, Lq, H, drops)
             gq, gk = torch.autograd.grad([so, xo], [qkv, kv], [g1, g2])
             res[fused] = (so, xo, gq, gk)
     finally:
-        ops.FUSED_ATTENTION = old
+        ops.FUSED_ATTENTION, ops.FUSED_ATTENTION_BWD = old
     assert ops.L.lib().vmr_attention_fwd_supported(D // H, T, 1)
     for a, b, what in zip(res[True], res[False], ("self ctx", "cross ctx", "dqkv", "dkv")):
         _close(a, b, 1.5e-2, "fused vs composed " + what)
@@ -337,6 +337,9 @@ def test_fused_attention_rejects_unsupported_shapes(dev):
     assert lib.vmr_attention_fwd_supported(256, 129, 1) == 0
     assert lib.vmr_attention_fwd_supported(64, 20, 1) == 0
     assert lib.vmr_attention_fwd_supported(256, 20, 0) == 0   # fp32 goes through the composed path
+    assert lib.vmr_attention_bwd_supported(256, 128, 128, 1) == 1
+    assert lib.vmr_attention_bwd_supported(256, 129, 20, 1) == 0
+    assert lib.vmr_attention_bwd_supported(64, 20, 20, 1) == 0
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])

@@ -115,6 +115,7 @@ def bmm4(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, ta: int, tb: int, *,
 SPLITK_TARGET = int(os.environ.get("VMR_SPLITK_TARGET", "512"))   # workgroups to aim for in dW products
 USE_SLABS = os.environ.get("VMR_SPLITK_SLABS", "1") != "0"
 FUSED_ATTENTION = os.environ.get("VMR_FUSED_ATTN", "1") != "0"   # csrc/attention.hip forward (bf16, hd 128/256)
+FUSED_ATTENTION_BWD = os.environ.get("VMR_FUSED_ATTN_BWD", "1") != "0"   # csrc/attention_bwd.hip
 
 
 def splitk_for(M: int, N: int, K: int) -> int:
@@ -645,9 +646,19 @@ def _attend_fwd(q4, k4, v4, o4, rmask, cmask, mode, H, cm_stride, scale, drop):
 
 
 def _attend_bwd(do4, q4, k4, v4, P, Pk, dq4, dk4, dv4, scale, drop, accumulate_dq):
-    Z1, Z2, R, _ = q4.shape
+    Z1, Z2, R, hd = q4.shape
     Ck = k4.shape[2]
     ld = P.shape[3]
+    ts = (q4, k4, v4, do4, dq4, dk4, dv4)
+    if FUSED_ATTENTION_BWD and L.lib().vmr_attention_bwd_supported(hd, R, Ck, L.dtype_code(q4)) and all(
+            t.stride(3) == 1 and all(s % 8 == 0 for s in t.stride()[:3]) for t in ts):
+        # one kernel per slice: dP, softmax/dropout backward, dQ, dK, dV (csrc/attention_bwd.hip)
+        strides = (C.c_int64 * 21)(*[s for t in ts for s in t.stride()[:3]])
+        L.check(L.lib().vmr_attention_bwd(do4.data_ptr(), q4.data_ptr(), k4.data_ptr(), v4.data_ptr(), Pk.data_ptr(),
+                                          dq4.data_ptr(), dk4.data_ptr(), dv4.data_ptr(), strides, Z1, Z2, R, Ck, hd, ld,
+                                          scale, 1 if accumulate_dq else 0, L.dtype_code(q4), drop[0], drop[1],
+                                          _ptr(drop[2]), L.stream_ptr()), "vmr_attention_bwd")
+        return
     bmm4(P[..., :Ck], do4, dv4, 1, 1)                                   # dV = P^T . dO
     dP = torch.empty(Z1, Z2, R, ld, device=q4.device, dtype=torch.float32)
     bmm4(do4, v4, dP[..., :Ck], 0, 0)                                   # dP = dO . V^T
