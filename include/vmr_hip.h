@@ -87,6 +87,11 @@ typedef struct {
    * residual row per group of res_div consecutive rows (a per-clip term added to all T tokens of the
    * clip: the pooled-query half of CQConcatenate, layers.py:462-468, without materialising the cat). */
   int32_t res_div;
+  /* bias gradient for free: with transA (A stored [K][M], the weight-gradient product dW = dz^T.x) the call
+   * also ACCUMULATES a_colsum[m] += sum_k A[k][m] (fp32) -- inside the LDS-DMA kernel as one extra MFMA per
+   * A fragment against a ones operand in the first column tile, otherwise by a column-sum launch.
+   * Replaces the separate bias-gradient pass over dz (layers.py:15-26 backward).  Z1*Z2 must be 1. */
+  float* a_colsum;
 } vmr_gemm_t;
 
 int vmr_gemm(const vmr_gemm_t* g, void* stream);

@@ -40,7 +40,8 @@ class GemmDesc(C.Structure):
                 ("sC1", C.c_int64), ("sC2", C.c_int64),
                 ("splitk", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
                 ("drop_row0", C.c_uint32), ("drop_step", C.c_void_p),
-                ("bias2", C.c_void_p), ("bias_scale", C.c_float), ("res_div", C.c_int32)]
+                ("bias2", C.c_void_p), ("bias_scale", C.c_float), ("res_div", C.c_int32),
+                ("a_colsum", C.c_void_p)]
 
 
 _lib = None

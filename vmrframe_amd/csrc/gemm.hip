@@ -546,6 +546,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
   // of iteration kt+1, beside that iteration's first reads).
   constexpr int NKK = BK / 32;
   bf16x8 fa[2][MT], fb[2][4];
+  // bias gradient of the weight-gradient product (TA): column sums of A^T = one more MFMA per A fragment against
+  // a ones operand, in the waves that own the first 64 columns of the first column tile
+  constexpr int NCS = TA ? MT : 1;
+  f32x4 accdb[NCS];
+#pragma unroll
+  for (int i = 0; i < NCS; ++i) accdb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool colsum = TA && g.a_colsum != nullptr && tc.tn == 0 && wn == 0;   // wave-uniform
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
   auto mma = [&](int buf) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -553,6 +563,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0);  // C^T tile
+    if constexpr (TA) {
+      if (colsum) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) accdb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[buf][i], accdb[i], 0, 0, 0);
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
   };
   for (int kt = 0; kt < nk; ++kt) {
@@ -584,6 +600,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
     }
   }
   if (nk > 0) mma((NKK - 1) & 1);
+  if constexpr (TA) {
+    if (colsum && lane < 16) {   // every row of the ones-product holds the column sums: lanes 0..15 carry m = lane
+#pragma unroll
+      for (int i = 0; i < MT; ++i) atomicAdd(&g.a_colsum[m0 + wm * (MT * 16) + i * 16 + lane], accdb[i][0]);
+    }
+  }
   if (direct) {
     epilogue_direct<MT>(g, acc, wm, wn, lane, m0, n0, tc.zb,
                     (g.flags & VMR_EPI_OUT_F32) ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
@@ -951,6 +973,7 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   VMR_CHECK(!(g.flags & VMR_EPI_BIAS) || g.bias, "vmr_gemm: bias flag without pointer");
   if (g.bias_scale == 0.f) g.bias_scale = 1.f;
   if (g.res_div <= 0) g.res_div = 1;
+  VMR_CHECK(!g.a_colsum || (g.transA && g.Z1 * g.Z2 == 1), "vmr_gemm: a_colsum needs transA and Z1*Z2 == 1");
   VMR_CHECK(g.res_div == 1 || !(g.flags & VMR_EPI_AUX), "vmr_gemm: res_div with aux (aux shares ldr) is not supported");
   VMR_CHECK(!(g.flags & VMR_EPI_RESIDUAL) || g.residual, "vmr_gemm: residual flag without pointer");
   VMR_CHECK(!(g.flags & VMR_EPI_AUX) || g.aux, "vmr_gemm: aux flag without pointer");
@@ -987,7 +1010,7 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   const bool dma_ok = g_gemm_dma && al && g.dtype == VMR_BF16 && g.M % BM == 0 && g.N % BN == 0 && g.K % 64 == 0 &&
                       g.K >= 128 * g.splitk &&
                       (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));   // the direct epilogue loads bias as float4
-  if (dma_ok && g_gemm_dma >= 3 && g.M >= 256 && g.res_div == 1) {
+  if (dma_ok && g_gemm_dma >= 3 && g.M >= 256 && g.res_div == 1 && !g.a_colsum) {
     // 256x128 tiles for the rows that fill whole rounds of the 256 CUs; the ragged remainder (e.g. the
     // 1280 query-token rows of a packed [8192 | 1280] matrix) goes to the 128x128 kernel instead of
     // costing a second, nearly empty round of big tiles.
@@ -1070,7 +1093,15 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
     }
   }
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)Z);
+  float* colsum_fallback = nullptr;
+  if (g.a_colsum && !dma_ok) {   // only the LDS-DMA kernel folds the column sums into the product
+    colsum_fallback = g.a_colsum;
+    g.a_colsum = nullptr;
+  }
   hipLaunchKernelGGL(pk.fn, grid, dim3(256), pk.smem, (hipStream_t)stream, g, tiles_m, tiles_n);
   VMR_LAUNCH_CHECK();
+  if (colsum_fallback)   // A is stored [K][M]: a plain column-sum pass (vmr_relu_bwd_bias mode 0 accumulates)
+    return vmr_relu_bwd_bias(0, g.A, nullptr, nullptr, colsum_fallback, g.K, g.M, g.lda, 1.0f, g.dtype, 0.f, 0, nullptr, nullptr,
+                             1.0f, stream);
   return 0;
 }

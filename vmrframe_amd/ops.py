@@ -61,7 +61,7 @@ class DropCtx:
 # ---------------------------------------------------------------------------
 def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=None, residual=None, aux=None,
          ldr=0, rowscale=None, alpha=1.0, Z1=1, Z2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, drop=NO_DROP,
-         bias2=None, bias_scale=1.0, res_div=1):
+         bias2=None, bias_scale=1.0, res_div=1, a_colsum=None):
     d = L.GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cmat.data_ptr()
     d.bias, d.residual, d.aux, d.rowscale = _ptr(bias), _ptr(residual), _ptr(aux), _ptr(rowscale)
@@ -76,6 +76,7 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
     d.drop_p, d.drop_seed = drop[0], drop[1]
     d.drop_step = _ptr(drop[2])
     d.bias2, d.bias_scale, d.res_div = _ptr(bias2), bias_scale, res_div
+    d.a_colsum = _ptr(a_colsum)
     if GEMM_HOOK is not None:
         GEMM_HOOK(lambda: L.check(L.lib().vmr_gemm(C.byref(d), L.stream_ptr()), "vmr_gemm"), M, N, K, ta, tb,
                   Z1 * Z2, dtype)
@@ -322,6 +323,7 @@ class _Linear(torch.autograd.Function):
         dt = L.dtype_code(dyb)
         lib, st = L.lib(), L.stream_ptr()
         scale = 1.0 / (1.0 - drop[0]) if drop[0] > 0 else 1.0
+        colsum_in_gemm = False
         bgrad = main_grad(ctx.bias_param) if (has_bias and Np == N) else None
         has_b2 = ctx.bias2_param is not None
         if has_b2 and (bgrad is None or main_grad(ctx.bias2_param) is None):
@@ -340,7 +342,12 @@ class _Linear(torch.autograd.Function):
                                           drop[0], drop[1], _ptr(drop[2]), _ptr(db2), dbs, st), "vmr_relu_bwd_bias")
         else:
             dzb = dyb
-            if has_bias:
+            # plain linear layer: the bias gradient (column sums of dz) rides on the weight-gradient GEMM below
+            # (vmr_gemm_t.a_colsum) when that GEMM accumulates straight into the arena
+            colsum_in_gemm = (has_bias and bgrad is not None and db2 is None and
+                              all(main_grad(w) is not None for w in ctx.weights) and
+                              (ctx.kslice is not None or all(int(np.prod(shp[1:])) == x.shape[1] for shp in wshapes)))
+            if has_bias and not colsum_in_gemm:
                 L.check(lib.vmr_relu_bwd_bias(0, dyb.data_ptr(), None, None, db.data_ptr(), M, Np, Np, 1.0, dt, 0.0, 0,
                                               None, _ptr(db2), dbs, st), "vmr_relu_bwd_bias")
         dz = dzb[:, :N] if Np != N else dzb
@@ -372,12 +379,12 @@ class _Linear(torch.autograd.Function):
                         # every workgroup of a single-round grid land together and run far below HBM speed
                         ws = torch.empty(sk_, n, Kp, device=dy.device, dtype=torch.float32)
                         gemm(a, x, ws, n, Kp, M, 1, 1, a.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_SLAB,
-                             splitk=sk_)
+                             splitk=sk_, a_colsum=db[r:r + n] if colsum_in_gemm else None)
                         L.check(lib.vmr_splitk_reduce(ws.data_ptr(), g_.data_ptr(), sk_, n * Kp, Kp, kf,
                                                       L.stream_ptr()), "vmr_splitk_reduce")
                     else:
                         gemm(a, x, g_, n, Kp, M, 1, 1, a.stride(0), x.stride(0), kf, dtype=dt, flags=L.EPI_ACCUM,
-                             splitk=sk_)
+                             splitk=sk_, a_colsum=db[r:r + n] if colsum_in_gemm else None)
                     r += n
             if db is not None and Np != N:
                 db = db[:N]
