@@ -271,6 +271,20 @@ int vmr_infer_basic(const float* slogits, const float* elogits, const float* vma
                     int B, int T, void* stream);
 int vmr_iou_metrics(const float* props, const float* gts, float* ious, double* acc, int n, void* stream);
 
+/* ------------------------------------------------------------ narrow heads
+ * Conv1D with N <= 8 output channels (match head N = 4: models/SeqPAN.py:41,78; start / end heads N = 1:
+ * layers.py:659-671) as bandwidth-bound matrix-vector kernels instead of a >= 94 %-padded MFMA tile.
+ * fwd: y[m,0:N] (fp32, dense [M,N]) = x[m,:] . W[n,:]^T + bias;  x: [M,K] dtype with row stride ldx; W: fp32 [N,K].
+ * bwd: dx[m,:] = sum_n dy[m,n] W[n,:] (dtype, dense [M,K], nullable) and dW (fp32 [N,K]) / db ([N], nullable)
+ *      are ACCUMULATED (two-stage through `workspace`, VMR_NARROW_WS_FLOATS(M,N,K) fp32, caller-owned
+ *      scratch).  K %% 8 == 0, K <= 2048. */
+#define VMR_NARROW_WS_FLOATS(M, N, K) \
+  ((((int64_t)(M) + 127) / 128) * ((K) >= 2048 ? 1 : 256 / ((K) / 8)) * ((int64_t)(N) * (K) + (N)))
+int vmr_narrow_linear_fwd(const void* x, const float* W, const float* bias, float* y, int64_t M, int N,
+                          int K, int64_t ldx, int dtype, void* stream);
+int vmr_narrow_linear_bwd(const float* dy, const void* x, const float* W, void* dx, float* dW, float* db,
+                          float* workspace, int64_t M, int N, int K, int64_t ldx, int dtype, void* stream);
+
 /* --------------------------------------------------------------- optimizer
  * fused AdamW over a flat fp32 parameter arena (utils/utils.py:87-97:
  * AdamW, weight_decay 0.01 except names containing bias/layer_norm) with the

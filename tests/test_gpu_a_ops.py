@@ -393,6 +393,28 @@ def test_linear_column_slices_and_row_broadcast_residual(dev, dt, tol):
     _close(ga, ra, tol, "da"); _close(gp, rp, tol, "dpooled"); _close(gW, rW, tol, "dW"); _close(gb, rb, tol, "db")
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dims", [(8192, 1, 1024), (8192, 4, 1024), (50, 8, 32), (3, 3, 2048), (129, 1, 8)])
+def test_narrow_linear_fwd_bwd(dev, dt, tol, dims):
+    """The N <= 8 output heads (match N=4, start/end N=1) on the matrix-vector kernels vs torch."""
+    ops = _ops()
+    M, N, K = dims
+    torch.manual_seed(23)
+    x = torch.randn(M, K, device=dev).to(dt).requires_grad_(True)
+    W = (torch.randn(N, K, 1, device=dev) / math.sqrt(K)).requires_grad_(True)
+    b = torch.randn(N, device=dev, requires_grad=True)
+    y = ops.narrow_linear(x, W, b)
+    assert y.dtype == torch.float32 and y.shape == (M, N)
+    xr = x.detach().float().requires_grad_(True)
+    Wr, br = W.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    ref = xr @ Wr[:, :, 0].t() + br
+    _close(y, ref, 1e-4 if dt == torch.float32 else 1e-3, "y")     # fp32 accumulation of exact bf16 inputs
+    g = torch.randn_like(ref)
+    gx, gW, gb = torch.autograd.grad(y, [x, W, b], g)
+    rx, rW, rb = torch.autograd.grad(ref, [xr, Wr, br], g)
+    _close(gx, rx, tol, "dx"); _close(gW, rW, 2e-4 if dt == torch.float32 else 2e-3, "dW"); _close(gb, rb, 1e-4, "db")
+
+
 def test_soft_ce_matches_torch(dev):
     ops = _ops()
     torch.manual_seed(6)

@@ -252,6 +252,10 @@ class SeqPAN(nn.Module):
     def _lin(self, x, prefix, **kw):
         return ops.linear(x, self.P(prefix + ".conv1d.weight"), self.P(prefix + ".conv1d.bias"), self._cache, **kw)
 
+    def _head(self, x, prefix):
+        """Conv1D with <= 8 output channels -> fp32 logits (matrix-vector kernels, ops.narrow_linear)."""
+        return ops.narrow_linear(x, self.P(prefix + ".conv1d.weight"), self.P(prefix + ".conv1d.bias"))
+
     def _lin_cat2(self, a, b, prefix):
         """Conv1D(cat([a, b], 1)) without the concat: a.W[:, :D]^T + b.W[:, D:]^T + bias."""
         W, bias = self.P(prefix + ".conv1d.weight"), self.P(prefix + ".conv1d.bias")
@@ -416,7 +420,7 @@ class SeqPAN(nn.Module):
         pq = ops.linear(pooled, Wc, bc, self._cache, kslice=(D, 2 * D))           # [B, D]
         fuse = ops.linear(t2v, Wc, None, self._cache, kslice=(0, D), residual=pq, res_div=T)
         # match head (reference models/SeqPAN.py:78-82)
-        mlogits = self._lin(fuse, "match_conv1d").float().reshape(B, T, 4)
+        mlogits = self._head(fuse, "match_conv1d").reshape(B, T, 4)
         if self.gumbel_override is not None:
             g = self.gumbel_override.to(mlogits.device)
         else:
@@ -435,8 +439,8 @@ class SeqPAN(nn.Module):
         # accumulates through the residual input): no [Nv, 2D] concat copies
         sh = self._lin_cat2(sn, fuse2, "predictor.start_hidden")
         eh = self._lin_cat2(en, fuse2, "predictor.end_hidden")
-        slogits = self._lin(sh, "predictor.start_dense").float().reshape(B, T)
-        elogits = self._lin(eh, "predictor.end_dense").float().reshape(B, T)
+        slogits = self._head(sh, "predictor.start_dense").reshape(B, T)
+        elogits = self._head(eh, "predictor.end_dense").reshape(B, T)
         self.last_drop_sites = dc.sites
 
         if self.sync_timing:

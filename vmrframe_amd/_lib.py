@@ -64,6 +64,8 @@ SIGNATURES = {
     "vmr_iou_metrics": [_P, _P, _P, _P, _I, _P],
     "vmr_attention_bwd_supported": [_I, _I, _I, _I],
     "vmr_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _F, _U, _P, _P],
+    "vmr_narrow_linear_fwd": [_P, _P, _P, _P, _L, _I, _I, _L, _I, _P],
+    "vmr_narrow_linear_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P],
     "vmr_cq_softmax_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_cq_softmax_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_soft_ce_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],

@@ -2,6 +2,7 @@
 //   * WeightedPool (reference models/layers.py:440-453): alpha = softmax_l(x.w + mask), pooled = sum_l alpha*x
 //   * infer_basic (utils/engine.py:28-44) and the IoU / R1@k / mIoU bookkeeping of the train and eval loops
 //     (utils/utils.py:161-185, models/loss.py:83-109)   [SURVEY.md 8f, row N4]
+//   * the narrow (N <= 8) output heads as matrix-vector kernels
 // One workgroup per clip; rows are reduced by waves, columns by threads.  fp32 math, activations
 // in the compute dtype.
 #include "common.h"
@@ -269,6 +270,207 @@ extern "C" int vmr_weighted_pool_bwd(const void* dpooled, const void* x, const f
   else
     hipLaunchKernelGGL((weighted_pool_bwd_kernel<float>), dim3(B), dim3(256), 0, (hipStream_t)stream,
                        (const float*)dpooled, (const float*)x, w, alpha, (float*)dx, dw, L, D);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ narrow heads
+// y[m, 0:N] = x[m, :] . W[n, :]^T + b  for N <= 8 output channels (match head N = 4, start / end heads
+// N = 1; reference models/SeqPAN.py:41,78 and layers.py:659-671 through Conv1D, layers.py:15-26).  A
+// 128-wide MFMA tile would be >= 94 % padding: these are bandwidth-bound matrix-vector products.
+// fwd: W (fp32 masters) staged in LDS once per workgroup, one wave per row, fp32 logits out.
+// bwd: a streaming dx kernel (W in LDS) and a row-slab reduction that ACCUMULATES dW / db (fp32; 8 rows in flight per thread).
+namespace {
+
+constexpr int NL_MAXN = 8;
+
+template <typename T, int N>
+__global__ __launch_bounds__(256) void narrow_fwd_kernel(const T* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int64_t M,
+                                                         int K, int64_t ldx, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Ws = reinterpret_cast<float*>(smem);   // [N][K]
+  for (int i = threadIdx.x * 4; i < N * K; i += 1024) *reinterpret_cast<f32x4*>(Ws + i) = *reinterpret_cast<const f32x4*>(W + i);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  for (int64_t m = r0 + wid; m < min(M, r0 + rows_per_block); m += 4) {
+    float acc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = 0.f;
+    for (int i = lane * 8; i < K; i += 512) {
+      float xv[8];
+      Vec8<T>::load(x + m * ldx + i, xv);
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        float wv[8];
+        Vec8<float>::load(Ws + n * K + i, wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[n] += xv[e] * wv[e];
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = wave_sum(acc[n]);
+    if (lane == 0) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) y[m * N + n] = acc[n] + (bias ? bias[n] : 0.f);
+    }
+  }
+}
+
+// dx[m, chunk] = sum_n dy[m,n] * W[n, chunk]: pure streaming, one thread per (row, 8-column chunk), W in LDS
+template <typename T, int N>
+__global__ __launch_bounds__(256) void narrow_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                                        T* __restrict__ dx, int64_t M, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Ws = reinterpret_cast<float*>(smem);   // [N][K]
+  for (int i = threadIdx.x * 4; i < N * K; i += 1024) *reinterpret_cast<f32x4*>(Ws + i) = *reinterpret_cast<const f32x4*>(W + i);
+  __syncthreads();
+  const int cpr = K / 8;
+  const int64_t total = M * cpr;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t m = idx / cpr;
+    const int c = (int)(idx - m * cpr) * 8;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const float g = dy[m * N + n];
+      float wv[8];
+      Vec8<float>::load(Ws + n * K + c, wv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += g * wv[e];
+    }
+    Vec8<T>::store(dx + m * K + c, o);
+  }
+}
+
+// dW[n, chunk] += sum_m dy[m,n] * x[m, chunk], db[n] += sum_m dy[m,n]: thread = one 8-column chunk over a slab of
+// rows, 8 rows in flight per thread (the loop is latency-bound otherwise), one atomic per output per workgroup row group
+template <typename T, int N>
+__global__ __launch_bounds__(256) void narrow_dw_kernel(const float* __restrict__ dy, const T* __restrict__ x,
+                                                        float* __restrict__ part, int64_t M, int K, int64_t ldx,
+                                                        int rows_per_block) {
+  const int cpr = K / 8;                         // chunks per row
+  const int groups = max(1, 256 / cpr);          // row groups working in parallel
+  const int chunk = threadIdx.x % cpr, grp = threadIdx.x / cpr;
+  if (grp >= groups) return;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float gw[N][8], gb[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    gb[n] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gw[n][e] = 0.f;
+  }
+  typedef __attribute__((ext_vector_type(8))) T TV8;
+  for (int64_t mb = r0 + grp; mb < r1; mb += (int64_t)groups * 8) {
+    TV8 xr[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {      // 8 independent row loads in flight (clamped; masked below)
+      const int64_t m = min(mb + (int64_t)u * groups, M - 1);
+      xr[u] = *reinterpret_cast<const TV8*>(x + m * ldx + chunk * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t m = mb + (int64_t)u * groups;
+      if (m >= r1) continue;
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        const float g = dy[m * N + n];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gw[n][e] += g * (float)xr[u][e];
+        if (chunk == 0) gb[n] += g;
+      }
+    }
+  }
+  // one partial row [N*K + N] per (workgroup, row group): float atomics from every workgroup onto the same
+  // N*K addresses serialise in L2 (measured 40-70 us for 131-524 k atomics); a second stage sums the rows
+  float* prow = part + ((int64_t)blockIdx.x * groups + grp) * ((int64_t)N * K + N);
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    Vec8<float>::store(prow + (int64_t)n * K + chunk * 8, gw[n]);
+    if (chunk == 0) prow[(int64_t)N * K + n] = gb[n];
+  }
+}
+
+// out[j] += sum_r part[r][j]   (j < nk: dW, else db): blockIdx.y takes 16 partial rows (16 independent loads in
+// flight per thread), so only nrows/16 adders meet on an address
+__global__ __launch_bounds__(256) void narrow_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
+                                                            float* __restrict__ db, int nrows, int nk, int nb) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= nk + nb) return;
+  const int r0 = blockIdx.y * 16;
+  float v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = (r0 + k < nrows) ? part[(int64_t)(r0 + k) * (nk + nb) + j] : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += v[k];
+  if (j < nk) atomicAdd(&dW[j], s);
+  else if (db) atomicAdd(&db[j - nk], s);
+}
+
+template <typename T>
+int launch_narrow_fwd(int N, dim3 grid, size_t lds, hipStream_t st, const void* x, const float* W, const float* bias, float* y,
+                      int64_t M, int K, int64_t ldx, int rpb) {
+#define VMR_NF(NN) hipLaunchKernelGGL((narrow_fwd_kernel<T, NN>), grid, dim3(256), lds, st, (const T*)x, W, bias, y, M, K, ldx, rpb)
+  switch (N) {
+    case 1: VMR_NF(1); break; case 2: VMR_NF(2); break; case 3: VMR_NF(3); break; case 4: VMR_NF(4); break;
+    case 5: VMR_NF(5); break; case 6: VMR_NF(6); break; case 7: VMR_NF(7); break; default: VMR_NF(8); break;
+  }
+#undef VMR_NF
+  return 0;
+}
+
+constexpr int NL_RPB = 128;   // rows per workgroup of the dW reduction
+template <typename T>
+int launch_narrow_bwd(int N, hipStream_t st, const float* dy, const void* x, const float* W, void* dx, float* dW, float* db,
+                      float* ws, int64_t M, int K, int64_t ldx) {
+  const dim3 gw((unsigned)((M + NL_RPB - 1) / NL_RPB));
+  const dim3 gx((unsigned)min((int64_t)4096, (M * (K / 8) + 255) / 256));
+  const size_t lds = (size_t)N * K * 4;
+  const int groups = max(1, 256 / (K / 8));
+#define VMR_NB(NN)                                                                                                    \
+  do {                                                                                                                \
+    if (dx) hipLaunchKernelGGL((narrow_dx_kernel<T, NN>), gx, dim3(256), lds, st, dy, W, (T*)dx, M, K);                \
+    hipLaunchKernelGGL((narrow_dw_kernel<T, NN>), gw, dim3(256), 0, st, dy, (const T*)x, ws, M, K, ldx, NL_RPB);       \
+  } while (0)
+  switch (N) {
+    case 1: VMR_NB(1); break; case 2: VMR_NB(2); break; case 3: VMR_NB(3); break; case 4: VMR_NB(4); break;
+    case 5: VMR_NB(5); break; case 6: VMR_NB(6); break; case 7: VMR_NB(7); break; default: VMR_NB(8); break;
+  }
+#undef VMR_NB
+  hipLaunchKernelGGL(narrow_reduce_kernel, dim3(cdiv(N * K + N, 256), cdiv((int)gw.x * groups, 16)), dim3(256), 0, st, ws, dW, db,
+                     (int)gw.x * groups, N * K, N);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vmr_narrow_linear_fwd(const void* x, const float* W, const float* bias, float* y, int64_t M, int N, int K,
+                                     int64_t ldx, int dtype, void* stream) {
+  VMR_CHECK(x && W && y, "vmr_narrow_linear_fwd: null pointer");
+  VMR_CHECK(N >= 1 && N <= NL_MAXN && K % 8 == 0 && ldx % 8 == 0 && ldx >= K && (size_t)N * K * 4 <= 64 * 1024,
+            "vmr_narrow_linear_fwd: need 1 <= N <= 8, K %% 8 == 0, N*K*4 <= 64 KiB (N=%d K=%d)", N, K);
+  if (M == 0) return 0;
+  const int rpb = 32;
+  dim3 grid((unsigned)((M + rpb - 1) / rpb));
+  const size_t lds = (size_t)N * K * 4;
+  if (dtype == VMR_BF16) launch_narrow_fwd<bf16_t>(N, grid, lds, (hipStream_t)stream, x, W, bias, y, M, K, ldx, rpb);
+  else launch_narrow_fwd<float>(N, grid, lds, (hipStream_t)stream, x, W, bias, y, M, K, ldx, rpb);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_narrow_linear_bwd(const float* dy, const void* x, const float* W, void* dx /*nullable*/, float* dW,
+                                     float* db /*nullable*/, float* workspace, int64_t M, int N, int K, int64_t ldx,
+                                     int dtype, void* stream) {
+  VMR_CHECK(dy && x && W && dW && workspace, "vmr_narrow_linear_bwd: null pointer");
+  VMR_CHECK(N >= 1 && N <= NL_MAXN && K % 8 == 0 && K <= 2048 && ldx % 8 == 0 && ldx >= K && (size_t)N * K * 4 <= 64 * 1024,
+            "vmr_narrow_linear_bwd: need 1 <= N <= 8, K %% 8 == 0, K <= 2048, N*K*4 <= 64 KiB (N=%d K=%d)", N, K);
+  if (M == 0) return 0;
+  if (dtype == VMR_BF16) launch_narrow_bwd<bf16_t>(N, (hipStream_t)stream, dy, x, W, dx, dW, db, workspace, M, K, ldx);
+  else launch_narrow_bwd<float>(N, (hipStream_t)stream, dy, x, W, dx, dW, db, workspace, M, K, ldx);
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -33,6 +33,10 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _cdiv(x: int, m: int) -> int:
+    return (x + m - 1) // m
+
+
 def _rup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -463,6 +467,50 @@ class _WeightedPool(torch.autograd.Function):
 def weighted_pool(x, w, mask):
     """x [B,L,D] (compute dtype), w [D,1] fp32 parameter, mask [B,L] fp32 -> pooled [B,D]."""
     return _WeightedPool.apply(x, w, mask.contiguous())
+
+
+class _NarrowLinear(torch.autograd.Function):
+    """Conv1D with <= 8 output channels (the match / start / end heads) on the matrix-vector kernels:
+    fp32 logits [M, N] straight from the compute-dtype features, one backward pass for dx, dW, db."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        L.require_gpu(x, W)
+        assert x.dim() == 2 and x.stride(1) == 1
+        M, K = x.shape
+        N = W.shape[0]
+        Wm = W.detach().reshape(N, -1)
+        assert Wm.shape[1] == K and Wm.is_contiguous()
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        L.check(L.lib().vmr_narrow_linear_fwd(x.data_ptr(), Wm.data_ptr(), _ptr(bias), y.data_ptr(), M, N, K, x.stride(0),
+                                              L.dtype_code(x), L.stream_ptr()), "vmr_narrow_linear_fwd")
+        ctx.save_for_backward(x, W, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, bias = ctx.saved_tensors
+        M, K = x.shape
+        N = W.shape[0]
+        dy = dy.contiguous().float()
+        dx = torch.empty(M, K, device=x.device, dtype=x.dtype) if ctx.needs_input_grad[0] else None
+        gW, gb = main_grad(W), (main_grad(bias) if bias is not None else None)
+        dW = gW if gW is not None else torch.zeros(N, K, device=x.device, dtype=torch.float32)
+        db = None
+        if bias is not None:
+            db = gb if gb is not None else torch.zeros(N, device=x.device, dtype=torch.float32)
+        groups = max(1, 256 // (K // 8))
+        ws = torch.empty(_cdiv(M, 128) * groups * (N * K + N), device=x.device, dtype=torch.float32)
+        L.check(L.lib().vmr_narrow_linear_bwd(dy.data_ptr(), x.data_ptr(), W.detach().reshape(N, -1).data_ptr(), _ptr(dx),
+                                              dW.data_ptr(), _ptr(db), ws.data_ptr(), M, N, K, x.stride(0),
+                                              L.dtype_code(x), L.stream_ptr()), "vmr_narrow_linear_bwd")
+        return (dx, None if gW is not None else dW.reshape(W.shape),
+                None if (bias is None or gb is not None) else db)
+
+
+def narrow_linear(x, W, bias):
+    """x [M,K] (compute dtype) . W[N,K(,1)]^T + bias -> fp32 [M,N], N <= 8."""
+    return _NarrowLinear.apply(x, W, bias)
 
 
 def group_view(params):
