@@ -285,6 +285,26 @@ int vmr_narrow_linear_fwd(const void* x, const float* W, const float* bias, floa
 int vmr_narrow_linear_bwd(const float* dy, const void* x, const float* W, void* dx, float* dW, float* db,
                           float* workspace, int64_t M, int N, int K, int64_t ldx, int dtype, void* stream);
 
+/* ------------------------------------------------- match head + its loss
+ * vmr_gumbel_softmax_fwd/bwd: F.gumbel_softmax(logits, tau) of models/SeqPAN.py:79 over C <= 8 classes:
+ *   probs = softmax((logits + g)/tau), g = -log(Exp(1)) noise -- given (`noise`, fp32 [R,C]) or drawn in the
+ *   kernel from the counter hash (seed, optional device step counter: hipGraph replay draws fresh noise).
+ *   `padded` (nullable, dtype [R,ldo]) receives the same probabilities zero-padded to ldo columns (the
+ *   operand of the label-embedding product, models/SeqPAN.py:80-82).  bwd: dlogits from dprobs and/or dpadded.
+ * vmr_match_loss_fwd/bwd: lossfun_match (models/loss.py:24-41): sum_r -probs[r,label[r]]*vmask[r] /
+ *   (sum_r vmask[r] + 1e-12) + || offdiag(E^T E) ||_F, E = label_embs fp32 [D,C].  aux: fp32 [C*C + 4]
+ *   (Gram matrix, norm, denominator, 2 scratch) kept for the backward; dE is ACCUMULATED. */
+int vmr_gumbel_softmax_fwd(const float* logits, const float* noise /*nullable*/, float tau, uint32_t seed,
+                           const uint32_t* step, float* probs, void* padded, int64_t R, int C, int ldo,
+                           int dtype, void* stream);
+int vmr_gumbel_softmax_bwd(const float* dprobs /*nullable*/, const void* dpadded /*nullable*/,
+                           const float* probs, float tau, float* dlogits, int64_t R, int C, int ldo,
+                           int dtype, void* stream);
+int vmr_match_loss_fwd(const float* probs, const int64_t* labels, const float* vmask, const float* E,
+                       float* loss, float* aux, int64_t R, int D, int C, void* stream);
+int vmr_match_loss_bwd(const float* dloss, const int64_t* labels, const float* vmask, const float* E,
+                       const float* aux, float* dprobs, float* dE, int64_t R, int D, int C, void* stream);
+
 /* --------------------------------------------------------------- optimizer
  * fused AdamW over a flat fp32 parameter arena (utils/utils.py:87-97:
  * AdamW, weight_decay 0.01 except names containing bias/layer_norm) with the

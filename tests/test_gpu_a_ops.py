@@ -415,6 +415,48 @@ def test_narrow_linear_fwd_bwd(dev, dt, tol, dims):
     _close(gx, rx, tol, "dx"); _close(gW, rW, 2e-4 if dt == torch.float32 else 2e-3, "dW"); _close(gb, rb, 1e-4, "db")
 
 
+def test_gumbel_softmax_and_match_loss(dev):
+    """vmr_gumbel_softmax_* and vmr_match_loss_* against torch (explicit noise), and the statistics of the
+    in-kernel noise (reference models/SeqPAN.py:79, models/loss.py:24-41)."""
+    ops = _ops()
+    torch.manual_seed(29)
+    R, Cc, D = 777, 4, 64
+    logits = torch.randn(R, Cc, device=dev, requires_grad=True)
+    noise = -torch.empty(R, Cc, device=dev).exponential_().log()
+    E = torch.randn(D, Cc, device=dev, requires_grad=True)
+    labels = torch.randint(0, Cc, (R,), device=dev)
+    vmask = (torch.rand(R, device=dev) > 0.3).float()
+    probs, padded = ops.gumbel_softmax(logits, noise, 0.3, 1, None, 8, torch.bfloat16)
+    lr = logits.detach().clone().requires_grad_(True)
+    Er = E.detach().clone().requires_grad_(True)
+    pref = torch.softmax((lr + noise) / 0.3, dim=-1)
+    _close(probs, pref, 1e-5, "probs")
+    assert padded.shape == (R, 8) and (padded[:, 4:] == 0).all()
+    _close(padded[:, :4], pref, 1e-2, "padded")
+    loss = ops.match_loss(probs.view(1, R, Cc), E, labels.view(1, R), vmask.view(1, R))
+    onehot = torch.nn.functional.one_hot(labels, Cc).float()
+    lref = (-(onehot * pref).sum(-1) * vmask).sum() / (vmask.sum() + 1e-12)
+    lref = lref + torch.norm(Er.t() @ Er * (1.0 - torch.eye(Cc, device=dev)), p=2)
+    assert abs(loss.item() - lref.item()) <= 1e-4 * max(1.0, abs(lref.item()))
+    w = torch.randn(R, 8, device=dev)
+    total = loss * 1.7 + (padded.float() * w).sum()
+    tref = lref * 1.7 + (pref * w[:, :4]).sum()
+    g1 = torch.autograd.grad(total, [logits, E])
+    g2 = torch.autograd.grad(tref, [lr, Er])
+    _close(g1[0], g2[0], 2e-2, "dlogits")      # (the padded branch carries bf16-rounded probabilities)
+    _close(g1[1], g2[1], 1e-4, "dlabel_embs")
+    # in-kernel noise: Gumbel(0,1) has mean 0.5772 and variance pi^2/6; draws differ per seed / step
+    z = torch.zeros(200000, 1, device=dev)
+    tau = 1.0
+    p1, _ = ops.gumbel_softmax(torch.zeros(50000, 4, device=dev), None, tau, 7, None, 8, torch.bfloat16)
+    p2, _ = ops.gumbel_softmax(torch.zeros(50000, 4, device=dev), None, tau, 8, None, 8, torch.bfloat16)
+    assert not torch.equal(p1, p2)
+    assert abs(p1.mean().item() - 0.25) < 1e-6 + 1e-3           # rows sum to one
+    # with equal logits every class wins equally often
+    wins = torch.bincount(p1.argmax(1), minlength=4).float() / p1.shape[0]
+    assert (wins - 0.25).abs().max().item() < 0.01
+
+
 def test_soft_ce_matches_torch(dev):
     ops = _ops()
     torch.manual_seed(6)

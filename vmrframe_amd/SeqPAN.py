@@ -420,13 +420,12 @@ class SeqPAN(nn.Module):
         pq = ops.linear(pooled, Wc, bc, self._cache, kslice=(D, 2 * D))           # [B, D]
         fuse = ops.linear(t2v, Wc, None, self._cache, kslice=(0, D), residual=pq, res_div=T)
         # match head (reference models/SeqPAN.py:78-82)
-        mlogits = self._head(fuse, "match_conv1d").reshape(B, T, 4)
-        if self.gumbel_override is not None:
-            g = self.gumbel_override.to(mlogits.device)
-        else:
-            g = -torch.empty_like(mlogits).exponential_().log()
-        match_score = torch.softmax((mlogits + g) / 0.3, dim=-1)
-        ms = F.pad(match_score.reshape(Nv, 4), (0, 4)).to(cdt)                    # K padded 4 -> 8
+        mlogits = self._head(fuse, "match_conv1d")                                 # [Nv, 4] fp32
+        gseed, gstep = dc.noise_seed("match.gumbel")
+        noise = None if self.gumbel_override is None else self.gumbel_override.to(mlogits.device).reshape(Nv, 4)
+        # Gumbel-softmax (tau 0.3) + the K-padded compute-dtype copy in one kernel
+        ms_probs, ms = ops.gumbel_softmax(mlogits, noise, 0.3, gseed, gstep, 8, cdt)
+        match_score = ms_probs.view(B, T, 4)
         # fuse2 = (fuse + match_score . label_embs^T) * vmask : one GEMM epilogue
         fuse2 = ops.linear(ms, self.P("label_embs"), None, self._cache, residual=fuse,
                            rowscale=vmask.reshape(-1))
@@ -459,12 +458,8 @@ def lossfun_loc(start_logits, end_logits, s_labels, e_labels, vmask=None):
 
 
 def lossfun_match(m_probs, label_embs, m_labels, vmask):
-    """reference models/loss.py:24-41 (tiny: [B,T,4] and a 4x4 Gram matrix)."""
-    onehot = F.one_hot(m_labels, 4).float()
-    per = -(onehot * m_probs).sum(-1)
-    loss = (per * vmask).sum() / (vmask.sum() + 1e-12)
-    gram = label_embs.t() @ label_embs * (1.0 - torch.eye(4, device=label_embs.device))
-    return loss + torch.norm(gram, p=2)
+    """reference models/loss.py:24-41 on the HIP kernels (masked mean of -p[label] + off-diagonal Gram norm)."""
+    return ops.match_loss(m_probs, label_embs, m_labels, vmask)
 
 
 def train_engine_SeqPAN(model, data, configs, runtype):

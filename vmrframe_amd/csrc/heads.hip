@@ -1,0 +1,209 @@
+// heads.hip -- the match head and its loss (reference models/SeqPAN.py:78-82, models/loss.py:24-41), which were
+// strings of ~50 tiny framework launches on [B,T,4] tensors:
+//   * Gumbel-softmax over C <= 8 classes (F.gumbel_softmax, tau = 0.3): noise either given (parity tests) or
+//     drawn in-kernel from the counter hash; also emits the zero-padded compute-dtype copy the label-embedding
+//     GEMM consumes
+//   * lossfun_match: masked mean of -p[label] plus the Frobenius norm of the off-diagonal Gram matrix of the
+//     label embeddings; forward and backward in one launch each
+#include "common.h"
+
+namespace {
+
+constexpr int HC_MAX = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void gumbel_softmax_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ noise,
+                                                                 float inv_tau, uint32_t seed0, const uint32_t* __restrict__ step,
+                                                                 float* __restrict__ probs, T* __restrict__ padded, int64_t R,
+                                                                 int C, int ldo) {
+  const uint32_t seed = vmr_seed(seed0, step);
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256) {
+    float v[HC_MAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < HC_MAX; ++c) {
+      if (c < C) {
+        float g;
+        if (noise) g = noise[r * C + c];
+        else {   // g = -log(E), E ~ Exp(1) = -log(U): one 32-bit hash per element, U in (0,1)
+          const uint2 h = vmr_hash4(seed, (uint64_t)r * C + c);
+          const float u = ((float)(h.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+          g = -__logf(-__logf(u));
+        }
+        v[c] = (logits[r * C + c] + g) * inv_tau;
+        mx = fmaxf(mx, v[c]);
+      }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < HC_MAX; ++c)
+      if (c < C) { v[c] = expf(v[c] - mx); sum += v[c]; }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int c = 0; c < HC_MAX; ++c)
+      if (c < C) probs[r * C + c] = v[c] * inv;
+    if (padded)
+      for (int c = 0; c < ldo; ++c) padded[r * ldo + c] = from_f<T>(c < C ? v[c] * inv : 0.f);
+  }
+}
+
+// dlogits = inv_tau * p * (dp - sum_c p*dp), dp = dprobs (nullable) + dpadded[:, :C] (nullable)
+template <typename T>
+__global__ __launch_bounds__(256) void gumbel_softmax_bwd_kernel(const float* __restrict__ dprobs, const T* __restrict__ dpadded,
+                                                                 const float* __restrict__ probs, float inv_tau,
+                                                                 float* __restrict__ dlogits, int64_t R, int C, int ldo) {
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256) {
+    float dp[HC_MAX], p[HC_MAX];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < HC_MAX; ++c)
+      if (c < C) {
+        p[c] = probs[r * C + c];
+        dp[c] = (dprobs ? dprobs[r * C + c] : 0.f) + (dpadded ? to_f<T>(dpadded[r * ldo + c]) : 0.f);
+        dot += p[c] * dp[c];
+      }
+#pragma unroll
+    for (int c = 0; c < HC_MAX; ++c)
+      if (c < C) dlogits[r * C + c] = inv_tau * p[c] * (dp[c] - dot);
+  }
+}
+
+// stats = {numerator sum_r -p[r,label]*vmask[r], denominator sum_r vmask[r]} accumulated by atomics (caller zeroes)
+__global__ __launch_bounds__(256) void match_loss_partial_kernel(const float* __restrict__ probs, const int64_t* __restrict__ labels,
+                                                                 const float* __restrict__ vmask, float* __restrict__ stats,
+                                                                 int64_t R, int C) {
+  float num = 0.f, den = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256) {
+    const float m = vmask[r];
+    const int64_t l = labels[r];
+    if (l >= 0 && l < C) num -= probs[r * C + l] * m;
+    den += m;
+  }
+  num = wave_sum(num);
+  den = wave_sum(den);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], num); atomicAdd(&stats[1], den); }
+}
+
+// one workgroup: Gram matrix G = E^T E of the label embeddings E [D,C], off-diagonal Frobenius norm;
+// loss = stats[0]/(stats[1]+1e-12) + norm; aux = {G (C*C), norm, denominator}
+__global__ __launch_bounds__(256) void match_loss_final_kernel(const float* __restrict__ E, const float* __restrict__ stats,
+                                                               float* __restrict__ loss, float* __restrict__ aux, int D, int C) {
+  __shared__ float red[4][HC_MAX * HC_MAX];
+  float g[HC_MAX * HC_MAX];
+#pragma unroll
+  for (int i = 0; i < HC_MAX * HC_MAX; ++i) g[i] = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float e[HC_MAX];
+#pragma unroll
+    for (int c = 0; c < HC_MAX; ++c) e[c] = c < C ? E[(int64_t)d * C + c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < HC_MAX; ++i)
+#pragma unroll
+      for (int j = 0; j < HC_MAX; ++j) g[i * HC_MAX + j] += e[i] * e[j];
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < HC_MAX * HC_MAX; ++i) {
+    const float s = wave_sum(g[i]);
+    if (lane == 0) red[wid][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float nrm = 0.f;
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) {
+        const float v = red[0][i * HC_MAX + j] + red[1][i * HC_MAX + j] + red[2][i * HC_MAX + j] + red[3][i * HC_MAX + j];
+        aux[i * C + j] = v;
+        if (i != j) nrm += v * v;
+      }
+    nrm = sqrtf(nrm);
+    aux[C * C] = nrm;
+    aux[C * C + 1] = stats[1] + 1e-12f;
+    loss[0] = stats[0] / (stats[1] + 1e-12f) + nrm;
+  }
+}
+
+// dprobs[r,c] = -dloss * vmask[r] / denom at c == label; dE[d,j] += dloss * 2/norm * sum_{i != j} E[d,i] G[i,j]
+__global__ __launch_bounds__(256) void match_loss_bwd_kernel(const float* __restrict__ dloss, const int64_t* __restrict__ labels,
+                                                             const float* __restrict__ vmask, const float* __restrict__ E,
+                                                             const float* __restrict__ aux, float* __restrict__ dprobs,
+                                                             float* __restrict__ dE, int64_t R, int D, int C) {
+  const float gl = dloss[0];
+  const float nrm = aux[C * C], den = aux[C * C + 1];
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  for (int64_t r = tid; r < R; r += nth) {
+    const int64_t l = labels[r];
+    const float v = -gl * vmask[r] / den;
+    for (int c = 0; c < C; ++c) dprobs[r * C + c] = (c == l) ? v : 0.f;
+  }
+  if (dE && nrm > 0.f) {
+    for (int64_t i = tid; i < (int64_t)D * C; i += nth) {
+      const int d = (int)(i / C), j = (int)(i - (int64_t)d * C);
+      float s = 0.f;
+      for (int k = 0; k < C; ++k)
+        if (k != j) s += E[(int64_t)d * C + k] * aux[k * C + j];
+      atomicAdd(&dE[i], gl * 2.f * s / nrm);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vmr_gumbel_softmax_fwd(const float* logits, const float* noise, float tau, uint32_t seed, const uint32_t* step,
+                                      float* probs, void* padded, int64_t R, int C, int ldo, int dtype, void* stream) {
+  VMR_CHECK(logits && probs && tau > 0.f, "vmr_gumbel_softmax_fwd: bad arguments");
+  VMR_CHECK(C >= 1 && C <= HC_MAX && (!padded || ldo >= C), "vmr_gumbel_softmax_fwd: need 1 <= C <= %d and ldo >= C", HC_MAX);
+  if (R == 0) return 0;
+  const dim3 grid((unsigned)min((int64_t)2048, (R + 255) / 256));
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(gumbel_softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, logits, noise, 1.f / tau, seed,
+                       step, probs, (bf16_t*)padded, R, C, ldo);
+  else
+    hipLaunchKernelGGL(gumbel_softmax_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, logits, noise, 1.f / tau, seed,
+                       step, probs, (float*)padded, R, C, ldo);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_gumbel_softmax_bwd(const float* dprobs, const void* dpadded, const float* probs, float tau, float* dlogits,
+                                      int64_t R, int C, int ldo, int dtype, void* stream) {
+  VMR_CHECK(probs && dlogits && tau > 0.f && (dprobs || dpadded), "vmr_gumbel_softmax_bwd: bad arguments");
+  VMR_CHECK(C >= 1 && C <= HC_MAX, "vmr_gumbel_softmax_bwd: need 1 <= C <= %d", HC_MAX);
+  if (R == 0) return 0;
+  const dim3 grid((unsigned)min((int64_t)2048, (R + 255) / 256));
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(gumbel_softmax_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, dprobs, (const bf16_t*)dpadded,
+                       probs, 1.f / tau, dlogits, R, C, ldo);
+  else
+    hipLaunchKernelGGL(gumbel_softmax_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, dprobs, (const float*)dpadded,
+                       probs, 1.f / tau, dlogits, R, C, ldo);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_match_loss_fwd(const float* probs, const int64_t* labels, const float* vmask, const float* E, float* loss,
+                                  float* aux /*[C*C+2] + 2 scratch floats*/, int64_t R, int D, int C, void* stream) {
+  VMR_CHECK(probs && labels && vmask && E && loss && aux, "vmr_match_loss_fwd: null pointer");
+  VMR_CHECK(C >= 1 && C <= HC_MAX, "vmr_match_loss_fwd: need 1 <= C <= %d", HC_MAX);
+  float* stats = aux + C * C + 2;
+  hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) return vmr_fail(-5, "vmr_match_loss_fwd: memset: %s", hipGetErrorString(e));
+  if (R > 0)
+    hipLaunchKernelGGL(match_loss_partial_kernel, dim3((unsigned)min((int64_t)256, (R + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, probs, labels, vmask, stats, R, C);
+  hipLaunchKernelGGL(match_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, E, stats, loss, aux, D, C);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_match_loss_bwd(const float* dloss, const int64_t* labels, const float* vmask, const float* E, const float* aux,
+                                  float* dprobs, float* dE /*nullable, accumulated*/, int64_t R, int D, int C, void* stream) {
+  VMR_CHECK(dloss && labels && vmask && E && aux && dprobs, "vmr_match_loss_bwd: null pointer");
+  VMR_CHECK(C >= 1 && C <= HC_MAX, "vmr_match_loss_bwd: need 1 <= C <= %d", HC_MAX);
+  const int64_t work = R > (int64_t)D * C ? R : (int64_t)D * C;
+  if (work == 0) return 0;
+  hipLaunchKernelGGL(match_loss_bwd_kernel, dim3((unsigned)min((int64_t)1024, (work + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, dloss, labels, vmask, E, aux, dprobs, dE, R, D, C);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}

@@ -59,6 +59,13 @@ class DropCtx:
         self.sites.append((name, seed))
         return (self.p, seed, self.step)
 
+    def noise_seed(self, name: str = "") -> Tuple[int, Optional[torch.Tensor]]:
+        """Seed of a sampling site that is active in eval mode too (the Gumbel noise of the match head)."""
+        self.n += 1
+        seed = (self.base * 0x9E3779B1 + self.n * 0x85EBCA6B + 0x7654321) & 0xFFFFFFFF
+        self.sites.append((name, seed))
+        return seed, self.step
+
 
 # ---------------------------------------------------------------------------
 # raw GEMM launch
@@ -511,6 +518,91 @@ class _NarrowLinear(torch.autograd.Function):
 def narrow_linear(x, W, bias):
     """x [M,K] (compute dtype) . W[N,K(,1)]^T + bias -> fp32 [M,N], N <= 8."""
     return _NarrowLinear.apply(x, W, bias)
+
+
+class _GumbelSoftmax(torch.autograd.Function):
+    """F.gumbel_softmax(logits, tau) (reference models/SeqPAN.py:79) over <= 8 classes in one kernel, plus the
+    zero-padded compute-dtype copy of the probabilities that feeds the label-embedding product."""
+
+    @staticmethod
+    def forward(ctx, logits, noise, tau, seed, step, pad_to, dtype):
+        L.require_gpu(logits)
+        R, Cc = logits.shape
+        logits = logits.contiguous().float()
+        probs = torch.empty(R, Cc, device=logits.device, dtype=torch.float32)
+        padded = torch.empty(R, pad_to, device=logits.device, dtype=dtype)
+        L.check(L.lib().vmr_gumbel_softmax_fwd(logits.data_ptr(), _ptr(noise), tau, seed, _ptr(step), probs.data_ptr(),
+                                               padded.data_ptr(), R, Cc, pad_to, L.dtype_code(padded), L.stream_ptr()),
+                "vmr_gumbel_softmax_fwd")
+        ctx.save_for_backward(probs)
+        ctx.meta = (tau, pad_to, dtype)
+        return probs, padded
+
+    @staticmethod
+    def backward(ctx, dprobs, dpadded):
+        (probs,) = ctx.saved_tensors
+        tau, pad_to, dtype = ctx.meta
+        R, Cc = probs.shape
+        dprobs = None if dprobs is None else dprobs.contiguous().float()
+        dpadded = None if dpadded is None else dpadded.contiguous()
+        dl = torch.empty_like(probs)
+        L.check(L.lib().vmr_gumbel_softmax_bwd(_ptr(dprobs), _ptr(dpadded), probs.data_ptr(), tau, dl.data_ptr(), R, Cc, pad_to,
+                                               L.dtype_code(dpadded) if dpadded is not None else L.BF16, L.stream_ptr()),
+                "vmr_gumbel_softmax_bwd")
+        return dl, None, None, None, None, None, None
+
+
+def gumbel_softmax(logits, noise, tau, seed, step, pad_to, dtype):
+    """logits fp32 [R,C<=8]; noise: explicit Gumbel noise [R,C] or None (drawn in the kernel from seed/step).
+    Returns (probs fp32 [R,C], padded `dtype` [R,pad_to])."""
+    if noise is not None:
+        noise = noise.contiguous().float()
+    return _GumbelSoftmax.apply(logits, noise, float(tau), int(seed), step, int(pad_to), dtype)
+
+
+class _MatchLoss(torch.autograd.Function):
+    """lossfun_match (reference models/loss.py:24-41), forward and backward in one launch each."""
+
+    @staticmethod
+    def forward(ctx, probs, label_embs, labels, vmask):
+        L.require_gpu(probs, label_embs, labels, vmask)
+        Cc = probs.shape[-1]
+        p2 = probs.contiguous().float().view(-1, Cc)
+        R = p2.shape[0]
+        E = label_embs.detach().contiguous().float()
+        D = E.shape[0]
+        assert E.shape[1] == Cc
+        lab = labels.contiguous().view(-1).long()
+        vm = vmask.contiguous().float().view(-1)
+        assert lab.numel() == R and vm.numel() == R
+        loss = torch.empty(1, device=p2.device, dtype=torch.float32)
+        aux = torch.empty(Cc * Cc + 4, device=p2.device, dtype=torch.float32)
+        L.check(L.lib().vmr_match_loss_fwd(p2.data_ptr(), lab.data_ptr(), vm.data_ptr(), E.data_ptr(), loss.data_ptr(),
+                                           aux.data_ptr(), R, D, Cc, L.stream_ptr()), "vmr_match_loss_fwd")
+        ctx.save_for_backward(lab, vm, label_embs, aux)
+        ctx.pshape = probs.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lab, vm, label_embs, aux = ctx.saved_tensors
+        Cc = ctx.pshape[-1]
+        R = lab.numel()
+        E = label_embs.detach().contiguous().float()
+        D = E.shape[0]
+        dl = dloss.contiguous().float().view(1)
+        dprobs = torch.empty(R, Cc, device=dl.device, dtype=torch.float32)
+        gE = main_grad(label_embs)
+        need_e = ctx.needs_input_grad[1]
+        dE = gE if (gE is not None and gE.is_contiguous()) else (torch.zeros(D, Cc, device=dl.device, dtype=torch.float32)
+                                                              if need_e else None)
+        L.check(L.lib().vmr_match_loss_bwd(dl.data_ptr(), lab.data_ptr(), vm.data_ptr(), E.data_ptr(), aux.data_ptr(),
+                                           dprobs.data_ptr(), _ptr(dE), R, D, Cc, L.stream_ptr()), "vmr_match_loss_bwd")
+        return dprobs.view(ctx.pshape), (None if (dE is None or dE is gE) else dE), None, None
+
+
+def match_loss(probs, label_embs, labels, vmask):
+    return _MatchLoss.apply(probs, label_embs, labels, vmask)
 
 
 def group_view(params):
