@@ -305,6 +305,13 @@ int vmr_match_loss_fwd(const float* probs, const int64_t* labels, const float* v
 int vmr_match_loss_bwd(const float* dloss, const int64_t* labels, const float* vmask, const float* E,
                        const float* aux, float* dprobs, float* dE, int64_t R, int D, int C, void* stream);
 
+/* y = x*a + b over the last dim (a, b fp32 [D]): the rank-1-folded operand of the CQAttention trilinear score
+ * (models/layers.py:427-437).  bwd: dx = dy*a; da += colsum(dy*x); db += colsum(dy) (ACCUMULATED). */
+int vmr_scale_shift_fwd(const void* x, const float* a, const float* b, void* y, int64_t rows, int D, int dtype,
+                        void* stream);
+int vmr_scale_shift_bwd(const void* dy, const void* x, const float* a, void* dx, float* da, float* db,
+                        int64_t rows, int D, int dtype, void* stream);
+
 /* --------------------------------------------------------------- optimizer
  * fused AdamW over a flat fp32 parameter arena (utils/utils.py:87-97:
  * AdamW, weight_decay 0.01 except names containing bias/layer_norm) with the

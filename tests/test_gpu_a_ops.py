@@ -457,6 +457,25 @@ def test_gumbel_softmax_and_match_loss(dev):
     assert (wins - 0.25).abs().max().item() < 0.01
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_scale_shift_fwd_bwd(dev, dt, tol):
+    ops = _ops()
+    torch.manual_seed(31)
+    R, D = 1280, 1024
+    x = torch.randn(2, R // 2, D, device=dev).to(dt).requires_grad_(True)
+    a = torch.randn(1, 1, D, device=dev, requires_grad=True)
+    b = torch.randn(D, 1, device=dev, requires_grad=True)
+    y = ops.scale_shift(x, a, b)
+    xr = x.detach().float().requires_grad_(True)
+    ar, br = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    ref = xr * ar + br.view(1, 1, D)
+    _close(y, ref, tol, "y")
+    g = torch.randn_like(ref)
+    gx, ga, gb = torch.autograd.grad(y, [x, a, b], g.to(dt))
+    rx, ra, rb = torch.autograd.grad(ref, [xr, ar, br], g.to(dt).float())
+    _close(gx, rx, tol, "dx"); _close(ga, ra, tol, "da"); _close(gb, rb, tol, "db")
+
+
 def test_soft_ce_matches_torch(dev):
     ops = _ops()
     torch.manual_seed(6)

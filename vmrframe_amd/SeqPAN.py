@@ -348,14 +348,14 @@ class SeqPAN(nn.Module):
         w4C, w4Q, w4mlu = self.P(prefix + ".w4C"), self.P(prefix + ".w4Q"), self.P(prefix + ".w4mlu")
         cd = ops.dropout(ctx, dc.next(prefix + ".c"))
         qd = ops.dropout(qry, dc.next(prefix + ".q"))
-        if Lq <= Lc:
-            qf = qd.float()
-            bop = (qf * w4mlu + w4C.view(1, 1, D)).to(cdt)
-            S2, rowterm, colterm = ops.bmm(cd, bop, 0, 0, out_f32=True), None, (qf @ w4Q).squeeze(2)
+        if Lq <= Lc:      # (rank-1 terms: one scale-shift kernel + one matrix-vector kernel on the short stream)
+            bop = ops.scale_shift(qd, w4mlu, w4C)
+            colterm = ops.narrow_linear(qd.reshape(B * Lq, D), w4Q, None, N=1).view(B, Lq)
+            S2, rowterm = ops.bmm(cd, bop, 0, 0, out_f32=True), None
         else:
-            cf = cd.float()
-            aop = (cf * w4mlu + w4Q.view(1, 1, D)).to(cdt)
-            S2, rowterm, colterm = ops.bmm(aop, qd, 0, 0, out_f32=True), (cf @ w4C).squeeze(2), None
+            aop = ops.scale_shift(cd, w4mlu, w4Q)
+            rowterm = ops.narrow_linear(cd.reshape(B * Lc, D), w4C, None, N=1).view(B, Lc)
+            S2, colterm = ops.bmm(aop, qd, 0, 0, out_f32=True), None
         # both masked softmaxes in one HIP kernel; outputs are 8-padded so the GEMMs below use 16-byte loads
         S_p, S_tp = ops.cq_softmax(S2, rowterm, colterm, cmask, qmask, cdt)
         c2q = ops.bmm(S_p, qry, 0, 1)                      # [B,Lc,D]

@@ -70,6 +70,8 @@ SIGNATURES = {
     "vmr_gumbel_softmax_bwd": [_P, _P, _P, _F, _P, _L, _I, _I, _I, _P],
     "vmr_match_loss_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "vmr_match_loss_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "vmr_scale_shift_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "vmr_scale_shift_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "vmr_cq_softmax_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_cq_softmax_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_soft_ce_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],

@@ -207,3 +207,95 @@ extern "C" int vmr_match_loss_bwd(const float* dloss, const int64_t* labels, con
   VMR_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------ CQAttention rank-1 prep
+// y[r,:] = x[r,:] * a + b  (a, b fp32 [D]; x, y compute dtype): the operand C*w4mlu + w4Q (or Q*w4mlu + w4C) of
+// the trilinear score (reference models/layers.py:427-437), always built on the SHORT stream.
+// bwd: dx = dy * a; da[d] += sum_r dy*x; db[d] += sum_r dy (row slabs over blockIdx.y, one atomic per slab).
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_shift_fwd_kernel(const T* __restrict__ x, const float* __restrict__ a,
+                                                              const float* __restrict__ b, T* __restrict__ y, int64_t rows, int D) {
+  const int64_t total = rows * (D / 8);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % (D / 8)) * 8;
+    float xv[8], av[8], bv[8];
+    Vec8<T>::load(x + i * 8, xv);
+    Vec8<float>::load(a + c, av);
+    Vec8<float>::load(b + c, bv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xv[e] = xv[e] * av[e] + bv[e];
+    Vec8<T>::store(y + i * 8, xv);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_shift_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                              const float* __restrict__ a, T* __restrict__ dx,
+                                                              float* __restrict__ da, float* __restrict__ db, int64_t rows, int D,
+                                                              int rows_per_block) {
+  __shared__ float red[2][8][256];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + cg * 8;
+  const int64_t rbeg = (int64_t)blockIdx.y * rows_per_block, rend = min(rows, rbeg + rows_per_block);
+  float sa[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < D) {
+    float av[8];
+    Vec8<float>::load(a + c0, av);
+    for (int64_t r = rbeg + rl; r < rend; r += 8) {
+      float g[8], xv[8], o[8];
+      Vec8<T>::load(dy + r * D + c0, g);
+      Vec8<T>::load(x + r * D + c0, xv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { o[e] = g[e] * av[e]; sa[e] += g[e] * xv[e]; sb[e] += g[e]; }
+      Vec8<T>::store(dx + r * D + c0, o);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][rl][cg * 8 + e] = sa[e]; red[1][rl][cg * 8 + e] = sb[e]; }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < D) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s0 += red[0][k][threadIdx.x]; s1 += red[1][k][threadIdx.x]; }
+    atomicAdd(&da[c], s0);
+    atomicAdd(&db[c], s1);
+  }
+}
+
+}  // namespace
+
+extern "C" int vmr_scale_shift_fwd(const void* x, const float* a, const float* b, void* y, int64_t rows, int D, int dtype,
+                                   void* stream) {
+  VMR_CHECK(x && a && b && y && D % 8 == 0, "vmr_scale_shift_fwd: bad arguments");
+  if (rows == 0) return 0;
+  const dim3 grid((unsigned)min((int64_t)4096, (rows * (D / 8) + 255) / 256));
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(scale_shift_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, a, b, (bf16_t*)y,
+                       rows, D);
+  else
+    hipLaunchKernelGGL(scale_shift_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, a, b, (float*)y,
+                       rows, D);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_scale_shift_bwd(const void* dy, const void* x, const float* a, void* dx, float* da, float* db, int64_t rows,
+                                   int D, int dtype, void* stream) {
+  VMR_CHECK(dy && x && a && dx && da && db && D % 8 == 0, "vmr_scale_shift_bwd: bad arguments");
+  if (rows == 0) return 0;
+  const int gx = cdiv(D, 256);
+  int gy = (int)min((int64_t)(512 / gx > 0 ? 512 / gx : 1), (rows + 31) / 32);
+  const int rpb = (int)((rows + gy - 1) / gy);
+  gy = (int)((rows + rpb - 1) / rpb);
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(scale_shift_bwd_kernel<bf16_t>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                       (const bf16_t*)x, a, (bf16_t*)dx, da, db, rows, D, rpb);
+  else
+    hipLaunchKernelGGL(scale_shift_bwd_kernel<float>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
+                       (const float*)x, a, (float*)dx, da, db, rows, D, rpb);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}

@@ -197,7 +197,10 @@ __global__ __launch_bounds__(256) void cq_softmax_fwd_kernel(const float* __rest
     tile[i] = v;
   }
   __syncthreads();
+  // blockIdx.y splits the two softmaxes over two workgroups per sample (each re-reads the small tile)
+  const bool do_rows = gridDim.y == 1 || blockIdx.y == 0, do_cols = gridDim.y == 1 || blockIdx.y == 1;
   // rows: softmax over q with the query mask
+  if (do_rows)
   for (int c = wid; c < Lc; c += 4) {
     float mx = -INFINITY;
     for (int q = lane; q < Lq; q += 64)
@@ -215,6 +218,7 @@ __global__ __launch_bounds__(256) void cq_softmax_fwd_kernel(const float* __rest
   }
   // columns: softmax over c with the context mask.  256/Lq' threads share a column (each takes a
   // stripe of c), so a short query axis (Lq = 20) does not leave 236 threads idle.
+  if (!do_cols) return;
   if (Lq > 256) {   // long query axis: a thread per column keeps every thread busy already
     for (int q = threadIdx.x; q < ldP; q += 256) {
       if (q >= Lq) {
@@ -359,10 +363,10 @@ extern "C" int vmr_cq_softmax_fwd(const float* S2, const float* rowterm, const f
     if (e != hipSuccess) return vmr_fail(-5, "vmr_cq_softmax_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(cq_softmax_fwd_kernel<bf16_t>, dim3(B), dim3(256), lds, (hipStream_t)stream, S2, rowterm, colterm,
+    hipLaunchKernelGGL(cq_softmax_fwd_kernel<bf16_t>, dim3(B, 2), dim3(256), lds, (hipStream_t)stream, S2, rowterm, colterm,
                        cmask, qmask, (bf16_t*)Srow, (bf16_t*)Scol, Lc, Lq, ldS, ldP);
   else
-    hipLaunchKernelGGL(cq_softmax_fwd_kernel<float>, dim3(B), dim3(256), lds, (hipStream_t)stream, S2, rowterm, colterm,
+    hipLaunchKernelGGL(cq_softmax_fwd_kernel<float>, dim3(B, 2), dim3(256), lds, (hipStream_t)stream, S2, rowterm, colterm,
                        cmask, qmask, (float*)Srow, (float*)Scol, Lc, Lq, ldS, ldP);
   VMR_LAUNCH_CHECK();
   return 0;

@@ -481,24 +481,24 @@ class _NarrowLinear(torch.autograd.Function):
     fp32 logits [M, N] straight from the compute-dtype features, one backward pass for dx, dW, db."""
 
     @staticmethod
-    def forward(ctx, x, W, bias):
+    def forward(ctx, x, W, bias, N):
         L.require_gpu(x, W)
         assert x.dim() == 2 and x.stride(1) == 1
         M, K = x.shape
-        N = W.shape[0]
         Wm = W.detach().reshape(N, -1)
         assert Wm.shape[1] == K and Wm.is_contiguous()
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
         L.check(L.lib().vmr_narrow_linear_fwd(x.data_ptr(), Wm.data_ptr(), _ptr(bias), y.data_ptr(), M, N, K, x.stride(0),
                                               L.dtype_code(x), L.stream_ptr()), "vmr_narrow_linear_fwd")
         ctx.save_for_backward(x, W, bias)
+        ctx.N = N
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, W, bias = ctx.saved_tensors
         M, K = x.shape
-        N = W.shape[0]
+        N = ctx.N
         dy = dy.contiguous().float()
         dx = torch.empty(M, K, device=x.device, dtype=x.dtype) if ctx.needs_input_grad[0] else None
         gW, gb = main_grad(W), (main_grad(bias) if bias is not None else None)
@@ -512,12 +512,13 @@ class _NarrowLinear(torch.autograd.Function):
                                               dW.data_ptr(), _ptr(db), ws.data_ptr(), M, N, K, x.stride(0),
                                               L.dtype_code(x), L.stream_ptr()), "vmr_narrow_linear_bwd")
         return (dx, None if gW is not None else dW.reshape(W.shape),
-                None if (bias is None or gb is not None) else db)
+                None if (bias is None or gb is not None) else db, None)
 
 
-def narrow_linear(x, W, bias):
-    """x [M,K] (compute dtype) . W[N,K(,1)]^T + bias -> fp32 [M,N], N <= 8."""
-    return _NarrowLinear.apply(x, W, bias)
+def narrow_linear(x, W, bias, N=None):
+    """x [M,K] (compute dtype) . W^T + bias -> fp32 [M,N], N <= 8; W holds N*K values as N contiguous rows
+    ([N,K,1] conv weights; a [K,1] column vector with N=1)."""
+    return _NarrowLinear.apply(x, W, bias, W.shape[0] if N is None else N)
 
 
 class _GumbelSoftmax(torch.autograd.Function):
@@ -603,6 +604,42 @@ class _MatchLoss(torch.autograd.Function):
 
 def match_loss(probs, label_embs, labels, vmask):
     return _MatchLoss.apply(probs, label_embs, labels, vmask)
+
+
+class _ScaleShift(torch.autograd.Function):
+    """y = x * a + b over the last dim (a, b fp32 parameters): the rank-1-folded operand of the CQAttention
+    trilinear score (reference models/layers.py:427-437), one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        L.require_gpu(x, a, b)
+        D = x.shape[-1]
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.check(L.lib().vmr_scale_shift_fwd(x.data_ptr(), a.data_ptr(), b.data_ptr(), y.data_ptr(), x.numel() // D, D,
+                                            L.dtype_code(x), L.stream_ptr()), "vmr_scale_shift_fwd")
+        ctx.save_for_backward(x, a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a, b = ctx.saved_tensors
+        D = x.shape[-1]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        ga, gb = main_grad(a), main_grad(b)
+        da = ga if ga is not None else torch.zeros(D, device=x.device, dtype=torch.float32)
+        db = gb if gb is not None else torch.zeros(D, device=x.device, dtype=torch.float32)
+        L.check(L.lib().vmr_scale_shift_bwd(dy.data_ptr(), x.data_ptr(), a.data_ptr(), dx.data_ptr(), da.data_ptr(),
+                                            db.data_ptr(), x.numel() // D, D, L.dtype_code(x), L.stream_ptr()),
+                "vmr_scale_shift_bwd")
+        return dx, (None if ga is not None else da.view(a.shape)), (None if gb is not None else db.view(b.shape))
+
+
+def scale_shift(x, a, b):
+    """x [..., D] (compute dtype) * a + b; a, b: fp32 parameters with D elements (any shape)."""
+    assert a.numel() == x.shape[-1] and b.numel() == x.shape[-1] and a.is_contiguous() and b.is_contiguous()
+    return _ScaleShift.apply(x, a, b)
 
 
 def group_view(params):
