@@ -970,6 +970,16 @@ def _bmm_raw(a, b, ta, tb, out_f32=False):
     M = a.shape[2] if ta else a.shape[1]
     N = b.shape[2] if tb else b.shape[1]
     Np = _rup(N, 8)
+    K = a.shape[1] if ta else a.shape[2]
+    tiles = _cdiv(M, 128) * _cdiv(N, 128) * Z
+    if tiles < 256 and K >= 512 and a.dtype != torch.float32:
+        # a handful of tiles with a long K (the [Lc x Lq] score / score-gradient products of CQAttention, K = D):
+        # split K so the grid fills the chip; fp32 partials meet through atomics (<= 8 adders per address)
+        sk = max(2, min(8, K // 128, _cdiv(512, tiles)))
+        cbuf = torch.zeros(Z, M, Np, device=a.device, dtype=torch.float32)
+        c = cbuf[..., :N]
+        bmm4(a.unsqueeze(0), b.unsqueeze(0), c.unsqueeze(0), ta, tb, flags=L.EPI_ACCUM, splitk=sk)
+        return c if out_f32 else cbuf.to(a.dtype)[..., :N]
     cbuf = torch.empty(Z, M, Np, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
     c = cbuf[..., :N]
     bmm4(a.unsqueeze(0), b.unsqueeze(0), c.unsqueeze(0), ta, tb)
