@@ -398,7 +398,8 @@ class SeqPAN(nn.Module):
 
         # text / video projections -> LayerNorm (+ positional table) -> packed tokens
         tq = self._text_embedding(word_ids, char_ids, dc)
-        vx = ops.cast_pad(vfeat_in.reshape(Nv, -1).float(), cdt, dc.next("video.in"))
+        # (V is zero-padded to a multiple of 64 columns, e.g. 500 -> 512: the projection stays on the LDS-DMA GEMM)
+        vx = ops.cast_pad(vfeat_in.reshape(Nv, -1).float(), cdt, dc.next("video.in"), mult=64 if cdt != torch.float32 else 8)
         vq = self._lin(vx, "video_affine.video_conv1d")
         xv = self._ln(vq, "video_affine.v_layer_norm", 1e-6, pos=pos_p, S=T)
         xt = self._ln(tq, "text_encoder.q_layer_norm", 1e-6, pos=pos_p, S=Lq)

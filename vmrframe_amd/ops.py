@@ -163,8 +163,10 @@ class WeightCache:
         the optimizer kernel rewrites the mirror in place."""
         self.store = {k: v for k, v in self.store.items() if getattr(v[1], "_vmr_mirror", False)}
 
-    def get(self, params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
-        key = (tuple(id(p) for p in params), dtype)
+    def get(self, params: Sequence[torch.Tensor], dtype: torch.dtype, kpad: int = 0) -> torch.Tensor:
+        """kpad > K: zero-pad the copy's K to kpad columns (an input padded to a multiple of 64 elements keeps
+        its GEMM on the LDS-DMA kernel: V = 500 video features -> 512)."""
+        key = (tuple(id(p) for p in params), dtype, kpad)
         ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
         hit = self.store.get(key)
         if hit is not None and hit[0] == ver:
@@ -175,7 +177,7 @@ class WeightCache:
             mirrors = [getattr(p, "_vmr_w16", None) for p in params]
             if all(m is not None for m in mirrors):
                 K = mirrors[0].numel() // mirrors[0].shape[0]
-                ok = K % 8 == 0
+                ok = K % 8 == 0 and kpad in (0, K)
                 for a_, b_ in zip(mirrors[:-1], mirrors[1:]):
                     ok = ok and a_.data_ptr() + a_.numel() * 2 == b_.data_ptr()
                 if ok:
@@ -187,7 +189,7 @@ class WeightCache:
         with torch.no_grad():
             mats = [p.detach().reshape(p.shape[0], -1).contiguous() for p in params]
             K = mats[0].shape[1]
-            Kp = _rup(K, 8)
+            Kp = max(_rup(K, 8), kpad)
             N = sum(m.shape[0] for m in mats)
             if len(mats) == 1 and dtype == torch.float32 and Kp == K:
                 w = mats[0]
@@ -205,13 +207,13 @@ class WeightCache:
 # ---------------------------------------------------------------------------
 # cast (+pad, +input dropout)
 # ---------------------------------------------------------------------------
-def cast_pad(x: torch.Tensor, dtype: torch.dtype, drop=NO_DROP) -> torch.Tensor:
-    """[rows, cols] fp32 -> [rows, roundup(cols, 8)] compute dtype, zero padded, with the
+def cast_pad(x: torch.Tensor, dtype: torch.dtype, drop=NO_DROP, mult: int = 8) -> torch.Tensor:
+    """[rows, cols] fp32 -> [rows, roundup(cols, mult)] compute dtype, zero padded, with the
     VisualProjection input dropout (reference models/layers.py:120).  No gradient."""
     L.require_gpu(x)
     x = x.contiguous()
     rows, cols = x.shape
-    out = torch.empty(rows, _rup(cols, 8), device=x.device, dtype=dtype)
+    out = torch.empty(rows, _rup(cols, mult), device=x.device, dtype=dtype)
     L.check(L.lib().vmr_cast(x.data_ptr(), L.dtype_code(x), out.data_ptr(), L.dtype_code(out), rows, cols, cols,
                              out.shape[1], drop[0], drop[1], _ptr(drop[2]), L.stream_ptr()), "vmr_cast")
     return out
@@ -272,7 +274,7 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, kslice, res_div, *weights):
         L.require_gpu(x)
         assert x.dim() == 2 and x.stride(1) == 1
-        W = cache.get(weights, x.dtype)
+        W = cache.get(weights, x.dtype, 0 if kslice is not None else x.shape[1])
         if kslice is not None:               # y = x . W[:, k0:k1]^T : a column slice of ONE weight, used in place
             assert len(weights) == 1 and kslice[0] % 8 == 0 and kslice[1] % 8 == 0
             W = W[:, kslice[0]:kslice[1]]
