@@ -178,7 +178,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         const float h = ((float)cx[c][e] - mean) * rstd;
         ag[c][e] += d * h;
         ab[c][e] += d;
-        if (dpos) atomicAdd(&dpos[(int64_t)(row % S) * D + i + e], d);
         const float dh = d * g[e];
         s1 += dh;
         s2 += dh * h;
@@ -219,6 +218,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   float* mine = part + (int64_t)blockIdx.x * 2 * SLOTS;
   for (int i = threadIdx.x; i < 2 * SLOTS; i += 256)
     mine[i] = red[i] + red[2 * SLOTS + i] + red[4 * SLOTS + i] + red[6 * SLOTS + i];
+}
+
+// Positional-table gradient of "LN(x) + pos[row % S]" (PositionalEmbedding, reference layers.py:96-107,397):
+// dpos[s, :] += sum_b d[b*S + s, :] with d = dropout-masked dy.  One thread per (s, 8 channels) walks the batch;
+// this replaced one float atomic PER ELEMENT inside ln_bwd (8.4 M atomics, 64 per address: 242 us at cfg2).
+template <typename T>
+__global__ __launch_bounds__(256) void dpos_kernel(const T* __restrict__ dy, float* __restrict__ dpos, int64_t rows, int S, int D,
+                                                   float drop_p, uint32_t seed0, const uint32_t* __restrict__ step) {
+  const uint32_t seed = vmr_seed(seed0, step);
+  const uint32_t thresh = vmr_drop_thresh(drop_p);
+  const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const int cpr = D / 8;
+  const int64_t total = (int64_t)S * cpr;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int s = (int)(idx / cpr), c = (int)(idx - (int64_t)s * cpr) * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t row = s; row < rows; row += S) {
+      float g[8];
+      Vec8<T>::load(dy + row * D + c, g);
+      const uint32_t keep = drop_p > 0.f ? vmr_keep8(seed, (uint64_t)row * D + c, thresh) : 0xFFu;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (drop_p > 0.f) ? (((keep >> e) & 1) ? g[e] * dscale : 0.f) : g[e];
+    }
+    float old[8];
+    Vec8<float>::load(dpos + (int64_t)s * D + c, old);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) old[e] += acc[e];
+    Vec8<float>::store(dpos + (int64_t)s * D + c, old);
+  }
 }
 
 // out[j] += sum_b part[b][j]   (j < n): second stage of the column reductions.  blockIdx.y takes
@@ -490,6 +518,17 @@ extern "C" int vmr_layernorm_bwd(const void* dy, const void* x, const float* gam
                                       (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres,
                                       (float*)dx, part, dpos, S, rows, D, drop_p, drop_seed, drop_step));
   VMR_LAUNCH_CHECK();
+  if (dpos) {
+    VMR_CHECK(S > 0 && D % 8 == 0, "vmr_layernorm_bwd: dpos needs S > 0");
+    const dim3 gp((unsigned)min((int64_t)4096, ((int64_t)S * (D / 8) + 255) / 256));
+    if (dtype == VMR_BF16)
+      hipLaunchKernelGGL(dpos_kernel<bf16_t>, gp, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dpos, rows, S, D, drop_p,
+                         drop_seed, drop_step);
+    else
+      hipLaunchKernelGGL(dpos_kernel<float>, gp, dim3(256), 0, (hipStream_t)stream, (const float*)dy, dpos, rows, S, D, drop_p,
+                         drop_seed, drop_step);
+    VMR_LAUNCH_CHECK();
+  }
   if (part) {
     hipLaunchKernelGGL(colreduce_kernel, dim3(cdiv(2 * D, 256), cdiv(grid, 16)), dim3(256), 0, (hipStream_t)stream,
                        part, dgamma, dbeta, grid, D, D, slots);
