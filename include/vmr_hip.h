@@ -312,6 +312,24 @@ int vmr_scale_shift_fwd(const void* x, const float* a, const float* b, void* y, 
 int vmr_scale_shift_bwd(const void* dy, const void* x, const float* a, void* dx, float* da, float* db,
                         int64_t rows, int D, int dtype, void* stream);
 
+/* ------------------------------------------------------------ CharacterEmbedding
+ * reference models/layers.py:51-75 in one kernel each way: out[word, coff_k + o] = max_p relu(b_k[o] +
+ * sum_{c,j} W_k[o,c,0,j] * drop(table[ids[word,p+j], c])) for the four kernel widths k = 1..4 (oc[k-1] out
+ * channels each, concatenated along the columns: OT = sum oc).  ids: int64 [W, C] (4 <= C <= 16), table fp32
+ * [num_chars, CD] (row 0 = padding: no gradient), w[k-1]: fp32 [oc, CD, 1, k], b[k-1]: fp32 [oc]; out: dtype
+ * [W, ldo]; amax: int8 [W, OT] (arg-max positions, kept for the backward).  Dropout acts on the gathered
+ * character rows (counter stream index (word*C + p)*CD + c).
+ * bwd: dw[k-1] / db[k-1] (fp32, shapes of w / b) and dtable (nullable) are ACCUMULATED; workspace:
+ * vmr_char_cnn_ws_floats(W, CD, oc, dtype) fp32 of caller-owned scratch. */
+int vmr_char_cnn_ws_floats(int W, int CD, const int* oc, int dtype);
+int vmr_char_cnn_fwd(const int64_t* char_ids, const float* table, const float* const* w, const float* const* b,
+                     const int* oc, void* out, int64_t ldo, int8_t* amax, int W, int C, int CD, int dtype,
+                     float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream);
+int vmr_char_cnn_bwd(const void* dout, const void* out, int64_t ldo, const int8_t* amax, const int64_t* char_ids,
+                     const float* table, const float* const* w, const float* const* b, const int* oc,
+                     float* const* dw, float* const* db, float* dtable, float* workspace, int W, int C, int CD,
+                     int dtype, float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream);
+
 /* --------------------------------------------------------------- optimizer
  * fused AdamW over a flat fp32 parameter arena (utils/utils.py:87-97:
  * AdamW, weight_decay 0.01 except names containing bias/layer_norm) with the

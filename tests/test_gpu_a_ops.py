@@ -476,6 +476,72 @@ def test_scale_shift_fwd_bwd(dev, dt, tol):
     _close(gx, rx, tol, "dx"); _close(ga, ra, tol, "da"); _close(gb, rb, tol, "db")
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dims", [(7, 5, 16, 12), (64 * 20, 8, 100, 60), (33, 16, 24, 9)])
+def test_char_cnn_fwd_bwd(dev, dt, tol, dims):
+    """csrc/charcnn.hip against the reference formulation of CharacterEmbedding (models/layers.py:51-75):
+    nn.Embedding(padding_idx=0) -> Conv2d(char_dim, 10k, (1,k)) + ReLU -> max over positions, k = 1..4."""
+    ops = _ops()
+    Wn, Cc, CD, NCH = dims
+    torch.manual_seed(37)
+    ids = torch.randint(0, NCH, (Wn, Cc), device=dev)
+    ids[0] = 0                                             # an all-padding word
+    table = torch.randn(NCH, CD, device=dev)
+    table[0] = 0
+    table.requires_grad_(True)
+    ws = [(torch.randn(10 * (k + 1), CD, 1, k + 1, device=dev) / math.sqrt(CD * (k + 1))).requires_grad_(True) for k in range(4)]
+    bs = [(0.1 * torch.randn(10 * (k + 1), device=dev)).requires_grad_(True) for k in range(4)]
+    out = ops.char_cnn(ids.view(1, Wn, Cc), table, ws, bs, ops.NO_DROP, dt)
+    tr = table.detach().clone().requires_grad_(True)
+    wr = [w.detach().clone().requires_grad_(True) for w in ws]
+    br = [b.detach().clone().requires_grad_(True) for b in bs]
+    ce = torch.nn.functional.embedding(ids, tr, padding_idx=0)                      # [W, C, CD]
+    if dt == torch.bfloat16:                                                         # operands rounded like the kernel's
+        ce = ce + (ce.to(dt).float() - ce).detach()
+    x = ce.permute(1 - 1, 2, 1).unsqueeze(2)                                        # [W, CD, 1, C]
+    feats = []
+    for k in range(4):
+        w = wr[k] if dt == torch.float32 else wr[k] + (wr[k].to(dt).float() - wr[k]).detach()
+        y = torch.relu(torch.nn.functional.conv2d(x, w, br[k]))                     # [W, 10k, 1, C-k]
+        feats.append(y.max(dim=3).values.squeeze(2))
+    ref = torch.cat(feats, 1)
+    assert out.shape == ref.shape
+    _close(out, ref, tol, "char features")
+    g = torch.randn_like(ref)
+    g1 = torch.autograd.grad(out, [table, *ws, *bs], g.to(dt))
+    g2 = torch.autograd.grad(ref, [tr, *wr, *br], g.to(dt).float())
+    for a, b, name in zip(g1, g2, ["dtable"] + [f"dW{k}" for k in range(4)] + [f"db{k}" for k in range(4)]):
+        _close(a, b, tol, name)
+    assert (g1[0][0] == 0).all()                                                     # padding row: no gradient
+
+
+def test_char_cnn_dropout_is_consistent(dev):
+    """Dropout on the gathered character rows: the backward regenerates the forward's mask (finite differences
+    of the same seeded function)."""
+    ops = _ops()
+    torch.manual_seed(41)
+    Wn, Cc, CD, NCH = 40, 8, 20, 15
+    ids = torch.randint(1, NCH, (Wn, Cc), device=dev)
+    table = torch.randn(NCH, CD, device=dev, requires_grad=True)
+    ws = [(torch.randn(10 * (k + 1), CD, 1, k + 1, device=dev) / math.sqrt(CD * (k + 1))).requires_grad_(True) for k in range(4)]
+    bs = [(0.5 + 0.1 * torch.randn(10 * (k + 1), device=dev)).requires_grad_(True) for k in range(4)]   # keep ReLUs active
+    w8 = torch.randn(Wn, 100, device=dev)
+    drop = (0.3, 77, None)
+
+    def f(t):
+        return (ops.char_cnn(ids, t, ws, bs, drop, torch.float32) * w8).sum()
+    y = f(table)
+    (gt,) = torch.autograd.grad(y, [table])
+    d = torch.randn_like(table)
+    eps = 1e-3
+    with torch.no_grad():
+        fd = (f(table + eps * d) - f(table - eps * d)) / (2 * eps)
+    an = (gt * d).sum()
+    assert abs(fd.item() - an.item()) <= 3e-2 * max(1.0, abs(an.item())), (fd.item(), an.item())
+    a, b = ops.char_cnn(ids, table, ws, bs, drop, torch.float32), ops.char_cnn(ids, table, ws, bs, (0.3, 78, None), torch.float32)
+    assert not torch.equal(a, b)
+
+
 def test_soft_ce_matches_torch(dev):
     ops = _ops()
     torch.manual_seed(6)

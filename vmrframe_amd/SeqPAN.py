@@ -289,18 +289,14 @@ class SeqPAN(nn.Module):
         table = torch.cat([self.P(pre + "word_emb.pad_vec"), self.P(pre + "word_emb.unk_vec"),
                            self.P(pre + "word_emb.glove_vec")], 0)
         wemb = ops.embedding(word_ids, table, 0)
-        cemb = ops.embedding(char_ids, self.P(pre + "char_emb.char_emb.weight"), 0)              # [B,L,C,cd]
         if dc.p > 0:
             wemb = F.dropout(wemb, dc.p, True)
-            cemb = F.dropout(cemb, dc.p, True)
-        C = cemb.shape[2]
-        feats = [ops.to_dtype(wemb.reshape(B * Lq, -1), cdt)]
-        for i in range(4):
-            k = i + 1
-            win = cemb.unfold(2, k, 1).reshape(B * Lq * (C - k + 1), self.char_dim * k)   # (cd, k) order == weight
-            y = ops.linear(ops.to_dtype(win, cdt, pad8=True), self.P(f"{pre}char_emb.char_convs.{i}.0.weight"),
-                           self.P(f"{pre}char_emb.char_convs.{i}.0.bias"), self._cache, relu=True)
-            feats.append(y.reshape(B * Lq, C - k + 1, -1).amax(dim=1))
+        # character CNN: lookup + dropout + 4 x (conv + ReLU + max over positions) in one kernel (csrc/charcnn.hip)
+        cfeat = ops.char_cnn(char_ids, self.P(pre + "char_emb.char_emb.weight"),
+                             [self.P(f"{pre}char_emb.char_convs.{i}.0.weight") for i in range(4)],
+                             [self.P(f"{pre}char_emb.char_convs.{i}.0.bias") for i in range(4)],
+                             dc.next("text.char"), cdt)
+        feats = [ops.to_dtype(wemb.reshape(B * Lq, -1), cdt), cfeat]
         emb = torch.cat(feats, dim=1)                                                    # [B*L, 400]
         return self._lin(emb, pre + "query_conv1d")
 

@@ -1,0 +1,315 @@
+// charcnn.hip -- CharacterEmbedding (reference models/layers.py:51-75) as one kernel each way: character
+// lookup (padding_idx 0) + dropout + the four Conv2d(char_dim -> 10k, kernel (1,k)), k = 1..4, + ReLU + max over
+// positions, written straight into the [words, ldo] embedding matrix that feeds query_conv1d.
+// It replaces 4 x {unfold, cast, 128-wide MFMA GEMM with N = 10..40, amax} and their backward chains
+// (~110 launches, ~0.8 ms of a cfg2 step).  The work is tiny (0.44 GFLOP forward): plain FMA on LDS-resident
+// operands.  Per workgroup: the conv weights TRANSPOSED in LDS ([c*k+j][out channel]: lanes of a wave read
+// consecutive out channels), the dropped-out character rows of WPB words in LDS (fp32 values rounded through
+// the compute dtype, like the operand of the GEMM path they replace).
+// Backward: dW/db partials per workgroup (two-stage, no atomics on the weights), the gradient of the
+// character rows scattered into the table gradient with float atomics (6000 addresses, spread in time).
+#include "common.h"
+
+namespace {
+
+constexpr int CC_NK = 4;            // kernel widths 1..4
+constexpr int CC_MAXC = 16;         // characters per word
+
+struct CharCnnArgs {
+  const int64_t* ids;               // [W, C]
+  const float* table;               // [num_chars, CD]
+  const float* w[CC_NK];            // [oc_k, CD, 1, k] fp32 masters
+  const float* b[CC_NK];            // [oc_k]
+  int oc[CC_NK];                    // out channels per width
+  int woff[CC_NK];                  // element offset of conv k in the LDS / partial weight block
+  int coff[CC_NK];                  // first output column of conv k
+  int W, C, CD, OT, wtot;           // words, chars per word, char dim, total out channels, total weight elements
+  float drop_p; uint32_t seed; const uint32_t* step;
+};
+
+template <typename T> __device__ __forceinline__ float round_through(float v) { return to_f<T>(from_f<T>(v)); }
+
+// LDS layout: Wt (T) [wtot] | ce (float) [WPB][C][CD] | (bwd) G float [WPB][OT], A int [WPB][OT]
+template <typename T>
+__device__ __forceinline__ void stage_weights(const CharCnnArgs& a, T* Wt) {
+#pragma unroll
+  for (int kk = 0; kk < CC_NK; ++kk) {
+    const int k = kk + 1, n = a.oc[kk] * a.CD * k;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {      // i = (o*CD + c)*k + j  (the parameter's own order)
+      const int o = i / (a.CD * k), r = i - o * (a.CD * k);
+      Wt[a.woff[kk] + r * a.oc[kk] + o] = from_f<T>(a.w[kk][i]);
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_chars(const CharCnnArgs& a, float* ce, int w0, int nw, uint32_t seed, uint32_t thresh,
+                                            float dscale) {
+  const int per = a.C * a.CD;
+  for (int i = threadIdx.x; i < nw * per; i += blockDim.x) {
+    const int wl = i / per, r = i - wl * per, pos = r / a.CD, d = r - pos * a.CD;
+    const int64_t word = w0 + wl;
+    const int64_t id = a.ids[word * a.C + pos];
+    float v = a.table[id * a.CD + d];
+    if (a.drop_p > 0.f) v = vmr_keep(seed, (uint64_t)(word * a.C + pos) * a.CD + d, thresh) ? v * dscale : 0.f;
+    ce[i] = round_through<T>(v);
+  }
+}
+
+template <typename T, int K, int CM>
+__device__ __forceinline__ void conv_fwd(const CharCnnArgs& a, const T* Wt, const float* ce, int w0, int nw, T* out, int64_t ldo,
+                                         int8_t* amax) {
+  const int kk = K - 1, oc = a.oc[kk], np = a.C - K + 1;
+  const T* wt = Wt + a.woff[kk];
+  for (int item = threadIdx.x; item < oc * nw; item += blockDim.x) {
+    const int o = item % oc, wl = item / oc;
+    const float* cw = ce + wl * a.C * a.CD;
+    float acc[CM];
+#pragma unroll
+    for (int p = 0; p < CM; ++p) acc[p] = 0.f;
+    for (int c = 0; c < a.CD; ++c) {
+      float wv[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) wv[j] = to_f<T>(wt[(c * K + j) * oc + o]);
+      float cv[CM];
+#pragma unroll
+      for (int p = 0; p < CM; ++p) cv[p] = p < a.C ? cw[p * a.CD + c] : 0.f;
+#pragma unroll
+      for (int p = 0; p < CM - K + 1; ++p)
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[p] += wv[j] * cv[p + j];
+    }
+    float best = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int p = 0; p < CM - K + 1; ++p)
+      if (p < np && acc[p] > best) { best = acc[p]; arg = p; }
+    best += a.b[kk][o];
+    const int64_t word = w0 + wl;
+    out[word * ldo + a.coff[kk] + o] = from_f<T>(fmaxf(best, 0.f));
+    amax[word * a.OT + a.coff[kk] + o] = (int8_t)arg;
+  }
+}
+
+template <typename T, int WPB, int CM>
+__global__ __launch_bounds__(256) void char_cnn_fwd_kernel(CharCnnArgs a, T* __restrict__ out, int64_t ldo,
+                                                           int8_t* __restrict__ amax) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* Wt = reinterpret_cast<T*>(smem);
+  float* ce = reinterpret_cast<float*>(smem + ((a.wtot * sizeof(T) + 15) & ~(size_t)15));
+  const uint32_t seed = vmr_seed(a.seed, a.step);
+  const uint32_t thresh = vmr_drop_thresh(a.drop_p);
+  const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  const int w0 = blockIdx.x * WPB, nw = min(WPB, a.W - w0);
+  stage_weights<T>(a, Wt);
+  stage_chars<T>(a, ce, w0, nw, seed, thresh, dscale);
+  __syncthreads();
+  conv_fwd<T, 1, CM>(a, Wt, ce, w0, nw, out, ldo, amax);
+  conv_fwd<T, 2, CM>(a, Wt, ce, w0, nw, out, ldo, amax);
+  conv_fwd<T, 3, CM>(a, Wt, ce, w0, nw, out, ldo, amax);
+  conv_fwd<T, 4, CM>(a, Wt, ce, w0, nw, out, ldo, amax);
+}
+
+// ---- backward: partial row of workgroup g = [W_1 | W_2 | W_3 | W_4 | b (OT)]  (wtot + OT floats)
+template <typename T, int K>
+__device__ __forceinline__ void conv_dw(const CharCnnArgs& a, const float* ce, const float* G, const int* A, int nw,
+                                        float* prow) {
+  const int kk = K - 1, oc = a.oc[kk];
+  for (int item = threadIdx.x; item < oc * a.CD; item += blockDim.x) {
+    const int o = item / a.CD, c = item - o * a.CD;
+    float acc[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[j] = 0.f;
+    for (int wl = 0; wl < nw; ++wl) {
+      const float g = G[wl * a.OT + a.coff[kk] + o];
+      if (g != 0.f) {
+        const int p = A[wl * a.OT + a.coff[kk] + o];
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] += g * ce[(wl * a.C + p + j) * a.CD + c];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) prow[a.woff[kk] + (o * a.CD + c) * K + j] = acc[j];
+  }
+}
+
+template <typename T, int WPB>
+__global__ __launch_bounds__(256) void char_cnn_bwd_kernel(CharCnnArgs a, const T* __restrict__ dout, const T* __restrict__ out,
+                                                           int64_t ldo, const int8_t* __restrict__ amax,
+                                                           float* __restrict__ part, float* __restrict__ dtable) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* Wt = reinterpret_cast<T*>(smem);
+  float* ce = reinterpret_cast<float*>(smem + ((a.wtot * sizeof(T) + 15) & ~(size_t)15));
+  float* G = ce + WPB * a.C * a.CD;
+  int* A = reinterpret_cast<int*>(G + WPB * a.OT);
+  const uint32_t seed = vmr_seed(a.seed, a.step);
+  const uint32_t thresh = vmr_drop_thresh(a.drop_p);
+  const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  const int w0 = blockIdx.x * WPB, nw = min(WPB, a.W - w0);
+  stage_weights<T>(a, Wt);
+  stage_chars<T>(a, ce, w0, nw, seed, thresh, dscale);
+  for (int i = threadIdx.x; i < nw * a.OT; i += blockDim.x) {
+    const int wl = i / a.OT, o = i - wl * a.OT;
+    const int64_t word = w0 + wl;
+    const float y = to_f<T>(out[word * ldo + o]);
+    G[i] = y > 0.f ? to_f<T>(dout[word * ldo + o]) : 0.f;   // ReLU
+    A[i] = amax[word * a.OT + o];
+  }
+  __syncthreads();
+  float* prow = part + (int64_t)blockIdx.x * (a.wtot + a.OT);
+  conv_dw<T, 1>(a, ce, G, A, nw, prow);
+  conv_dw<T, 2>(a, ce, G, A, nw, prow);
+  conv_dw<T, 3>(a, ce, G, A, nw, prow);
+  conv_dw<T, 4>(a, ce, G, A, nw, prow);
+  for (int o = threadIdx.x; o < a.OT; o += blockDim.x) {     // bias partials
+    float s = 0.f;
+    for (int wl = 0; wl < nw; ++wl) s += G[wl * a.OT + o];
+    prow[a.wtot + o] = s;
+  }
+  // gradient of the (dropped-out) character rows -> table rows; each thread accumulates its (word, channel)
+  // column over the positions in a private LDS strip (dynamic position index)
+  if (dtable) {
+    float* dl = reinterpret_cast<float*>(A + WPB * a.OT) + threadIdx.x * (CC_MAXC + 1);
+    for (int item = threadIdx.x; item < nw * a.CD; item += blockDim.x) {
+      const int wl = item / a.CD, c = item - wl * a.CD;
+      for (int p = 0; p < a.C; ++p) dl[p] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < CC_NK; ++kk) {
+        const int k = kk + 1, oc = a.oc[kk];
+        const T* wt = Wt + a.woff[kk];
+        for (int o = 0; o < oc; ++o) {
+          const float g = G[wl * a.OT + a.coff[kk] + o];
+          if (g != 0.f) {
+            const int p = A[wl * a.OT + a.coff[kk] + o];
+            for (int j = 0; j < k; ++j) dl[p + j] += g * to_f<T>(wt[(c * k + j) * oc + o]);
+          }
+        }
+      }
+      const int64_t word = w0 + wl;
+      for (int p = 0; p < a.C; ++p) {
+        const int64_t id = a.ids[word * a.C + p];
+        float v = dl[p];
+        if (a.drop_p > 0.f) v = vmr_keep(seed, (uint64_t)(word * a.C + p) * a.CD + c, thresh) ? v * dscale : 0.f;
+        if (id != 0 && v != 0.f) atomicAdd(&dtable[id * a.CD + c], v);     // padding_idx 0 receives no gradient
+      }
+    }
+  }
+}
+
+struct CcDst { float* w[CC_NK]; float* b[CC_NK]; int woff[CC_NK], wn[CC_NK], coff[CC_NK], oc[CC_NK]; };
+
+// dst += sum over partial rows; 16 rows per thread in flight, blockIdx.y walks the row groups
+__global__ __launch_bounds__(256) void char_cnn_reduce_kernel(const float* __restrict__ part, CcDst d, int nrows, int wtot, int OT) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= wtot + OT) return;
+  const int r0 = blockIdx.y * 16;
+  float v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = (r0 + k < nrows) ? part[(int64_t)(r0 + k) * (wtot + OT) + j] : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += v[k];
+  float* dst = nullptr;
+  if (j < wtot) {
+#pragma unroll
+    for (int kk = 0; kk < CC_NK; ++kk)
+      if (j >= d.woff[kk] && j < d.woff[kk] + d.wn[kk]) dst = d.w[kk] + (j - d.woff[kk]);
+  } else {
+    const int o = j - wtot;
+#pragma unroll
+    for (int kk = 0; kk < CC_NK; ++kk)
+      if (o >= d.coff[kk] && o < d.coff[kk] + d.oc[kk]) dst = d.b[kk] + (o - d.coff[kk]);
+  }
+  if (dst) atomicAdd(dst, s);
+}
+
+int fill_args(CharCnnArgs& a, const int64_t* ids, const float* table, const float* const* w, const float* const* b, const int* oc,
+              int W, int C, int CD, float drop_p, uint32_t seed, const uint32_t* step) {
+  a.ids = ids; a.table = table;
+  int wo = 0, co = 0;
+  for (int kk = 0; kk < CC_NK; ++kk) {
+    a.w[kk] = w[kk]; a.b[kk] = b[kk]; a.oc[kk] = oc[kk];
+    a.woff[kk] = wo; a.coff[kk] = co;
+    wo += oc[kk] * CD * (kk + 1);
+    co += oc[kk];
+  }
+  a.W = W; a.C = C; a.CD = CD; a.OT = co; a.wtot = wo;
+  a.drop_p = drop_p; a.seed = seed; a.step = step;
+  return 0;
+}
+
+
+}  // namespace
+
+extern "C" int vmr_char_cnn_ws_floats(int W, int CD, const int* oc, int dtype) {
+  int wtot = 0, ot = 0;
+  for (int kk = 0; kk < CC_NK; ++kk) { wtot += oc[kk] * CD * (kk + 1); ot += oc[kk]; }
+  const int wpb = dtype == VMR_BF16 ? 16 : 4;
+  return ((W + wpb - 1) / wpb) * (wtot + ot);
+}
+
+extern "C" int vmr_char_cnn_fwd(const int64_t* char_ids, const float* table, const float* const* w, const float* const* b,
+                                const int* oc, void* out, int64_t ldo, int8_t* amax, int W, int C, int CD, int dtype,
+                                float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream) {
+  VMR_CHECK(char_ids && table && w && b && oc && out && amax, "vmr_char_cnn_fwd: null pointer");
+  VMR_CHECK(C >= CC_NK && C <= CC_MAXC && CD >= 1, "vmr_char_cnn_fwd: need %d <= chars per word <= %d", CC_NK, CC_MAXC);
+  if (W == 0) return 0;
+  CharCnnArgs a;
+  fill_args(a, char_ids, table, w, b, oc, W, C, CD, drop_p, drop_seed, drop_step);
+  const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = dtype == VMR_BF16 ? 16 : 8;
+  const size_t lds = ((size_t)a.wtot * esz + 15) / 16 * 16 + (size_t)wpb * C * CD * 4;
+  VMR_CHECK(lds <= 160 * 1024, "vmr_char_cnn_fwd: operands do not fit LDS (%zu B)", lds);
+  const dim3 grid((unsigned)((W + wpb - 1) / wpb));
+#define VMR_CC_FWD(TT, WPBV, CMV)                                                                                          \
+  do {                                                                                                                     \
+    const void* fn = (const void*)char_cnn_fwd_kernel<TT, WPBV, CMV>;                                                      \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)    \
+      return vmr_fail(-5, "vmr_char_cnn_fwd: hipFuncSetAttribute");                                                        \
+    hipLaunchKernelGGL((char_cnn_fwd_kernel<TT, WPBV, CMV>), grid, dim3(256), lds, (hipStream_t)stream, a, (TT*)out, ldo,  \
+                       amax);                                                                                              \
+  } while (0)
+  if (dtype == VMR_BF16) { if (C <= 8) VMR_CC_FWD(bf16_t, 16, 8); else VMR_CC_FWD(bf16_t, 16, 16); }
+  else { if (C <= 8) VMR_CC_FWD(float, 8, 8); else VMR_CC_FWD(float, 8, 16); }
+#undef VMR_CC_FWD
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_char_cnn_bwd(const void* dout, const void* out, int64_t ldo, const int8_t* amax, const int64_t* char_ids,
+                                const float* table, const float* const* w, const float* const* b, const int* oc, float* const* dw,
+                                float* const* db, float* dtable /*nullable*/, float* workspace, int W, int C, int CD, int dtype,
+                                float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream) {
+  VMR_CHECK(dout && out && amax && char_ids && table && w && b && oc && dw && db && workspace, "vmr_char_cnn_bwd: null pointer");
+  VMR_CHECK(C >= CC_NK && C <= CC_MAXC && CD >= 1, "vmr_char_cnn_bwd: need %d <= chars per word <= %d", CC_NK, CC_MAXC);
+  if (W == 0) return 0;
+  CharCnnArgs a;
+  fill_args(a, char_ids, table, w, b, oc, W, C, CD, drop_p, drop_seed, drop_step);
+  const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = dtype == VMR_BF16 ? 16 : 4;
+  const size_t lds = ((size_t)a.wtot * esz + 15) / 16 * 16 + (size_t)wpb * C * CD * 4 + (size_t)wpb * a.OT * 8 +
+                     (size_t)256 * (CC_MAXC + 1) * 4;
+  VMR_CHECK(lds <= 160 * 1024, "vmr_char_cnn_bwd: operands do not fit LDS (%zu B)", lds);
+  const int nblk = (W + wpb - 1) / wpb;
+  if (dtype == VMR_BF16) {
+    const void* fn = (const void*)char_cnn_bwd_kernel<bf16_t, 16>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return vmr_fail(-5, "vmr_char_cnn_bwd: hipFuncSetAttribute");
+    hipLaunchKernelGGL((char_cnn_bwd_kernel<bf16_t, 16>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, a, (const bf16_t*)dout,
+                       (const bf16_t*)out, ldo, amax, workspace, dtable);
+  } else {
+    const void* fn = (const void*)char_cnn_bwd_kernel<float, 4>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return vmr_fail(-5, "vmr_char_cnn_bwd: hipFuncSetAttribute");
+    hipLaunchKernelGGL((char_cnn_bwd_kernel<float, 4>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, a, (const float*)dout,
+                       (const float*)out, ldo, amax, workspace, dtable);
+  }
+  VMR_LAUNCH_CHECK();
+  CcDst d;
+  for (int kk = 0; kk < CC_NK; ++kk) {
+    d.w[kk] = dw[kk]; d.b[kk] = db[kk]; d.woff[kk] = a.woff[kk]; d.wn[kk] = oc[kk] * CD * (kk + 1);
+    d.coff[kk] = a.coff[kk]; d.oc[kk] = oc[kk];
+  }
+  hipLaunchKernelGGL(char_cnn_reduce_kernel, dim3(cdiv(a.wtot + a.OT, 256), cdiv(nblk, 16)), dim3(256), 0, (hipStream_t)stream,
+                     workspace, d, nblk, a.wtot, a.OT);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}

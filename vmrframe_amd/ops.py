@@ -644,6 +644,67 @@ def scale_shift(x, a, b):
     return _ScaleShift.apply(x, a, b)
 
 
+class _CharCnn(torch.autograd.Function):
+    """CharacterEmbedding (reference models/layers.py:51-75): lookup + dropout + 4 x (conv (1,k) + ReLU + max over
+    positions) in one kernel each way (csrc/charcnn.hip)."""
+
+    @staticmethod
+    def forward(ctx, char_ids, table, drop, dtype, *wb):
+        L.require_gpu(char_ids, table)
+        ws_, bs_ = wb[:4], wb[4:]
+        ids = char_ids.contiguous()
+        Wn = ids.numel() // ids.shape[-1]
+        Cc = ids.shape[-1]
+        CD = table.shape[1]
+        oc = [w.shape[0] for w in ws_]
+        for k, w in enumerate(ws_):
+            assert tuple(w.shape) == (oc[k], CD, 1, k + 1) and w.is_contiguous()
+        OT = sum(oc)
+        out = torch.empty(Wn, OT, device=table.device, dtype=dtype)
+        amax = torch.empty(Wn, OT, device=table.device, dtype=torch.int8)
+        wp = (C.c_void_p * 4)(*[w.data_ptr() for w in ws_])
+        bp = (C.c_void_p * 4)(*[b.data_ptr() for b in bs_])
+        ocp = (C.c_int * 4)(*oc)
+        L.check(L.lib().vmr_char_cnn_fwd(ids.data_ptr(), table.data_ptr(), wp, bp, ocp, out.data_ptr(), OT, amax.data_ptr(), Wn,
+                                         Cc, CD, L.dtype_code(out), drop[0], drop[1], _ptr(drop[2]), L.stream_ptr()),
+                "vmr_char_cnn_fwd")
+        ctx.save_for_backward(ids, table, out, amax, *wb)
+        ctx.meta = (drop, oc, Wn, Cc, CD, OT)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, table, out, amax, *wb = ctx.saved_tensors
+        drop, oc, Wn, Cc, CD, OT = ctx.meta
+        ws_, bs_ = wb[:4], wb[4:]
+        dout = dout.contiguous()
+        dev = out.device
+        gts = [main_grad(t) for t in (*ws_, *bs_)]
+        direct = all(g is not None for g in gts)
+        gws = [g if direct else torch.zeros_like(t, dtype=torch.float32) for g, t in zip(gts[:4], ws_)]
+        gbs = [g if direct else torch.zeros_like(t, dtype=torch.float32) for g, t in zip(gts[4:], bs_)]
+        gtab = main_grad(table)
+        dtab = gtab if gtab is not None else torch.zeros_like(table, dtype=torch.float32)
+        ocp = (C.c_int * 4)(*oc)
+        nws = L.lib().vmr_char_cnn_ws_floats(Wn, CD, ocp, L.dtype_code(out))
+        ws = torch.empty(nws, device=dev, dtype=torch.float32)
+        wp = (C.c_void_p * 4)(*[w.data_ptr() for w in ws_])
+        bp = (C.c_void_p * 4)(*[b.data_ptr() for b in bs_])
+        dwp = (C.c_void_p * 4)(*[g.data_ptr() for g in gws])
+        dbp = (C.c_void_p * 4)(*[g.data_ptr() for g in gbs])
+        L.check(L.lib().vmr_char_cnn_bwd(dout.data_ptr(), out.data_ptr(), OT, amax.data_ptr(), ids.data_ptr(), table.data_ptr(),
+                                         wp, bp, ocp, dwp, dbp, dtab.data_ptr(), ws.data_ptr(), Wn, Cc, CD, L.dtype_code(out),
+                                         drop[0], drop[1], _ptr(drop[2]), L.stream_ptr()), "vmr_char_cnn_bwd")
+        gw_ret = [None] * 8 if direct else [*gws, *gbs]
+        return (None, None if gtab is not None else dtab, None, None, *gw_ret)
+
+
+def char_cnn(char_ids, table, conv_weights, conv_biases, drop, dtype):
+    """char_ids int64 [..., C]; table fp32 [num_chars, char_dim]; 4 conv weights [10k, char_dim, 1, k] + biases
+    -> [words, sum(out channels)] in `dtype`."""
+    return _CharCnn.apply(char_ids, table, drop, dtype, *conv_weights, *conv_biases)
+
+
 def group_view(params):
     """ONE flat fp32 view over parameters laid out back to back in the flat arena (optim.FlatArena
     places the members of model.weight_groups() consecutively), carrying the matching view of the
