@@ -42,16 +42,23 @@ __device__ __forceinline__ void stage_weights(const CharCnnArgs& a, T* Wt) {
   }
 }
 
-template <typename T>
+// character rows of the workgroup's words, dropped out, rounded through T, stored [word][channel][CP positions]
+// (positions contiguous: the convolution reads them as 16-byte vectors; positions >= C are zero)
+// POS_MAJOR (backward): [word][position][channel] instead, channel contiguous (lanes differ in the channel there)
+template <typename T, int CP, bool POS_MAJOR = false>
 __device__ __forceinline__ void stage_chars(const CharCnnArgs& a, float* ce, int w0, int nw, uint32_t seed, uint32_t thresh,
                                             float dscale) {
-  const int per = a.C * a.CD;
+  const int per = CP * a.CD;
   for (int i = threadIdx.x; i < nw * per; i += blockDim.x) {
-    const int wl = i / per, r = i - wl * per, pos = r / a.CD, d = r - pos * a.CD;
-    const int64_t word = w0 + wl;
-    const int64_t id = a.ids[word * a.C + pos];
-    float v = a.table[id * a.CD + d];
-    if (a.drop_p > 0.f) v = vmr_keep(seed, (uint64_t)(word * a.C + pos) * a.CD + d, thresh) ? v * dscale : 0.f;
+    const int wl = i / per, r = i - wl * per;
+    const int d = POS_MAJOR ? r % a.CD : r / CP, pos = POS_MAJOR ? r / a.CD : r - (r / CP) * CP;
+    float v = 0.f;
+    if (pos < a.C) {
+      const int64_t word = w0 + wl;
+      const int64_t id = a.ids[word * a.C + pos];
+      v = a.table[id * a.CD + d];
+      if (a.drop_p > 0.f) v = vmr_keep(seed, (uint64_t)(word * a.C + pos) * a.CD + d, thresh) ? v * dscale : 0.f;
+    }
     ce[i] = round_through<T>(v);
   }
 }
@@ -63,7 +70,7 @@ __device__ __forceinline__ void conv_fwd(const CharCnnArgs& a, const T* Wt, cons
   const T* wt = Wt + a.woff[kk];
   for (int item = threadIdx.x; item < oc * nw; item += blockDim.x) {
     const int o = item % oc, wl = item / oc;
-    const float* cw = ce + wl * a.C * a.CD;
+    const float* cw = ce + wl * CM * a.CD;
     float acc[CM];
 #pragma unroll
     for (int p = 0; p < CM; ++p) acc[p] = 0.f;
@@ -73,7 +80,10 @@ __device__ __forceinline__ void conv_fwd(const CharCnnArgs& a, const T* Wt, cons
       for (int j = 0; j < K; ++j) wv[j] = to_f<T>(wt[(c * K + j) * oc + o]);
       float cv[CM];
 #pragma unroll
-      for (int p = 0; p < CM; ++p) cv[p] = p < a.C ? cw[p * a.CD + c] : 0.f;
+      for (int p4 = 0; p4 < CM; p4 += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(cw + c * CM + p4);
+        cv[p4] = t[0]; cv[p4 + 1] = t[1]; cv[p4 + 2] = t[2]; cv[p4 + 3] = t[3];
+      }
 #pragma unroll
       for (int p = 0; p < CM - K + 1; ++p)
 #pragma unroll
@@ -92,7 +102,7 @@ __device__ __forceinline__ void conv_fwd(const CharCnnArgs& a, const T* Wt, cons
 }
 
 template <typename T, int WPB, int CM>
-__global__ __launch_bounds__(256) void char_cnn_fwd_kernel(CharCnnArgs a, T* __restrict__ out, int64_t ldo,
+__global__ __launch_bounds__(1024) void char_cnn_fwd_kernel(CharCnnArgs a, T* __restrict__ out, int64_t ldo,
                                                            int8_t* __restrict__ amax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* Wt = reinterpret_cast<T*>(smem);
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256) void char_cnn_fwd_kernel(CharCnnArgs a, T* __r
   const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const int w0 = blockIdx.x * WPB, nw = min(WPB, a.W - w0);
   stage_weights<T>(a, Wt);
-  stage_chars<T>(a, ce, w0, nw, seed, thresh, dscale);
+  stage_chars<T, CM>(a, ce, w0, nw, seed, thresh, dscale);
   __syncthreads();
   conv_fwd<T, 1, CM>(a, Wt, ce, w0, nw, out, ldo, amax);
   conv_fwd<T, 2, CM>(a, Wt, ce, w0, nw, out, ldo, amax);
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(256) void char_cnn_fwd_kernel(CharCnnArgs a, T* __r
 }
 
 // ---- backward: partial row of workgroup g = [W_1 | W_2 | W_3 | W_4 | b (OT)]  (wtot + OT floats)
-template <typename T, int K>
+template <typename T, int K, int CP>
 __device__ __forceinline__ void conv_dw(const CharCnnArgs& a, const float* ce, const float* G, const int* A, int nw,
                                         float* prow) {
   const int kk = K - 1, oc = a.oc[kk];
@@ -125,7 +135,7 @@ __device__ __forceinline__ void conv_dw(const CharCnnArgs& a, const float* ce, c
       if (g != 0.f) {
         const int p = A[wl * a.OT + a.coff[kk] + o];
 #pragma unroll
-        for (int j = 0; j < K; ++j) acc[j] += g * ce[(wl * a.C + p + j) * a.CD + c];
+        for (int j = 0; j < K; ++j) acc[j] += g * ce[(wl * CP + p + j) * a.CD + c];
       }
     }
 #pragma unroll
@@ -133,21 +143,20 @@ __device__ __forceinline__ void conv_dw(const CharCnnArgs& a, const float* ce, c
   }
 }
 
-template <typename T, int WPB>
-__global__ __launch_bounds__(256) void char_cnn_bwd_kernel(CharCnnArgs a, const T* __restrict__ dout, const T* __restrict__ out,
+template <typename T, int WPB, int CP>
+__global__ __launch_bounds__(1024) void char_cnn_bwd_kernel(CharCnnArgs a, const T* __restrict__ dout, const T* __restrict__ out,
                                                            int64_t ldo, const int8_t* __restrict__ amax,
                                                            float* __restrict__ part, float* __restrict__ dtable) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* Wt = reinterpret_cast<T*>(smem);
-  float* ce = reinterpret_cast<float*>(smem + ((a.wtot * sizeof(T) + 15) & ~(size_t)15));
-  float* G = ce + WPB * a.C * a.CD;
+  float* ce = reinterpret_cast<float*>(smem);          // (no weights in LDS here: the row-gradient loop reads the
+                                                       //  120 KB of fp32 masters through L1/L2, coalesced enough)
+  float* G = ce + WPB * CP * a.CD;
   int* A = reinterpret_cast<int*>(G + WPB * a.OT);
   const uint32_t seed = vmr_seed(a.seed, a.step);
   const uint32_t thresh = vmr_drop_thresh(a.drop_p);
   const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const int w0 = blockIdx.x * WPB, nw = min(WPB, a.W - w0);
-  stage_weights<T>(a, Wt);
-  stage_chars<T>(a, ce, w0, nw, seed, thresh, dscale);
+  stage_chars<T, CP, true>(a, ce, w0, nw, seed, thresh, dscale);
   for (int i = threadIdx.x; i < nw * a.OT; i += blockDim.x) {
     const int wl = i / a.OT, o = i - wl * a.OT;
     const int64_t word = w0 + wl;
@@ -157,41 +166,39 @@ __global__ __launch_bounds__(256) void char_cnn_bwd_kernel(CharCnnArgs a, const 
   }
   __syncthreads();
   float* prow = part + (int64_t)blockIdx.x * (a.wtot + a.OT);
-  conv_dw<T, 1>(a, ce, G, A, nw, prow);
-  conv_dw<T, 2>(a, ce, G, A, nw, prow);
-  conv_dw<T, 3>(a, ce, G, A, nw, prow);
-  conv_dw<T, 4>(a, ce, G, A, nw, prow);
+  conv_dw<T, 1, CP>(a, ce, G, A, nw, prow);
+  conv_dw<T, 2, CP>(a, ce, G, A, nw, prow);
+  conv_dw<T, 3, CP>(a, ce, G, A, nw, prow);
+  conv_dw<T, 4, CP>(a, ce, G, A, nw, prow);
   for (int o = threadIdx.x; o < a.OT; o += blockDim.x) {     // bias partials
     float s = 0.f;
     for (int wl = 0; wl < nw; ++wl) s += G[wl * a.OT + o];
     prow[a.wtot + o] = s;
   }
-  // gradient of the (dropped-out) character rows -> table rows; each thread accumulates its (word, channel)
-  // column over the positions in a private LDS strip (dynamic position index)
+  // gradient of the (dropped-out) character rows -> table rows: one thread per (word, position, channel), channel
+  // fastest, so a wave shares (word, position): the arg-max / gradient reads broadcast and the branch is uniform
   if (dtable) {
-    float* dl = reinterpret_cast<float*>(A + WPB * a.OT) + threadIdx.x * (CC_MAXC + 1);
-    for (int item = threadIdx.x; item < nw * a.CD; item += blockDim.x) {
-      const int wl = item / a.CD, c = item - wl * a.CD;
-      for (int p = 0; p < a.C; ++p) dl[p] = 0.f;
+    for (int item = threadIdx.x; item < nw * a.CD * a.C; item += blockDim.x) {
+      const int wl = item / (a.CD * a.C), r = item - wl * (a.CD * a.C), q = r / a.CD, c = r - q * a.CD;
+      const int64_t word = w0 + wl;
+      const int64_t id = a.ids[word * a.C + q];
+      float d = 0.f;
+      if (id != 0) {                                            // padding_idx 0 receives no gradient
 #pragma unroll
-      for (int kk = 0; kk < CC_NK; ++kk) {
-        const int k = kk + 1, oc = a.oc[kk];
-        const T* wt = Wt + a.woff[kk];
-        for (int o = 0; o < oc; ++o) {
-          const float g = G[wl * a.OT + a.coff[kk] + o];
-          if (g != 0.f) {
-            const int p = A[wl * a.OT + a.coff[kk] + o];
-            for (int j = 0; j < k; ++j) dl[p + j] += g * to_f<T>(wt[(c * k + j) * oc + o]);
+        for (int kk = 0; kk < CC_NK; ++kk) {
+          const int k = kk + 1, oc = a.oc[kk];
+          const float* wk = a.w[kk];
+          const float* Gk = G + wl * a.OT + a.coff[kk];
+          const int* Ak = A + wl * a.OT + a.coff[kk];
+          for (int o = 0; o < oc; ++o) {
+            const float g = Gk[o];
+            const int j = q - Ak[o];
+            if (g != 0.f && j >= 0 && j < k) d += g * round_through<T>(wk[(o * a.CD + c) * k + j]);
           }
         }
+        if (a.drop_p > 0.f && !vmr_keep(seed, (uint64_t)(word * a.C + q) * a.CD + c, thresh)) d = 0.f;
       }
-      const int64_t word = w0 + wl;
-      for (int p = 0; p < a.C; ++p) {
-        const int64_t id = a.ids[word * a.C + p];
-        float v = dl[p];
-        if (a.drop_p > 0.f) v = vmr_keep(seed, (uint64_t)(word * a.C + p) * a.CD + c, thresh) ? v * dscale : 0.f;
-        if (id != 0 && v != 0.f) atomicAdd(&dtable[id * a.CD + c], v);     // padding_idx 0 receives no gradient
-      }
+      if (d != 0.f) atomicAdd(&dtable[id * a.CD + c], d * dscale);
     }
   }
 }
@@ -244,7 +251,7 @@ int fill_args(CharCnnArgs& a, const int64_t* ids, const float* table, const floa
 extern "C" int vmr_char_cnn_ws_floats(int W, int CD, const int* oc, int dtype) {
   int wtot = 0, ot = 0;
   for (int kk = 0; kk < CC_NK; ++kk) { wtot += oc[kk] * CD * (kk + 1); ot += oc[kk]; }
-  const int wpb = dtype == VMR_BF16 ? 16 : 4;
+  const int wpb = dtype == VMR_BF16 ? 8 : 4;
   return ((W + wpb - 1) / wpb) * (wtot + ot);
 }
 
@@ -256,8 +263,9 @@ extern "C" int vmr_char_cnn_fwd(const int64_t* char_ids, const float* table, con
   if (W == 0) return 0;
   CharCnnArgs a;
   fill_args(a, char_ids, table, w, b, oc, W, C, CD, drop_p, drop_seed, drop_step);
-  const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = dtype == VMR_BF16 ? 16 : 8;
-  const size_t lds = ((size_t)a.wtot * esz + 15) / 16 * 16 + (size_t)wpb * C * CD * 4;
+  const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = dtype == VMR_BF16 ? 8 : 4;
+  const int cp = C <= 8 ? 8 : 16;
+  const size_t lds = ((size_t)a.wtot * esz + 15) / 16 * 16 + (size_t)wpb * cp * CD * 4;
   VMR_CHECK(lds <= 160 * 1024, "vmr_char_cnn_fwd: operands do not fit LDS (%zu B)", lds);
   const dim3 grid((unsigned)((W + wpb - 1) / wpb));
 #define VMR_CC_FWD(TT, WPBV, CMV)                                                                                          \
@@ -265,11 +273,11 @@ extern "C" int vmr_char_cnn_fwd(const int64_t* char_ids, const float* table, con
     const void* fn = (const void*)char_cnn_fwd_kernel<TT, WPBV, CMV>;                                                      \
     if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)    \
       return vmr_fail(-5, "vmr_char_cnn_fwd: hipFuncSetAttribute");                                                        \
-    hipLaunchKernelGGL((char_cnn_fwd_kernel<TT, WPBV, CMV>), grid, dim3(256), lds, (hipStream_t)stream, a, (TT*)out, ldo,  \
+    hipLaunchKernelGGL((char_cnn_fwd_kernel<TT, WPBV, CMV>), grid, dim3(1024), lds, (hipStream_t)stream, a, (TT*)out, ldo,  \
                        amax);                                                                                              \
   } while (0)
-  if (dtype == VMR_BF16) { if (C <= 8) VMR_CC_FWD(bf16_t, 16, 8); else VMR_CC_FWD(bf16_t, 16, 16); }
-  else { if (C <= 8) VMR_CC_FWD(float, 8, 8); else VMR_CC_FWD(float, 8, 16); }
+  if (dtype == VMR_BF16) { if (C <= 8) VMR_CC_FWD(bf16_t, 8, 8); else VMR_CC_FWD(bf16_t, 8, 16); }
+  else { if (C <= 8) VMR_CC_FWD(float, 4, 8); else VMR_CC_FWD(float, 4, 16); }
 #undef VMR_CC_FWD
   VMR_LAUNCH_CHECK();
   return 0;
@@ -284,24 +292,22 @@ extern "C" int vmr_char_cnn_bwd(const void* dout, const void* out, int64_t ldo, 
   if (W == 0) return 0;
   CharCnnArgs a;
   fill_args(a, char_ids, table, w, b, oc, W, C, CD, drop_p, drop_seed, drop_step);
-  const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = dtype == VMR_BF16 ? 16 : 4;
-  const size_t lds = ((size_t)a.wtot * esz + 15) / 16 * 16 + (size_t)wpb * C * CD * 4 + (size_t)wpb * a.OT * 8 +
-                     (size_t)256 * (CC_MAXC + 1) * 4;
+  const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = dtype == VMR_BF16 ? 8 : 4, cp = C <= 8 ? 8 : 16;
+  const size_t lds = (size_t)wpb * cp * CD * 4 + (size_t)wpb * a.OT * 8;
+  (void)esz;
   VMR_CHECK(lds <= 160 * 1024, "vmr_char_cnn_bwd: operands do not fit LDS (%zu B)", lds);
   const int nblk = (W + wpb - 1) / wpb;
-  if (dtype == VMR_BF16) {
-    const void* fn = (const void*)char_cnn_bwd_kernel<bf16_t, 16>;
-    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return vmr_fail(-5, "vmr_char_cnn_bwd: hipFuncSetAttribute");
-    hipLaunchKernelGGL((char_cnn_bwd_kernel<bf16_t, 16>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, a, (const bf16_t*)dout,
-                       (const bf16_t*)out, ldo, amax, workspace, dtable);
-  } else {
-    const void* fn = (const void*)char_cnn_bwd_kernel<float, 4>;
-    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return vmr_fail(-5, "vmr_char_cnn_bwd: hipFuncSetAttribute");
-    hipLaunchKernelGGL((char_cnn_bwd_kernel<float, 4>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, a, (const float*)dout,
-                       (const float*)out, ldo, amax, workspace, dtable);
-  }
+#define VMR_CC_BWD(TT, WPBV, CPV)                                                                                          \
+  do {                                                                                                                     \
+    const void* fn = (const void*)char_cnn_bwd_kernel<TT, WPBV, CPV>;                                                      \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)    \
+      return vmr_fail(-5, "vmr_char_cnn_bwd: hipFuncSetAttribute");                                                        \
+    hipLaunchKernelGGL((char_cnn_bwd_kernel<TT, WPBV, CPV>), dim3(nblk), dim3(1024), lds, (hipStream_t)stream, a,          \
+                       (const TT*)dout, (const TT*)out, ldo, amax, workspace, dtable);                                    \
+  } while (0)
+  if (dtype == VMR_BF16) { if (cp == 8) VMR_CC_BWD(bf16_t, 8, 8); else VMR_CC_BWD(bf16_t, 8, 16); }
+  else { if (cp == 8) VMR_CC_BWD(float, 4, 8); else VMR_CC_BWD(float, 4, 16); }
+#undef VMR_CC_BWD
   VMR_LAUNCH_CHECK();
   CcDst d;
   for (int kk = 0; kk < CC_NK; ++kk) {
