@@ -234,12 +234,22 @@ __global__ __launch_bounds__(256) void dpos_kernel(const T* __restrict__ dy, flo
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int s = (int)(idx / cpr), c = (int)(idx - (int64_t)s * cpr) * 8;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int64_t row = s; row < rows; row += S) {
-      float g[8];
-      Vec8<T>::load(dy + row * D + c, g);
-      const uint32_t keep = drop_p > 0.f ? vmr_keep8(seed, (uint64_t)row * D + c, thresh) : 0xFFu;
+    typedef __attribute__((ext_vector_type(8))) T TV8;
+    for (int64_t row0 = s; row0 < rows; row0 += (int64_t)8 * S) {   // 8 batch rows in flight (the walk is latency-bound)
+      TV8 g8[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += (drop_p > 0.f) ? (((keep >> e) & 1) ? g[e] * dscale : 0.f) : g[e];
+      for (int u = 0; u < 8; ++u) g8[u] = *reinterpret_cast<const TV8*>(dy + min(row0 + (int64_t)u * S, rows - 1) * D + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t row = row0 + (int64_t)u * S;
+        if (row >= rows) continue;
+        const uint32_t keep = drop_p > 0.f ? vmr_keep8(seed, (uint64_t)row * D + c, thresh) : 0xFFu;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float g = (float)g8[u][e];
+          acc[e] += (drop_p > 0.f) ? (((keep >> e) & 1) ? g * dscale : 0.f) : g;
+        }
+      }
     }
     float old[8];
     Vec8<float>::load(dpos + (int64_t)s * D + c, old);
