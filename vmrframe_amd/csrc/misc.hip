@@ -29,6 +29,43 @@ __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, T
   }
 }
 
+// 8 destination columns per thread (ld_dst % 8 == 0; source rows 16-byte aligned where SRC_VEC): 16-byte stores,
+// one hash pair per 8 elements -- the [tokens, D] dropout copies of the CQ score path and the [B*T, V] input cast
+template <typename TS, typename TD, bool SRC_VEC>
+__global__ __launch_bounds__(256) void cast8_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t rows, int cols,
+                                                    int64_t ld_src, int64_t ld_dst, float drop_p, uint32_t seed0,
+                                                    const uint32_t* __restrict__ step) {
+  const uint32_t seed = vmr_seed(seed0, step);
+  const uint32_t thresh = vmr_drop_thresh(drop_p);
+  const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const int cpr = (int)(ld_dst / 8);
+  const int64_t total = rows * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cpr;
+    const int c = (int)(i - r * cpr) * 8;
+    float v[8];
+    if (SRC_VEC && c + 8 <= cols) Vec8<TS>::load(src + r * ld_src + c, v);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (c + e < cols) ? to_f<TS>(src[r * ld_src + c + e]) : 0.f;
+    }
+    if (drop_p > 0.f) {
+      const uint64_t idx = (uint64_t)r * cols + c;
+      if ((idx & 3) == 0) {
+        const uint32_t keep = vmr_keep8(seed, idx, thresh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ((keep >> e) & 1) ? v[e] * dscale : 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = vmr_keep(seed, idx + e, thresh) ? v[e] * dscale : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (c + e >= cols) v[e] = 0.f;
+    }
+    Vec8<TD>::store(dst + r * ld_dst + c, v);
+  }
+}
+
 // ------------------------------------------------ relu/dropout bwd + bias grad
 // MODE 0: db[c] += sum_r dy[r,c]                                   (plain bias)
 // MODE 1: dz = dy * scale * (h > 0)            ; db += colsum(dz)  (ReLU [+dropout]: h is the
@@ -229,6 +266,19 @@ template <typename TS>
 int launch_cast(const void* src, void* dst, int dst_dtype, int64_t rows, int cols, int64_t ld_src, int64_t ld_dst,
                 float drop_p, uint32_t seed, const uint32_t* step, hipStream_t st) {
   const int64_t total = rows * ld_dst;
+  const int spv = 16 / (int)sizeof(TS);   // source elements per 16 bytes
+  const bool dst_ok = ld_dst % 8 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+  if (dst_ok) {   // 8 columns per thread, 16-byte stores (and loads where the source rows are 16-byte aligned)
+    const bool src_vec = ld_src % spv == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    const int g8 = (int)min((int64_t)8192, (total / 8 + 255) / 256);
+#define VMR_CAST8(TD, SV)                                                                                          \
+  hipLaunchKernelGGL((cast8_kernel<TS, TD, SV>), dim3(g8), dim3(256), 0, st, (const TS*)src, (TD*)dst, rows, cols, \
+                     ld_src, ld_dst, drop_p, seed, step)
+    if (dst_dtype == VMR_BF16) { if (src_vec) VMR_CAST8(bf16_t, true); else VMR_CAST8(bf16_t, false); }
+    else { if (src_vec) VMR_CAST8(float, true); else VMR_CAST8(float, false); }
+#undef VMR_CAST8
+    return 0;
+  }
   const int grid = (int)min((int64_t)8192, (total + 255) / 256);
   if (dst_dtype == VMR_BF16)
     hipLaunchKernelGGL((cast_kernel<TS, bf16_t>), dim3(grid), dim3(256), 0, st, (const TS*)src, (bf16_t*)dst, rows, cols,
