@@ -45,9 +45,8 @@ def test_gemm_exact_integer_all_layouts(dev, dt, shape):
 
 @pytest.mark.parametrize("shape", [(512, 256, 128), (768, 384, 192), (9472, 1024, 128), (1024, 1024, 2368)])
 def test_gemm_lds_dma_kernels_exact(dev, shape):
-    """The interior LDS-DMA kernels (256x128 and 128x128 tiles, all four layouts), including the
-    ragged-M split ([8192 | 1280] rows -> big tiles + small tiles) and a fused epilogue with dropout
-    whose counter must stay row-consistent across the split."""
+    """The interior LDS-DMA kernels (128x128 and 160x128 tiles, all four layouts), including the ragged last
+    row tile of the tall variant at [9472 x 1024] and fused epilogues with dropout."""
     ops = _ops()
     from vmrframe_amd import _lib as L
     M, N, K = shape
@@ -540,6 +539,28 @@ def test_char_cnn_dropout_is_consistent(dev):
     assert abs(fd.item() - an.item()) <= 3e-2 * max(1.0, abs(an.item())), (fd.item(), an.item())
     a, b = ops.char_cnn(ids, table, ws, bs, drop, torch.float32), ops.char_cnn(ids, table, ws, bs, (0.3, 78, None), torch.float32)
     assert not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(300, 500, 512), (64, 1024, 1024), (37, 20, 24)])
+def test_cast_pad_dropout_matches_scalar_definition(dev, shape):
+    """vmr_cast (vector path: 8 columns per thread) = zero-padded cast with the counter-based input dropout
+    (reference models/layers.py:120), checked against the mask generator of the same stream."""
+    ops = _ops()
+    rows, cols, ld = shape
+    torch.manual_seed(43)
+    x = torch.randn(rows, cols, device=dev)
+    out = ops.cast_pad(x, torch.bfloat16, (0.25, 99, None), mult=64 if ld % 64 == 0 else 8)
+    assert out.shape == (rows, ld)
+    mask = ops.dropout_mask(rows * cols, 0.25, 99, dev).view(rows, cols)
+    ref = (x * mask).to(torch.bfloat16)
+    assert torch.equal(out[:, :cols], ref)
+    assert (out[:, cols:] == 0).all()
+    plain = ops.cast_pad(x, torch.bfloat16, ops.NO_DROP, mult=64 if ld % 64 == 0 else 8)
+    assert torch.equal(plain[:, :cols], x.to(torch.bfloat16))
+
+
+def _ceil8(v):
+    return (v + 7) // 8 * 8
 
 
 def test_soft_ce_matches_torch(dev):

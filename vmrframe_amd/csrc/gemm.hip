@@ -624,151 +624,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
   }
 }
 
-// ------------------------------------------- bf16 LDS-DMA kernel, 256x128 tile
-// 512 threads = 8 waves (4 along M x 2 along N, 64x64 per wave), BK = 64 (whole 128-B lines for
-// k-contiguous operands), 3-stage LDS ring of 48 KiB (144 KiB, one workgroup per CU): the loads
-// of K-step t+2 are issued while step t is computed.  Relative to two 128x128 workgroups on a CU
-// the B tile is fetched once instead of twice (1.33x fewer L2->LDS bytes per flop) and the ring is
-// one stage deeper.  Requires M % 256 == 0, N % 128 == 0, K % 64 == 0 (the host splits ragged M).
-constexpr int BIG_BM = 256, BIG_BK = 64, BIG_NST = 3;
-constexpr int BIG_A_BYTES = BIG_BM * BIG_BK * 2;   // 32 KiB
-constexpr int BIG_B_BYTES = 128 * BIG_BK * 2;      // 16 KiB
-constexpr int BIG_STAGE = BIG_A_BYTES + BIG_B_BYTES;
-constexpr int BIG_SMEM = BIG_NST * BIG_STAGE;      // 147,456 B
-
-// A operand of the 256-row tile: k-contiguous image [256][128 B] or transposed image [64 k][512 B]
-template <bool KC>
-__device__ __forceinline__ void dma_operand_a256(const bf16_t* __restrict__ P, int64_t ld, int r0, int k0,
-                                                 unsigned char* lds, int wid, int lane) {
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = wid * 4 + jj;  // 32 blocks of 1 KiB
-    const bf16_t* src;
-    if (KC) {
-      const int row = 8 * j + (lane >> 3);
-      const int c = (lane & 7) ^ (row & 7);
-      src = P + (int64_t)(r0 + row) * ld + k0 + c * 8;
-    } else {
-      const int r = 2 * j + (lane >> 5);
-      const int ph16 = lane & 31;
-      const int c32 = (ph16 >> 1) ^ swz_tr(r);
-      src = P + (int64_t)(k0 + r) * ld + r0 + (c32 * 2 + (ph16 & 1)) * 8;
-    }
-    __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)(lds + j * 1024), 16, 0, 0);
-  }
-}
-// B operand (128 rows / cols): 16 blocks, 2 per wave
-template <bool KC>
-__device__ __forceinline__ void dma_operand_b128(const bf16_t* __restrict__ P, int64_t ld, int r0, int k0,
-                                                 unsigned char* lds, int wid, int lane) {
-#pragma unroll
-  for (int jj = 0; jj < 2; ++jj) {
-    const int j = wid * 2 + jj;
-    const bf16_t* src;
-    if (KC) {
-      const int row = 8 * j + (lane >> 3);
-      const int c = (lane & 7) ^ (row & 7);
-      src = P + (int64_t)(r0 + row) * ld + k0 + c * 8;
-    } else {
-      const int r = 4 * j + (lane >> 4);
-      const int ph16 = lane & 15;
-      const int c32 = (ph16 >> 1) ^ swz_tr(r);
-      src = P + (int64_t)(k0 + r) * ld + r0 + (c32 * 2 + (ph16 & 1)) * 8;
-    }
-    __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)(lds + j * 1024), 16, 0, 0);
-  }
-}
-// fragment of the transposed 256-wide A image (512-B rows)
-__device__ __forceinline__ bf16x8 read_frag_tr512(const unsigned char* lds, int t16, int kk, int lane) {
-  const int g = lane >> 4, ii = lane & 15, q = ii >> 2, p = ii & 3;
-  const int r = kk * 32 + 8 * g + q;
-  const int a0 = r * 512 + ((t16 ^ swz_tr(r)) << 5) + p * 8;
-  const int a1 = (r + 4) * 512 + ((t16 ^ swz_tr(r + 4)) << 5) + p * 8;
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a0));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a1));
-  union { struct { s16x4 l, h; } s; bf16x8 v; } u;
-  u.s.l = lo; u.s.h = hi;
-  return u.v;
-}
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_dma256_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
-  const TileCoord tc = tile_coord(g, tiles_m, tiles_n);
-  const int m0 = tc.tm * BIG_BM, n0 = tc.tn * BN;
-  const int z1 = tc.zb / g.Z2, z2 = tc.zb - z1 * g.Z2;
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B) + z1 * g.sB1 + z2 * g.sB2;
-  const int64_t coff = z1 * g.sC1 + z2 * g.sC2 + ((g.flags & VMR_EPI_SLAB) ? (int64_t)tc.ks * g.M * g.ldc : 0);
-  int k_begin = 0, k_end = g.K;
-  if (g.splitk > 1) {
-    int chunk = (g.K + g.splitk - 1) / g.splitk;
-    chunk = (chunk + 63) / 64 * 64;
-    k_begin = tc.ks * chunk;
-    k_end = min(g.K, k_begin + chunk);
-  }
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int nk = k_end > k_begin ? (k_end - k_begin) / BIG_BK : 0;
-#pragma unroll
-  for (int s = 0; s < BIG_NST - 1; ++s) {
-    if (s < nk) {
-      dma_operand_a256<!TA>(A, g.lda, m0, k_begin + s * BIG_BK, smem + s * BIG_STAGE, wid, lane);
-      dma_operand_b128<!TB>(B, g.ldb, n0, k_begin + s * BIG_BK, smem + s * BIG_STAGE + BIG_A_BYTES, wid, lane);
-    }
-  }
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // step kt landed; kt+1's 6 loads in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + BIG_NST - 1 < nk) {
-      unsigned char* dst = smem + ((kt + BIG_NST - 1) % BIG_NST) * BIG_STAGE;
-      const int k0 = k_begin + (kt + BIG_NST - 1) * BIG_BK;
-      dma_operand_a256<!TA>(A, g.lda, m0, k0, dst, wid, lane);
-      dma_operand_b128<!TB>(B, g.ldb, n0, k0, dst + BIG_A_BYTES, wid, lane);
-    }
-    const unsigned char* cur = smem + (kt % BIG_NST) * BIG_STAGE;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        fa[i] = TA ? read_frag_tr512(cur, wm * 4 + i, kk, lane) : read_frag<true, 64>(cur, wm * 4 + i, kk, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag<!TB, 64>(cur + BIG_A_BYTES, wn * 4 + j, kk, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-  }
-  __syncthreads();
-  // epilogue: the whole 256x128 fp32 tile is staged at once (135 KiB of the 144-KiB ring)
-  float* cst = reinterpret_cast<float*>(smem);
-  bf16_t* Cp = (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM))
-                   ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
-                   : reinterpret_cast<bf16_t*>(g.C) + coff;
-  const bf16_t* Rp = reinterpret_cast<const bf16_t*>(g.residual) + coff;
-  bf16_t* Ap = reinterpret_cast<bf16_t*>(g.aux) + coff;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        cst[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * CST_LD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
-  __syncthreads();
-  epilogue_half<bf16_t, true, 512, 256>(g, cst, m0, n0, tc.zb, Cp, Rp, Ap);
-}
-
 // ----------------------------------------------------------------- f32 kernel
 constexpr int BK32 = 16;
 constexpr int OP_FLOATS32 = 2304;  // max(128*17, 16*144) floats per operand per stage
@@ -911,25 +766,7 @@ Pick pick_trans(int ta, int tb, int dtype, int bk) {
 }
 
 int g_gemm_bk = 0;   // 0 = not read yet; VMR_GEMM_BK=32|64 selects the bf16 K-step of the register-staged path
-int g_gemm_dma = -1;  // VMR_GEMM_DMA: 0 off, 1: 128x128 BK=32 x4, 2: 128x128 BK=64 x2, 3 (default): + 256x128 tile
-
-gemm_fn pick_big(int ta, int tb) {
-  if (!ta && !tb) return (gemm_fn)gemm_bf16_dma256_kernel<false, false>;
-  if (!ta && tb) return (gemm_fn)gemm_bf16_dma256_kernel<false, true>;
-  if (ta && !tb) return (gemm_fn)gemm_bf16_dma256_kernel<true, false>;
-  return (gemm_fn)gemm_bf16_dma256_kernel<true, true>;
-}
-
-int set_big_lds(const void* fn, int bytes) {
-  static thread_local const void* done[48];
-  static thread_local int ndone = 0;
-  for (int i = 0; i < ndone; ++i)
-    if (done[i] == fn) return 0;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) return vmr_fail(-5, "vmr_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-  if (ndone < 48) done[ndone++] = fn;
-  return 0;
-}
+int g_gemm_dma = -1;  // VMR_GEMM_DMA: 0 off (register-staged kernel only), 1: BK=32 x 4 stages, 2 (default): BK=64 x 2 stages
 
 template <int BK, int NST>
 gemm_fn pick_dma_t(int ta, int tb) {
@@ -1010,47 +847,6 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   const bool dma_ok = g_gemm_dma && al && g.dtype == VMR_BF16 && g.M % BM == 0 && g.N % BN == 0 && g.K % 64 == 0 &&
                       g.K >= 128 * g.splitk &&
                       (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));   // the direct epilogue loads bias as float4
-  if (dma_ok && g_gemm_dma >= 3 && g.M >= 256 && g.res_div == 1 && !g.a_colsum) {
-    // 256x128 tiles for the rows that fill whole rounds of the 256 CUs; the ragged remainder (e.g. the
-    // 1280 query-token rows of a packed [8192 | 1280] matrix) goes to the 128x128 kernel instead of
-    // costing a second, nearly empty round of big tiles.
-    const int64_t Zb = Z;
-    int big_tm = g.M / 256;
-    const int per_round = 256;
-    const int64_t total = (int64_t)big_tm * tiles_n * Zb;
-    if (total > per_round) {
-      const int64_t full = total / per_round * per_round;          // tiles in whole rounds
-      const int64_t rem_tiles = total - full;
-      if (rem_tiles * 4 < per_round * 3 && !((g.flags & VMR_EPI_DROPOUT) && Zb > 1)) {  // last round < 75 % full: trim it
-        const int keep_tm = (int)(full / ((int64_t)tiles_n * Zb));
-        if (keep_tm > 0) big_tm = keep_tm;
-      }
-    }
-    const int Mbig = big_tm * 256;
-    gemm_fn bf = pick_big(g.transA, g.transB);
-    if (int rc = set_big_lds(reinterpret_cast<const void*>(bf), BIG_SMEM)) return rc;
-    vmr_gemm_t gb = g;
-    gb.M = Mbig;
-    hipLaunchKernelGGL(bf, dim3((unsigned)(big_tm * tiles_n), 1, (unsigned)Z), dim3(512), BIG_SMEM,
-                       (hipStream_t)stream, gb, big_tm, tiles_n);
-    VMR_LAUNCH_CHECK();
-    if (Mbig == g.M) return 0;
-    // remainder rows [Mbig, M): shift the row-indexed pointers
-    const int64_t esz = 2, csz = (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM)) ? 4 : 2;
-    g.A = reinterpret_cast<const char*>(g.A) + (g.transA ? (int64_t)Mbig : (int64_t)Mbig * g.lda) * esz;
-    g.C = reinterpret_cast<char*>(g.C) + (int64_t)Mbig * g.ldc * csz;
-    if (g.residual) g.residual = reinterpret_cast<const char*>(g.residual) + (int64_t)Mbig * g.ldr * esz;
-    if (g.aux) g.aux = reinterpret_cast<char*>(g.aux) + (int64_t)Mbig * g.ldr * esz;
-    if (g.rowscale) g.rowscale += Mbig;
-    g.M -= Mbig;
-    g.drop_row0 += Mbig;
-    const int tm2 = cdiv(g.M, BM);
-    const Pick p2 = pick_dma(g.transA, g.transB, 2);
-    hipLaunchKernelGGL(p2.fn, dim3((unsigned)(tm2 * tiles_n), 1, (unsigned)Z), dim3(256), p2.smem,
-                       (hipStream_t)stream, g, tm2, tiles_n);
-    VMR_LAUNCH_CHECK();
-    return 0;
-  }
   if (dma_ok) pk = pick_dma(g.transA, g.transB, g_gemm_dma >= 2 ? 2 : 1);
   // 160-row tiles when they save a (partial) round: e.g. [9472 x 1024]: 592 tiles = 1.16 rounds of 128x128
   // -> 480 tiles = one round of 160x128
