@@ -330,6 +330,15 @@ int vmr_char_cnn_bwd(const void* dout, const void* out, int64_t ldo, const int8_
                      float* const* dw, float* const* db, float* dtable, float* workspace, int W, int C, int CD,
                      int dtype, float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream);
 
+/* ------------------------------------------------------------ input staging (next row N3)
+ * out[b, i, :] = mean(arena[row_off[b] + seg[b,i] : row_off[b] + seg[b,i+1], :]) when seg[b,i] < seg[b,i+1],
+ * else arena[row_off[b] + seg[b,i], :], for i < out_len[b]; rows i >= out_len[b] are zero; mask[b,i] = i < out_len[b].
+ * = interpolate_avrage / sample_vfeat_linear + pad_video_seq + convert_length_to_mask of the reference
+ * (utils/data_utils.py:70-84,161-201, utils/utils.py:125-130) for a whole batch in one launch, reading a
+ * device-resident feature arena (fp32 [frames, V]).  seg: int32 [B, T+1]; out: fp32 or bf16 [B, T, ldo]. */
+int vmr_resample_pad(const float* arena, const int64_t* row_off, const int* seg, const int* out_len, void* out,
+                     float* mask /*nullable*/, int B, int T, int V, int64_t ldo, int out_dtype, void* stream);
+
 /* --------------------------------------------------------------- optimizer
  * fused AdamW over a flat fp32 parameter arena (utils/utils.py:87-97:
  * AdamW, weight_decay 0.01 except names containing bias/layer_norm) with the

@@ -254,6 +254,39 @@ def metrics_case(mods):
     print("g_metrics: infer", infer[:5].tolist(), "summary", r)
 
 
+def staging_case():
+    """Next row N3: the reference's own interpolate_avrage / sample_vfeat_linear / pad_video_seq /
+    convert_length_to_mask (utils/data_utils.py, utils/utils.py) on random clips -> tests/golden/g_staging.npz."""
+    du = importlib.import_module("utils.data_utils")
+    uu = importlib.import_module("utils.utils")
+    from oracle import staging_ref as S
+    rng = np.random.default_rng(777)
+    V, T = 24, 16
+    vlens = [1, 2, 5, 15, 16, 17, 31, 32, 33, 100, 257]
+    out = {"V": V, "T": T, "vlens": np.asarray(vlens)}
+    feats = [torch.from_numpy(rng.standard_normal((n, V)).astype(np.float32)) for n in vlens]
+    for k, f in enumerate(feats):
+        out[f"feat{k}"] = f.numpy()
+        lab = torch.from_numpy(rng.random((f.shape[0], 2)).astype(np.float32))
+        out[f"label{k}"] = lab.numpy()
+        for method in ("truncation", "samelen"):
+            nv, nl = du.sample_vfeat_linear(f, lab, T, method)
+            out[f"{method}_v{k}"] = nv.numpy(); out[f"{method}_l{k}"] = nl.numpy()
+            ov, ol = S.sample_vfeat_linear(f, lab, T, method)
+            assert torch.equal(ov, nv) and torch.equal(ol, nl), ("oracle sample_vfeat_linear != reference", k, method)
+        out[f"idx{k}"] = S.segment_indices(f.shape[0], T)
+    for method in ("truncation", "samelen"):
+        sampled = [du.sample_vfeat_linear(f, f[:, :1], T, method)[0] for f in feats]
+        padded, lens = du.pad_video_seq(sampled, T)
+        vl = torch.as_tensor(lens, dtype=torch.int64)
+        mask = uu.convert_length_to_mask(vl, max_len=T)
+        out[f"{method}_batch"] = torch.stack(padded).numpy(); out[f"{method}_mask"] = mask.numpy(); out[f"{method}_lens"] = vl.numpy()
+        bv, bm, bl = S.stage_batch(feats, T, method)
+        assert torch.equal(bv, torch.stack(padded)) and torch.equal(bm, mask) and torch.equal(bl, vl)
+    np.savez_compressed(os.path.join(GOLD, "g_staging.npz"), **out)
+    print("g_staging: ok", len(out), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true")
@@ -262,6 +295,7 @@ def main():
     torch.manual_seed(0)
     mods = import_reference()
     metrics_case(mods)
+    staging_case()
     if args.only_metrics:
         return
     # g_tiny: everything stored (weights, intermediates, per-parameter grads)

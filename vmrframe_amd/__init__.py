@@ -7,6 +7,7 @@ Exports mirror what the reference's `main.py` resolves by name after
 from .SeqPAN import (BaseFast, SeqPAN, infer_BaseFast, infer_basic, infer_basic_device, infer_SeqPAN,  # noqa: F401
                      lossfun_loc, lossfun_match, train_engine_BaseFast, train_engine_SeqPAN)
 from .metrics import IoUMeter, append_ious, get_i345_mi  # noqa: F401
+from .staging import FeatureArena  # noqa: F401
 
 __all__ = ["SeqPAN", "train_engine_SeqPAN", "infer_SeqPAN", "BaseFast", "train_engine_BaseFast", "infer_BaseFast",
-           "infer_basic", "infer_basic_device", "lossfun_loc", "lossfun_match", "IoUMeter", "append_ious", "get_i345_mi"]
+           "infer_basic", "infer_basic_device", "lossfun_loc", "lossfun_match", "IoUMeter", "append_ious", "get_i345_mi", "FeatureArena"]
