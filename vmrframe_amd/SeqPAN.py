@@ -297,7 +297,12 @@ class SeqPAN(nn.Module):
                              [self.P(f"{pre}char_emb.char_convs.{i}.0.bias") for i in range(4)],
                              dc.next("text.char"), cdt)
         feats = [ops.to_dtype(wemb.reshape(B * Lq, -1), cdt), cfeat]
-        emb = torch.cat(feats, dim=1)                                                    # [B*L, 400]
+        width = sum(f.shape[1] for f in feats)                                           # 400
+        if cdt != torch.float32 and width % 128:
+            # zero columns up to a multiple of 128 (400 -> 512): query_conv1d and its dX / dW products then run on
+            # the LDS-DMA GEMM (K and N multiples of 64 / 128) instead of the bounds-checked kernel
+            feats.append(torch.zeros(B * Lq, -width % 128, device=cfeat.device, dtype=cdt))
+        emb = torch.cat(feats, dim=1)
         return self._lin(emb, pre + "query_conv1d")
 
     def _dual_block(self, X, prefix, vmask, tmask, rowmask, B, T, Lq, dc):

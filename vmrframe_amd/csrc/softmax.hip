@@ -199,8 +199,28 @@ __global__ __launch_bounds__(256) void cq_softmax_fwd_kernel(const float* __rest
   __syncthreads();
   // blockIdx.y splits the two softmaxes over two workgroups per sample (each re-reads the small tile)
   const bool do_rows = gridDim.y == 1 || blockIdx.y == 0, do_cols = gridDim.y == 1 || blockIdx.y == 1;
-  // rows: softmax over q with the query mask
-  if (do_rows)
+  // rows: softmax over q with the query mask.  Short query axis (Lq <= 32, e.g. 20 words): one THREAD per row
+  // (a wave per row would leave 2/3 of its lanes idle and walk 32 rows per wave)
+  if (do_rows && Lq <= 32) {
+    for (int c = threadIdx.x; c < Lc; c += 256) {
+      float v[32];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        v[q] = q < Lq ? tile[c * Lq + q] + (1.0f - qmask[(int64_t)b * Lq + q]) * VMR_NEG_INF_MASK : -INFINITY;
+        mx = fmaxf(mx, v[q]);
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) { v[q] = q < Lq ? __expf(v[q] - mx) : 0.f; sum += v[q]; }
+      const float inv = 1.f / sum;
+      T* o = Srow + ((int64_t)b * Lc + c) * ldP;
+#pragma unroll
+      for (int q = 0; q < 32; ++q)
+        if (q < ldP) o[q] = from_f<T>(v[q] * inv);
+      for (int q = 32; q < ldP; ++q) o[q] = from_f<T>(0.f);
+    }
+  } else if (do_rows)
   for (int c = wid; c < Lc; c += 4) {
     float mx = -INFINITY;
     for (int q = lane; q < Lq; q += 64)

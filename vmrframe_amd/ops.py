@@ -109,6 +109,21 @@ def mm(a: torch.Tensor, b: torch.Tensor, ta: int, tb: int, *, out=None, out_f32=
     return out
 
 
+def mm_few_tiles(a: torch.Tensor, b: torch.Tensor, ta: int, tb: int) -> Optional[torch.Tensor]:
+    """a . b for products with a handful of output tiles and a long K (a [64, D] pooled vector through a [D, D]
+    weight): split K over the idle CUs, fp32 partials through atomics, one cast.  None if the shape does not
+    qualify (the caller uses the plain path)."""
+    M, K = (a.shape[1], a.shape[0]) if ta else a.shape
+    N = b.shape[1] if tb else b.shape[0]
+    tiles = _cdiv(M, 128) * _cdiv(N, 128)
+    if a.dtype == torch.float32 or tiles >= 32 or K < 512:
+        return None
+    sk = max(2, min(8, K // 128))
+    acc = torch.zeros(M, N, device=a.device, dtype=torch.float32)
+    gemm(a, b, acc, M, N, K, ta, tb, a.stride(0), b.stride(0), N, dtype=L.dtype_code(a), flags=L.EPI_ACCUM, splitk=sk)
+    return acc
+
+
 def bmm4(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, ta: int, tb: int, *, flags=0, **kw):
     """Batched product over two leading dims of 4-D strided views:
     a [Z1,Z2,M,K] (or [..,K,M] if ta), b [Z1,Z2,N,K] (or [..,K,N] if tb), c [Z1,Z2,M,N]."""
@@ -301,9 +316,15 @@ class _Linear(torch.autograd.Function):
             flags |= L.EPI_AUX
         if rowscale is not None:
             flags |= L.EPI_ROWSCALE
-        gemm(x, W, ybuf, M, N, Kp, 0, 0, x.stride(0), W.stride(0), Np, dtype=dt, flags=flags, bias=bias,
-             residual=residual, aux=aux, ldr=N, rowscale=rowscale, drop=drop, bias2=bias2, bias_scale=bias_scale,
-             res_div=res_div)
+        few = None
+        if (Np == N and not relu and drop[0] == 0 and residual is None and rowscale is None and bias2 is None):
+            few = mm_few_tiles(x, W, 0, 0)         # e.g. the pooled-query projection of CQConcatenate: M = B
+        if few is not None:
+            ybuf = y = (few + bias if bias is not None else few).to(x.dtype)
+        else:
+            gemm(x, W, ybuf, M, N, Kp, 0, 0, x.stride(0), W.stride(0), Np, dtype=dt, flags=flags, bias=bias,
+                 residual=residual, aux=aux, ldr=N, rowscale=rowscale, drop=drop, bias2=bias2, bias_scale=bias_scale,
+                 res_div=res_div)
         ctx.save_for_backward(x, W, aux if aux is not None else (ybuf if relu else None), rowscale)
         ctx.meta = (relu, drop, bias is not None, residual is not None, [tuple(w.shape) for w in weights])
         ctx.weights = weights
@@ -366,7 +387,8 @@ class _Linear(torch.autograd.Function):
         dz = dzb[:, :N] if Np != N else dzb
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = mm(dz, W, 0, 1)                       # [M,N] . [N,Kp]
+            few = mm_few_tiles(dz, W, 0, 1)
+            dx = few.to(dz.dtype) if few is not None else mm(dz, W, 0, 1)                       # [M,N] . [N,Kp]
         # dW = dz^T . x  -> fp32 [N,Kp], split-K over the M (token) dimension
         sk = splitk_for(N, Kp, M)
         slots = [main_grad(w) for w in ctx.weights]
