@@ -44,6 +44,20 @@ __device__ __forceinline__ void stage_weights(const CharCnnArgs& a, T* Wt) {
 
 // character rows of the workgroup's words, dropped out, rounded through T, stored [word][channel][CP positions]
 // (positions contiguous: the convolution reads them as 16-byte vectors; positions >= C are zero)
+// backward layout of the weights: [o][j][c] (channel contiguous: lanes of a wave that differ in c read consecutive
+// elements, conflict-free)
+template <typename T>
+__device__ __forceinline__ void stage_weights_ojc(const CharCnnArgs& a, T* Wt) {
+#pragma unroll
+  for (int kk = 0; kk < CC_NK; ++kk) {
+    const int k = kk + 1, n = a.oc[kk] * a.CD * k;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {      // i = (o*CD + c)*k + j
+      const int o = i / (a.CD * k), r = i - o * (a.CD * k), c = r / k, j = r - c * k;
+      Wt[a.woff[kk] + (o * k + j) * a.CD + c] = from_f<T>(a.w[kk][i]);
+    }
+  }
+}
+
 // POS_MAJOR (backward): [word][position][channel] instead, channel contiguous (lanes differ in the channel there)
 template <typename T, int CP, bool POS_MAJOR = false>
 __device__ __forceinline__ void stage_chars(const CharCnnArgs& a, float* ce, int w0, int nw, uint32_t seed, uint32_t thresh,
@@ -148,14 +162,15 @@ __global__ __launch_bounds__(1024) void char_cnn_bwd_kernel(CharCnnArgs a, const
                                                            int64_t ldo, const int8_t* __restrict__ amax,
                                                            float* __restrict__ part, float* __restrict__ dtable) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* ce = reinterpret_cast<float*>(smem);          // (no weights in LDS here: the row-gradient loop reads the
-                                                       //  120 KB of fp32 masters through L1/L2, coalesced enough)
+  T* Wt = reinterpret_cast<T*>(smem);
+  float* ce = reinterpret_cast<float*>(smem + ((a.wtot * sizeof(T) + 15) & ~(size_t)15));
   float* G = ce + WPB * CP * a.CD;
   int* A = reinterpret_cast<int*>(G + WPB * a.OT);
   const uint32_t seed = vmr_seed(a.seed, a.step);
   const uint32_t thresh = vmr_drop_thresh(a.drop_p);
   const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const int w0 = blockIdx.x * WPB, nw = min(WPB, a.W - w0);
+  stage_weights_ojc<T>(a, Wt);
   stage_chars<T, CP, true>(a, ce, w0, nw, seed, thresh, dscale);
   for (int i = threadIdx.x; i < nw * a.OT; i += blockDim.x) {
     const int wl = i / a.OT, o = i - wl * a.OT;
@@ -187,13 +202,13 @@ __global__ __launch_bounds__(1024) void char_cnn_bwd_kernel(CharCnnArgs a, const
 #pragma unroll
         for (int kk = 0; kk < CC_NK; ++kk) {
           const int k = kk + 1, oc = a.oc[kk];
-          const float* wk = a.w[kk];
+          const T* wt = Wt + a.woff[kk];
           const float* Gk = G + wl * a.OT + a.coff[kk];
           const int* Ak = A + wl * a.OT + a.coff[kk];
           for (int o = 0; o < oc; ++o) {
             const float g = Gk[o];
             const int j = q - Ak[o];
-            if (g != 0.f && j >= 0 && j < k) d += g * round_through<T>(wk[(o * a.CD + c) * k + j]);
+            if (g != 0.f && j >= 0 && j < k) d += g * to_f<T>(wt[(o * k + j) * a.CD + c]);
           }
         }
         if (a.drop_p > 0.f && !vmr_keep(seed, (uint64_t)(word * a.C + q) * a.CD + c, thresh)) d = 0.f;
@@ -251,7 +266,7 @@ int fill_args(CharCnnArgs& a, const int64_t* ids, const float* table, const floa
 extern "C" int vmr_char_cnn_ws_floats(int W, int CD, const int* oc, int dtype) {
   int wtot = 0, ot = 0;
   for (int kk = 0; kk < CC_NK; ++kk) { wtot += oc[kk] * CD * (kk + 1); ot += oc[kk]; }
-  const int wpb = dtype == VMR_BF16 ? 8 : 4;
+  const int wpb = dtype == VMR_BF16 ? 8 : 4;   // words per workgroup of the backward kernel
   return ((W + wpb - 1) / wpb) * (wtot + ot);
 }
 
@@ -293,8 +308,7 @@ extern "C" int vmr_char_cnn_bwd(const void* dout, const void* out, int64_t ldo, 
   CharCnnArgs a;
   fill_args(a, char_ids, table, w, b, oc, W, C, CD, drop_p, drop_seed, drop_step);
   const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = dtype == VMR_BF16 ? 8 : 4, cp = C <= 8 ? 8 : 16;
-  const size_t lds = (size_t)wpb * cp * CD * 4 + (size_t)wpb * a.OT * 8;
-  (void)esz;
+  const size_t lds = ((size_t)a.wtot * esz + 15) / 16 * 16 + (size_t)wpb * cp * CD * 4 + (size_t)wpb * a.OT * 8;
   VMR_CHECK(lds <= 160 * 1024, "vmr_char_cnn_bwd: operands do not fit LDS (%zu B)", lds);
   const int nblk = (W + wpb - 1) / wpb;
 #define VMR_CC_BWD(TT, WPBV, CPV)                                                                                          \
