@@ -36,6 +36,20 @@ __device__ __forceinline__ TileCoord tile_coord(const vmr_gemm_t& g, int tiles_m
   // XCD-aware bijective remap: blocks with equal blockIdx.x % 8 share an XCD/L2;
   // give each XCD a contiguous run of logical tiles (n fastest), so the tiles that
   // re-read one A row-panel hit the same L2.
+  if (g.splitk > 1 && gridDim.z == 1) {
+    // split-K, unbatched: the K split rides in blockIdx.x (ks = bid % splitk).  Workgroups go to the 8 XCDs round-
+    // robin by linear id, so with splitk = 8 each XCD owns ONE K slab of both operands for all output tiles: a
+    // [K/8 x M] and a [K/8 x N] panel (2.4 MB each at cfg2) stay in that XCD's L2 and HBM reads each operand once.
+    // (With ks in blockIdx.z every XCD swept all K slabs of one operand: 8x the HBM / Infinity-Cache traffic.)
+    TileCoord t;
+    const int bid = blockIdx.x, sk = g.splitk;
+    t.ks = bid % sk;
+    const int tile = bid / sk;
+    t.tm = tile / tiles_n;
+    t.tn = tile - t.tm * tiles_n;
+    t.zb = 0;
+    return t;
+  }
   const int nblk = tiles_m * tiles_n;
   const int bid = blockIdx.x;
   const int q = nblk >> 3, r = nblk & 7;
@@ -889,6 +903,7 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
     }
   }
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)Z);
+  if (g.splitk > 1 && g.Z1 * g.Z2 == 1) grid = dim3((unsigned)(tiles_m * tiles_n * g.splitk), 1, 1);   // see tile_coord
   float* colsum_fallback = nullptr;
   if (g.a_colsum && !dma_ok) {   // only the LDS-DMA kernel folds the column sums into the product
     colsum_fallback = g.a_colsum;
