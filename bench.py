@@ -199,10 +199,18 @@ def main():
     # GEMM of two more (eager) steps of the same workload -- events cannot be recorded inside a graph replay
     timer = GemmTimer() if rank == 0 else None
     ops.GEMM_HOOK = timer
+    cq_rec = []
+
+    def cq_hook(launch, B_, Ll, Ls, D_):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record(); launch(); e_.record()
+        cq_rec.append((s_, e_, B_, Ll, Ls, D_))
+    ops.CQ_HOOK = cq_hook
     for _ in range(2):          # every rank takes part (the steps contain the gradient all-reduce)
         eager_step()
     torch.cuda.synchronize()
     ops.GEMM_HOOK = None
+    ops.CQ_HOOK = None
     timed_steps_for_hook = 2
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -245,6 +253,20 @@ def main():
                "step_mfma_frac": round(value * TRAIN_GFLOP_PER_CLIP * 1e9 / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
                "final_loss": round(final_loss, 4), "hipgraph": not args.no_graph,
                "roofline": roofline}
+        if cq_rec:
+            # the CQAttention score kernel (north-star "attention score/softmax/context-gather"): algorithmic
+            # bytes = read long + short operand, write both probability matrices (bf16); flops = the QK^T contraction
+            us = [s_.elapsed_time(e_) * 1e3 for (s_, e_, *_r) in cq_rec]
+            _, _, B_, Ll, Ls, D_ = cq_rec[0]
+            by = B_ * ((Ll + Ls) * D_ * 2 + 2 * Ll * ((Ls + 7) // 8 * 8) * 2)
+            fl = 2.0 * B_ * Ll * Ls * D_
+            t_ = sum(us) / len(us) * 1e-6
+            out["cq_score_kernel"] = {"kernel": "cq_score_kernel (trilinear QK^T + both masked softmaxes, one launch)",
+                                      "avg_launch_us": round(sum(us) / len(us), 2), "launches_per_step": len(us) / timed_steps_for_hook,
+                                      "bound": "hbm", "achieved": round(by / t_ / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                      "frac": round(by / t_ / 8e12, 4), "algorithmic_bytes_per_launch": by,
+                                      "mfma_frac": round(fl / t_ / (MFMA_BF16_PEAK_TFLOPS * 1e12), 5),
+                                      "note": "AI = 16 flop/B: HBM-bound by construction (<= 5 % of MFMA peak stand-alone)"}
         if args.workload != "seqpan":
             out["step_mfma_frac"] = None     # the 58 GFLOP/clip figure is SeqPAN's
         if world == 1 and not args.no_cpu_baseline and args.workload == "seqpan":

@@ -251,6 +251,21 @@ int vmr_eltwise(int op, const void* a, const void* b, const void* c, const void*
 int vmr_splitk_reduce(const float* slab, float* dst, int nsplit, int64_t n, int cols, int64_t ld_dst,
                       void* stream);
 
+/* ------------------------------------------------- CQAttention score kernel
+ * The trilinear similarity of CQAttention (models/layers.py:417-421,427-437; rank-1 terms folded onto the short
+ * stream by the caller) and BOTH masked softmaxes in one launch, one workgroup per clip:
+ *   M[v,t] = long[b,v,:] . short_op[b,t,:] + shortterm[b,t]          (long: [B,Ll<=128,D], short_op: [B,Ls<=32,D])
+ *   P_t = softmax_t(M + (1-mask_short[b,t])*-1e30),  P_v = softmax_v(M + (1-mask_long[b,v])*-1e30)
+ * orient 0 (context = long stream):  Srow = P_t, Scol = P_v as [B,Ll,ldP] (columns t, zero padded to ldP);
+ * orient 1 (context = short stream): Srow = P_v, Scol = P_t as [B,Ls,ldP] (columns v, zero padded to ldP)
+ * -- exactly the (S_row, S_col) layout of vmr_cq_softmax_fwd, whose backward consumes them.  The short operand is
+ * staged in LDS by DMA, the long operand is streamed from HBM once as MFMA fragments, the score tile stays in
+ * registers.  bf16, D %% 256 == 0 (vmr_cq_score_supported). */
+int vmr_cq_score_supported(int Ll, int Ls, int D, int dtype);
+int vmr_cq_score_fwd(const void* lng, const void* short_op, const float* shortterm, const float* mask_long,
+                     const float* mask_short, void* Srow, void* Scol, int B, int Ll, int Ls, int D, int ldP,
+                     int orient, int dtype, void* stream);
+
 /* ------------------------------------------------------------ WeightedPool
  * reference models/layers.py:440-453: alpha = softmax_l(x[b,l,:].w + (1-mask[b,l])*-1e30),
  * pooled[b,:] = sum_l alpha[b,l]*x[b,l,:].  x: [B,L,D] dtype; w, mask, alpha fp32; pooled [B,D] dtype.

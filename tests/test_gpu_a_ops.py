@@ -563,6 +563,46 @@ def _ceil8(v):
     return (v + 7) // 8 * 8
 
 
+@pytest.mark.parametrize("dims", [(64, 128, 20, 1024), (3, 70, 9, 256), (2, 128, 32, 512), (2, 1, 1, 256)])
+@pytest.mark.parametrize("orient", [0, 1])
+def test_cq_score_kernel_matches_composed_path(dev, dims, orient):
+    """csrc/cqscore.hip (score + both softmaxes, one launch) against the three-launch path (batched GEMM +
+    vmr_cq_softmax_fwd) and against torch, forward and backward, both orientations of CQAttention."""
+    ops = _ops()
+    B, Ll, Ls, D = dims
+    torch.manual_seed(47)
+    dt = torch.bfloat16
+    lng = (torch.randn(B, Ll, D, device=dev) / math.sqrt(D) * 4).to(dt).requires_grad_(True)
+    sht = torch.randn(B, Ls, D, device=dev).to(dt).requires_grad_(True)
+    term = torch.randn(B, Ls, device=dev, requires_grad=True)
+    ll = torch.randint(1, Ll + 1, (B,), device=dev); ll[0] = Ll
+    ls = torch.randint(1, Ls + 1, (B,), device=dev); ls[0] = Ls
+    ml = (torch.arange(Ll, device=dev)[None] < ll[:, None]).float()
+    ms = (torch.arange(Ls, device=dev)[None] < ls[:, None]).float()
+    assert ops.cq_score_supported(Ll, Ls, D, dt)
+    Sr, Sc = ops.cq_score(lng, sht, term, ml, ms, orient)
+    # torch reference in the (context, query) layout of the reference module
+    lr, sr, tr = lng.detach().float().requires_grad_(True), sht.detach().float().requires_grad_(True), term.detach().clone().requires_grad_(True)
+    M = lr @ sr.transpose(1, 2) + tr[:, None, :]                    # [B, v, t]
+    Pt = torch.softmax(M + (1 - ms[:, None, :]) * -1e30, dim=2)
+    Pv = torch.softmax(M + (1 - ml[:, :, None]) * -1e30, dim=1)
+    rr, rc = (Pt, Pv) if orient == 0 else (Pv.transpose(1, 2), Pt.transpose(1, 2))
+    _close(Sr, rr, 2e-2, "S_row"); _close(Sc, rc, 2e-2, "S_col")
+    g1, g2 = torch.randn_like(rr), torch.randn_like(rc)
+    ga = torch.autograd.grad([Sr, Sc], [lng, sht, term], [g1.to(dt), g2.to(dt)])
+    gb = torch.autograd.grad([rr, rc], [lr, sr, tr], [g1.to(dt).float(), g2.to(dt).float()])
+    for a, b, name in zip(ga, gb, ("dlong", "dshort", "dterm")):
+        _close(a, b, 4e-2, name)
+    # and the composed HIP path on the same inputs
+    if orient == 0:
+        S2 = ops.bmm(lng, sht, 0, 0, out_f32=True)
+        Cr, Cc = ops.cq_softmax(S2, None, term, ml, ms, dt)
+    else:
+        S2 = ops.bmm(sht, lng, 0, 0, out_f32=True)
+        Cr, Cc = ops.cq_softmax(S2, term, None, ms, ml, dt)
+    _close(Sr, Cr, 1e-2, "fused vs composed S_row"); _close(Sc, Cc, 1e-2, "fused vs composed S_col")
+
+
 def test_soft_ce_matches_torch(dev):
     ops = _ops()
     torch.manual_seed(6)

@@ -352,13 +352,22 @@ class SeqPAN(nn.Module):
         if Lq <= Lc:      # (rank-1 terms: one scale-shift kernel + one matrix-vector kernel on the short stream)
             bop = ops.scale_shift(qd, w4mlu, w4C)
             colterm = ops.narrow_linear(qd.reshape(B * Lq, D), w4Q, None, N=1).view(B, Lq)
-            S2, rowterm = ops.bmm(cd, bop, 0, 0, out_f32=True), None
+            fused = ops.cq_score_supported(Lc, Lq, D, cdt)
+            if fused:     # score + both softmaxes in one kernel: short operand in LDS, video rows streamed once
+                S_p, S_tp = ops.cq_score(cd, bop, colterm, cmask, qmask, 0)
+            else:
+                S2, rowterm = ops.bmm(cd, bop, 0, 0, out_f32=True), None
         else:
             aop = ops.scale_shift(cd, w4mlu, w4Q)
             rowterm = ops.narrow_linear(cd.reshape(B * Lc, D), w4C, None, N=1).view(B, Lc)
-            S2, colterm = ops.bmm(aop, qd, 0, 0, out_f32=True), None
-        # both masked softmaxes in one HIP kernel; outputs are 8-padded so the GEMMs below use 16-byte loads
-        S_p, S_tp = ops.cq_softmax(S2, rowterm, colterm, cmask, qmask, cdt)
+            fused = ops.cq_score_supported(Lq, Lc, D, cdt)
+            if fused:
+                S_p, S_tp = ops.cq_score(qd, aop, rowterm, qmask, cmask, 1)
+            else:
+                S2, colterm = ops.bmm(aop, qd, 0, 0, out_f32=True), None
+        if not fused:
+            # both masked softmaxes in one HIP kernel; outputs are 8-padded so the GEMMs below use 16-byte loads
+            S_p, S_tp = ops.cq_softmax(S2, rowterm, colterm, cmask, qmask, cdt)
         c2q = ops.bmm(S_p, qry, 0, 1)                      # [B,Lc,D]
         mid = ops.bmm(S_tp, ctx, 1, 1)                     # S_t^T . C   [B,Lq,D]
         q2c = ops.bmm(S_p, mid, 0, 1)                      # [B,Lc,D]

@@ -76,6 +76,8 @@ SIGNATURES = {
     "vmr_char_cnn_fwd": [_P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U, _P, _P],
     "vmr_char_cnn_bwd": [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U, _P, _P],
     "vmr_resample_pad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
+    "vmr_cq_score_supported": [_I, _I, _I, _I],
+    "vmr_cq_score_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vmr_cq_softmax_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_cq_softmax_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_soft_ce_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],

@@ -1,0 +1,225 @@
+// cqscore.hip -- the CQAttention score kernel (reference models/layers.py:417-421,427-437): the trilinear
+// similarity S (its rank-1 terms folded onto the short stream by the caller) and BOTH masked softmaxes in one launch:
+//     M[v, t] = long[b, v, :] . short_op[b, t, :] + shortterm[b, t]
+//     P_t = softmax over t of M + (1 - mask_short[t]) * -1e30        P_v = softmax over v of M + (1 - mask_long[v]) * -1e30
+// One workgroup (8 waves) per clip.  The SHORT operand ([L <= 32 words, D], e.g. Q*w4mlu + w4C) is staged once in LDS
+// by global->LDS DMA (k-contiguous image, XOR-swizzled); every wave streams its 16 rows of the LONG operand (the
+// [T <= 128 frames, D] video tensor) straight from HBM as MFMA fragments -- whole 16-byte chunks per lane, each row read
+// exactly once -- and keeps its [16 x 32] score tile in registers.  Scores are computed transposed so a lane owns 4
+// consecutive t of one v: the softmax over t is in-lane + 2 cross-lane steps; the softmax over v reduces across lanes
+// and, through 1 KiB of LDS, across the 8 waves.  The [T, L] score matrix never goes to HBM in fp32.
+// Replaces {zero-fill, batched split-K GEMM, cq_softmax} of the composed path.  bf16 only.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+struct CqArgs {
+  const bf16_t* lng; const bf16_t* sht; const float* shortterm; const float* mask_long; const float* mask_short;
+  bf16_t* Srow; bf16_t* Scol;
+  int Ll, Ls, D, ldP, orient;
+};
+
+__global__ __launch_bounds__(512) void cq_score_kernel(CqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D = a.D, RB = D * 2, CPRW = RB / 16;           // bytes / 16-B chunks per short-operand row
+  unsigned char* Ss = smem;                                // [32][RB]
+  float* red = reinterpret_cast<float*>(smem + 32 * RB);   // [8 waves][32] column partials
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const bf16_t* Lg = a.lng + (int64_t)b * a.Ll * D;
+  const bf16_t* Sg = a.sht + (int64_t)b * a.Ls * D;
+  // ---- short operand -> LDS (DMA, 1 KiB per wave-instruction; rows >= Ls re-read row Ls-1: masked out below)
+  const int nblk = 32 * RB / 1024;
+  for (int j = wid; j < nblk; j += 8) {
+    const int flat = j * 64 + lane, row = flat / CPRW, sl = flat - row * CPRW;
+    const int c = (sl & ~15) | ((sl & 15) ^ (row & 15));
+    const bf16_t* src = Sg + (int64_t)min(row, a.Ls - 1) * D + c * 8;
+    __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)(Ss + j * 1024), 16, 0, 0);
+  }
+  // ---- this wave's 16 long rows: fragments straight from HBM, 8 k-steps in flight
+  const int v0 = wid * 16;
+  const bool act = v0 < a.Ll;
+  const int vi = min(v0 + (lane & 15), a.Ll - 1);
+  const bf16_t* lrow = Lg + (int64_t)vi * D + (lane >> 4) * 8;
+  f32x4 st[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  const int nks = D / 32;
+  // 16 fragments (16 x 1 KiB per wave) in flight: each is re-requested right after it is consumed
+  bf16x8 fr[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+    if (u < nks) fr[u] = *reinterpret_cast<const bf16x8*>(lrow + u * 32);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the DMA blocks and the first fragments have landed
+  __builtin_amdgcn_s_barrier();
+  for (int k0 = 0; k0 < nks; k0 += 16) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int ks = k0 + u;
+      if (ks < nks) {
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = j * 16 + (lane & 15);
+            const int c = ks * 4 + (lane >> 4);
+            const bf16x8 sf = *reinterpret_cast<const bf16x8*>(Ss + row * RB + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
+            st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, fr[u], st[j], 0, 0, 0);   // C[t][v]
+          }
+        }
+        if (ks + 16 < nks) fr[u] = *reinterpret_cast<const bf16x8*>(lrow + (ks + 16) * 32);
+      }
+    }
+  }
+  // lane owns v = v0 + (lane&15) and t = j*16 + (lane>>4)*4 + r
+  const int v = v0 + (lane & 15);
+  const bool vok = act && v < a.Ll;
+  const float ml = vok ? a.mask_long[(int64_t)b * a.Ll + v] : 0.f;
+  float xt[2][4], xv[2][4];
+  float mxt = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = j * 16 + (lane >> 4) * 4 + r;
+      float m = -INFINITY, mv = -INFINITY;
+      if (t < a.Ls && vok) {
+        const float s = st[j][r] + a.shortterm[(int64_t)b * a.Ls + t];
+        m = s + (1.0f - a.mask_short[(int64_t)b * a.Ls + t]) * VMR_NEG_INF_MASK;   // softmax over t
+        mv = s + (1.0f - ml) * VMR_NEG_INF_MASK;                                    // softmax over v
+      }
+      xt[j][r] = m; xv[j][r] = mv;
+      mxt = fmaxf(mxt, m);
+    }
+  // ---- softmax over t (per v): in-lane + lanes 16 / 32 apart
+  mxt = fmaxf(mxt, __shfl_xor(mxt, 16, 64));
+  mxt = fmaxf(mxt, __shfl_xor(mxt, 32, 64));
+  float sumt = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { xt[j][r] = vok ? __expf(xt[j][r] - mxt) : 0.f; sumt += xt[j][r]; }
+  sumt += __shfl_xor(sumt, 16, 64);
+  sumt += __shfl_xor(sumt, 32, 64);
+  const float invt = vok ? 1.f / sumt : 0.f;
+  // ---- softmax over v (per t): lanes 1,2,4,8 apart inside the wave, then across the 8 waves through LDS
+  float cm[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float m = xv[j][r];
+      m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64));
+      m = fmaxf(m, __shfl_xor(m, 4, 64)); m = fmaxf(m, __shfl_xor(m, 8, 64));
+      cm[j][r] = m;
+      if ((lane & 15) == 0) red[wid * 32 + j * 16 + (lane >> 4) * 4 + r] = m;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = j * 16 + (lane >> 4) * 4 + r;
+      float m = red[t];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w * 32 + t]);
+      cm[j][r] = m;
+    }
+  __syncthreads();
+  float cs[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = (vok && cm[j][r] > -INFINITY) ? __expf(xv[j][r] - cm[j][r]) : 0.f;
+      xv[j][r] = e;
+      float s = e;
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+      if ((lane & 15) == 0) red[wid * 32 + j * 16 + (lane >> 4) * 4 + r] = s;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = j * 16 + (lane >> 4) * 4 + r;
+      float s = red[t];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) s += red[w * 32 + t];
+      cs[j][r] = s > 0.f ? 1.f / s : 0.f;
+    }
+  if (!vok) return;
+  // ---- outputs.  orient 0 (context = long): Srow = P_t, Scol = P_v, both [b, v, ldP] (8-byte stores);
+  //                orient 1 (context = short): Srow = P_v, Scol = P_t, both [b, t, ldP] (column v)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float pt[4], pv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pt[r] = xt[j][r] * invt; pv[r] = xv[j][r] * cs[j][r]; }
+    const int t0 = j * 16 + (lane >> 4) * 4;
+    if (a.orient == 0) {
+      if (t0 < a.ldP) {
+        Vec4<bf16_t>::store(a.Srow + ((int64_t)b * a.Ll + v) * a.ldP + t0, pt);
+        Vec4<bf16_t>::store(a.Scol + ((int64_t)b * a.Ll + v) * a.ldP + t0, pv);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (t0 + r < a.Ls) {
+          a.Srow[((int64_t)b * a.Ls + t0 + r) * a.ldP + v] = (bf16_t)pv[r];
+          a.Scol[((int64_t)b * a.Ls + t0 + r) * a.ldP + v] = (bf16_t)pt[r];
+        }
+    }
+  }
+}
+
+// orient 1 pads: columns Ll..ldP of every [t] row must be zero (the following GEMMs read ldP columns)
+__global__ __launch_bounds__(256) void cq_pad_zero_kernel(bf16_t* __restrict__ A, bf16_t* __restrict__ Bm, int64_t rows, int L,
+                                                          int ldP) {
+  const int pad = ldP - L;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * pad; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / pad;
+    const int c = L + (int)(i - r * pad);
+    A[r * ldP + c] = (bf16_t)0.f;
+    Bm[r * ldP + c] = (bf16_t)0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int vmr_cq_score_supported(int Ll, int Ls, int D, int dtype) {
+  return dtype == VMR_BF16 && Ll >= 1 && Ll <= 128 && Ls >= 1 && Ls <= 32 && D % 256 == 0 && D >= 256 && D <= 2048;
+}
+
+extern "C" int vmr_cq_score_fwd(const void* lng, const void* sht, const float* shortterm, const float* mask_long,
+                                const float* mask_short, void* Srow, void* Scol, int B, int Ll, int Ls, int D, int ldP,
+                                int orient, int dtype, void* stream) {
+  VMR_CHECK(lng && sht && shortterm && mask_long && mask_short && Srow && Scol, "vmr_cq_score_fwd: null pointer");
+  VMR_CHECK(vmr_cq_score_supported(Ll, Ls, D, dtype), "vmr_cq_score_fwd: unsupported shape Ll=%d Ls=%d D=%d", Ll, Ls, D);
+  VMR_CHECK(orient == 0 || orient == 1, "vmr_cq_score_fwd: bad orientation");
+  VMR_CHECK(ldP % 4 == 0 && ldP >= (orient == 0 ? Ls : Ll), "vmr_cq_score_fwd: bad ldP");
+  if (B == 0) return 0;
+  CqArgs a;
+  a.lng = (const bf16_t*)lng; a.sht = (const bf16_t*)sht; a.shortterm = shortterm; a.mask_long = mask_long;
+  a.mask_short = mask_short; a.Srow = (bf16_t*)Srow; a.Scol = (bf16_t*)Scol;
+  a.Ll = Ll; a.Ls = Ls; a.D = D; a.ldP = ldP; a.orient = orient;
+  const int smem = 32 * D * 2 + 8 * 32 * 4;
+  if (smem > 64 * 1024) {
+    static thread_local bool done = false;
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute((const void*)cq_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return vmr_fail(-5, "vmr_cq_score_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(cq_score_kernel, dim3(B), dim3(512), smem, (hipStream_t)stream, a);
+  VMR_LAUNCH_CHECK();
+  if (orient == 1 && ldP > Ll) {
+    const int64_t rows = (int64_t)B * Ls;
+    hipLaunchKernelGGL(cq_pad_zero_kernel, dim3((unsigned)min((int64_t)1024, (rows * (ldP - Ll) + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (bf16_t*)Srow, (bf16_t*)Scol, rows, Ll, ldP);
+    VMR_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -21,6 +21,7 @@ from . import _lib as L
 
 NO_DROP = (0.0, 0, None)
 GEMM_HOOK = None   # bench.py: callable(launch, M, N, K, ta, tb, Z, dtype) timing the launch with HIP events
+CQ_HOOK = None     # bench.py: callable(launch, B, Ll, Ls, D) around the CQAttention score kernel
 # Optional side stream for the weight-gradient GEMMs (dW = dY^T.X).  They are off the backward's
 # critical path (only the optimizer needs them), so the trainer lets them run beside the dX chain:
 # the hardware fills the single-round tails / epilogue bursts of one kernel with workgroups of the
@@ -143,6 +144,7 @@ SPLITK_TARGET = int(os.environ.get("VMR_SPLITK_TARGET", "512"))   # workgroups t
 USE_SLABS = os.environ.get("VMR_SPLITK_SLABS", "1") != "0"
 FUSED_ATTENTION = os.environ.get("VMR_FUSED_ATTN", "1") != "0"   # csrc/attention.hip forward (bf16, hd 128/256)
 FUSED_ATTENTION_BWD = os.environ.get("VMR_FUSED_ATTN_BWD", "1") != "0"   # csrc/attention_bwd.hip
+FUSED_CQ_SCORE = os.environ.get("VMR_FUSED_CQ", "1") != "0"   # csrc/cqscore.hip
 
 
 def splitk_for(M: int, N: int, K: int) -> int:
@@ -1186,6 +1188,73 @@ class _CQSoftmax(torch.autograd.Function):
                                            L.dtype_code(Srow), L.stream_ptr()), "vmr_cq_softmax_bwd")
         return (dS2[..., :Lq], None if drow is None else drow.reshape(rshape),
                 None if dcol is None else dcol.reshape(cshape), None, None, None)
+
+
+class _CQScore(torch.autograd.Function):
+    """CQAttention similarity + both masked softmaxes in ONE kernel (csrc/cqscore.hip): the short-stream operand
+    staged in LDS, the long stream read from HBM once, the score tile in registers.  Backward: the existing
+    vmr_cq_softmax_bwd on the saved probabilities, then the two small batched products."""
+
+    @staticmethod
+    def forward(ctx, lng, short_op, shortterm, mask_long, mask_short, orient):
+        L.require_gpu(lng, short_op)
+        B, Ll, D = lng.shape
+        Ls = short_op.shape[1]
+        lng, short_op = lng.contiguous(), short_op.contiguous()
+        rows, cols = (Ll, Ls) if orient == 0 else (Ls, Ll)
+        ldP = _rup(cols, 8)
+        Srow = torch.empty(B, rows, ldP, device=lng.device, dtype=lng.dtype)
+        Scol = torch.empty_like(Srow)
+        st = shortterm.contiguous().float()
+        def launch():
+            L.check(L.lib().vmr_cq_score_fwd(lng.data_ptr(), short_op.data_ptr(), st.data_ptr(), mask_long.data_ptr(),
+                                             mask_short.data_ptr(), Srow.data_ptr(), Scol.data_ptr(), B, Ll, Ls, D, ldP,
+                                             orient, L.dtype_code(lng), L.stream_ptr()), "vmr_cq_score_fwd")
+        if CQ_HOOK is not None:
+            CQ_HOOK(launch, B, Ll, Ls, D)
+        else:
+            launch()
+        ctx.save_for_backward(lng, short_op, Srow, Scol)
+        ctx.meta = (B, Ll, Ls, D, ldP, orient, tuple(shortterm.shape))
+        return Srow[..., :cols], Scol[..., :cols]
+
+    @staticmethod
+    def backward(ctx, dSrow, dScol):
+        lng, short_op, Srow, Scol = ctx.saved_tensors
+        B, Ll, Ls, D, ldP, orient, tshape = ctx.meta
+        rows, cols = (Ll, Ls) if orient == 0 else (Ls, Ll)
+        dev = Srow.device
+
+        def pad(g):
+            buf = torch.zeros(B, rows, ldP, device=dev, dtype=Srow.dtype)
+            buf[..., :cols] = g
+            return buf
+        dSr, dSc = pad(dSrow), pad(dScol)
+        dS2 = torch.zeros(B, rows, ldP, device=dev, dtype=torch.float32)
+        dterm = torch.empty(B, Ls, device=dev, dtype=torch.float32)
+        # S2[c,q] in the stored layout: orient 0 -> c = long row, q = short row (colterm); orient 1 -> c = short row (rowterm)
+        L.check(L.lib().vmr_cq_softmax_bwd(dSr.data_ptr(), dSc.data_ptr(), Srow.data_ptr(), Scol.data_ptr(), dS2.data_ptr(),
+                                           dterm.data_ptr() if orient == 1 else None,
+                                           dterm.data_ptr() if orient == 0 else None, B, rows, cols, ldP, ldP,
+                                           L.dtype_code(Srow), L.stream_ptr()), "vmr_cq_softmax_bwd")
+        dS = dS2.to(Srow.dtype)[..., :cols]                      # [B, rows, cols], row stride ldP
+        if orient == 0:                                          # S2 = long . short_op^T
+            dlong = _bmm_raw(dS, short_op, 0, 1)                 # [B,Ll,Ls] . [B,Ls,D]
+            dshort = _bmm_raw(dS, lng, 1, 1)                     # [B,Ll,Ls]^T . [B,Ll,D]
+        else:                                                    # S2 = short_op . long^T
+            dshort = _bmm_raw(dS, lng, 0, 1)                     # [B,Ls,Ll] . [B,Ll,D]
+            dlong = _bmm_raw(dS, short_op, 1, 1)                 # [B,Ls,Ll]^T . [B,Ls,D]
+        return dlong, dshort, dterm.reshape(tshape), None, None, None
+
+
+def cq_score_supported(Ll, Ls, D, dtype):
+    return FUSED_CQ_SCORE and bool(L.lib().vmr_cq_score_supported(Ll, Ls, D, L.F32 if dtype == torch.float32 else L.BF16))
+
+
+def cq_score(lng, short_op, shortterm, mask_long, mask_short, orient):
+    """(S_row, S_col) of CQAttention from the long stream [B,Ll,D], the folded short operand [B,Ls,D] and its rank-1
+    term [B,Ls]; orient 0: context = long stream, 1: context = short stream."""
+    return _CQScore.apply(lng, short_op, shortterm, mask_long.contiguous(), mask_short.contiguous(), orient)
 
 
 def cq_softmax(S2, rowterm, colterm, cmask, qmask, dtype):
