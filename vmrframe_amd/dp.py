@@ -57,6 +57,10 @@ class GradReducer:
         # not run on replay, and a collective must never be issued while a graph is being captured).
         self.model, self.opt, self.bucket_bytes, self.use_hooks = model, optimizer, bucket_bytes, use_hooks
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # RCCL averages in the collective itself (ncclAvg): no extra 262 MB divide pass over the arena; gloo (CPU
+        # tests) only sums
+        self.avg = dist.is_initialized() and dist.get_backend() == "nccl"
+        self.op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         self.buckets: List[dict] = []
         self.param_bucket = {}
         self.handles = []
@@ -94,7 +98,7 @@ class GradReducer:
 
     def _launch(self, bucket):
         if self.world > 1:
-            self.handles.append(dist.all_reduce(bucket["view"], op=dist.ReduceOp.SUM, async_op=True))
+            self.handles.append(dist.all_reduce(bucket["view"], op=self.op, async_op=True))
         bucket["launched"] = True
 
     def finish(self):
@@ -104,23 +108,26 @@ class GradReducer:
         if self.opt.grad_arena is None:            # first step: arena not built yet
             for p in self.model.parameters():
                 if p.grad is not None:
-                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
-                    p.grad.div_(self.world)
+                    dist.all_reduce(p.grad, op=self.op)
+                    if not self.avg:
+                        p.grad.div_(self.world)
             return
         if not self.use_hooks:
             flat = self.opt.grad_arena
             per = max(1, self.bucket_bytes // 4)
-            hs = [dist.all_reduce(flat[o:o + per], op=dist.ReduceOp.SUM, async_op=True)
+            hs = [dist.all_reduce(flat[o:o + per], op=self.op, async_op=True)
                   for o in range(0, flat.numel(), per)]
             for h in hs:
                 h.wait()
-            flat.div_(self.world)
+            if not self.avg:
+                flat.div_(self.world)
             return
         if not self.buckets:
             # arena was just built by the previous optimizer step but hooks were not armed for
             # this backward: reduce the whole arena in one go, then arm the hooks.
-            dist.all_reduce(self.opt.grad_arena, op=dist.ReduceOp.SUM)
-            self.opt.grad_arena.div_(self.world)
+            dist.all_reduce(self.opt.grad_arena, op=self.op)
+            if not self.avg:
+                self.opt.grad_arena.div_(self.world)
             self._setup_buckets()
             return
         for b in self.buckets:                     # parameters that got no gradient this step
@@ -129,7 +136,8 @@ class GradReducer:
         for h in self.handles:
             h.wait()
         self.handles.clear()
-        self.opt.grad_arena.div_(self.world)
+        if not self.avg:
+            self.opt.grad_arena.div_(self.world)
         for b in self.buckets:
             b["pending"] = b["count"]
             b["launched"] = False
