@@ -134,6 +134,16 @@ int vmr_ln_dwconv_fwd(const void* x, const float* gamma, const float* beta, floa
 int vmr_dwconv_bwd(const void* du, const void* x, const float* gamma, const float* beta,
                    const float* mean, const float* rstd, const float* w, void* dn, float* dw,
                    float* workspace, int B, int S, int D, int dtype, void* stream);
+/* Two sequence groups in ONE launch: x holds [B1,S1,D] (the video clips) followed
+ * by [B2,S2,D] (the query sentences) — the shared encoder (SeqPAN.py:77-80) runs
+ * both through the same conv block.  A group with B == 0 is skipped.  Workspace
+ * of the backward: fp32 [B1*VMR_DWCONV_BWD_BPS(S1) + B2*VMR_DWCONV_BWD_BPS(S2), D*7]. */
+int vmr_ln_dwconv_fwd2(const void* x, const float* gamma, const float* beta, float eps,
+                       const float* w, void* u, float* mean, float* rstd,
+                       int B1, int S1, int B2, int S2, int D, int dtype, void* stream);
+int vmr_dwconv_bwd2(const void* du, const void* x, const float* gamma, const float* beta,
+                    const float* mean, const float* rstd, const float* w, void* dn, float* dw,
+                    float* workspace, int B1, int S1, int B2, int S2, int D, int dtype, void* stream);
 
 /* ----------------------------------------------------------- masked softmax
  * P[z,r,:] = softmax_c( scale*S[z,r,c] + term ) with dropout on P.

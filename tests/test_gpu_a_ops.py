@@ -161,7 +161,7 @@ def test_layernorm_fwd_bwd(dev, dt, tol):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2)])
-@pytest.mark.parametrize("segs", [[(3, 16), (3, 6)], [(2, 128), (2, 20)], [(1, 1), (2, 3)], [(2, 70)]])
+@pytest.mark.parametrize("segs", [[(3, 16), (3, 6)], [(2, 128), (2, 20)], [(1, 1), (2, 3)], [(2, 70)], [(2, 40), (3, 9), (1, 130)]])
 def test_ln_dwconv_fwd_bwd(dev, dt, tol, segs):
     ops = _ops()
     torch.manual_seed(2)

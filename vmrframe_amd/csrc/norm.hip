@@ -295,12 +295,19 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict_
                                                             const float* __restrict__ beta, float eps,
                                                             const float* __restrict__ w, T* __restrict__ u,
                                                             float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                            int S, int D, int R, int tiles) {
+                                                            int S, int D, int R, int tiles, int nb1, int S2,
+                                                            int R2, int tiles2, int64_t rows1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* tile = reinterpret_cast<T*>(smem);  // [R+6][D]
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar branches
-  const int b = blockIdx.x / tiles, s0 = (blockIdx.x % tiles) * R;
+  // second sequence group (the query sentences behind the video clips): workgroups >= nb1
+  int bid = blockIdx.x;
+  if (bid >= nb1) {
+    bid -= nb1; S = S2; R = R2; tiles = tiles2;
+    x += rows1 * D; u += rows1 * D; mean_o += rows1; rstd_o += rows1;
+  }
+  const int b = bid / tiles, s0 = (bid % tiles) * R;
   const int nrows = R + 6;
   constexpr int RW = 4;   // rows a wave keeps in flight: their (unconditional, index-clamped) loads issue together
   for (int rb = wid; rb < nrows; rb += 4 * RW) {
@@ -380,12 +387,20 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
                                                          const float* __restrict__ rstd_i,
                                                          const float* __restrict__ w, T* __restrict__ dn,
                                                          float* __restrict__ part, int S, int D, int slices,
-                                                         int bps /*workgroups per (sample, slice)*/) {
+                                                         int bps /*workgroups per (sample, slice)*/, int nb1,
+                                                         int S2, int bps2, int64_t rows1, int prow1) {
   constexpr int CHN = DWB_CH;
   __shared__ float red[4][DWB_SLICE * 7];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar branches
-  const int j4 = blockIdx.x % bps, bs = blockIdx.x / bps;
+  // second sequence group: workgroups >= nb1; its partial rows follow the first group's
+  int bid = blockIdx.x;
+  if (bid >= nb1) {
+    bid -= nb1; S = S2; bps = bps2;
+    du += rows1 * D; x += rows1 * D; dn += rows1 * D; mean_i += rows1; rstd_i += rows1;
+    part += (int64_t)prow1 * D * 7;
+  }
+  const int j4 = bid % bps, bs = bid / bps;
   const int b = bs / slices, c0 = (bs % slices) * DWB_SLICE + lane * CHN;
   const bool act = c0 < D;
   constexpr int seg = 16;   // rows per wave
@@ -547,20 +562,32 @@ extern "C" int vmr_layernorm_bwd(const void* dy, const void* x, const float* gam
   return 0;
 }
 
-extern "C" int vmr_ln_dwconv_fwd(const void* x, const float* gamma, const float* beta, float eps, const float* w,
-                                 void* u, float* mean, float* rstd, int B, int S, int D, int dtype, void* stream) {
+// tile height for one sequence group: 16-row LDS tiles (10 output rows + halo): 32 KiB at D=1024 bf16
+// -> 4 workgroups / CU, 13 tiles per 128-frame clip; the extra halo re-reads are L2 hits, the
+// parallelism hides the row latency
+static void dwconv_tiling(int S, int D, size_t esz, int& R, int& tiles) {
+  const int nrows = (int)min((size_t)16, (size_t)(128 * 1024) / ((size_t)D * esz));
+  if (S <= 0 || nrows < 7) { R = 0; tiles = 0; return; }
+  R = min(nrows - 6, S);
+  tiles = cdiv(S, R);
+  R = cdiv(S, tiles);  // balance the tiles
+}
+
+extern "C" int vmr_ln_dwconv_fwd2(const void* x, const float* gamma, const float* beta, float eps, const float* w,
+                                  void* u, float* mean, float* rstd, int B1, int S1, int B2, int S2, int D,
+                                  int dtype, void* stream) {
   if (int rc = ln_check(D)) return rc;
   VMR_CHECK(x && gamma && beta && w && u && mean && rstd, "vmr_ln_dwconv_fwd: null pointer");
-  if (B == 0 || S == 0) return 0;
+  VMR_CHECK(B1 >= 0 && S1 >= 0 && B2 >= 0 && S2 >= 0, "vmr_ln_dwconv_fwd: negative shape");
+  if (B1 == 0 || S1 == 0) { B1 = 0; S1 = S1 > 0 ? S1 : 1; }
+  if (B2 == 0 || S2 == 0) { B2 = 0; S2 = S2 > 0 ? S2 : 1; }
+  if (B1 + B2 == 0) return 0;
   const size_t esz = dtype == VMR_BF16 ? 2 : 4;
-  // 16-row LDS tiles (10 output rows + halo): 32 KiB at D=1024 bf16 -> 4 workgroups / CU, 13 tiles
-  // per 128-frame clip; the extra halo re-reads are L2 hits, the parallelism hides the row latency
-  int nrows = (int)min((size_t)16, (size_t)(128 * 1024) / ((size_t)D * esz));
-  VMR_CHECK(nrows >= 7, "vmr_ln_dwconv_fwd: D too large for the LDS tile");
-  int R = min(nrows - 6, S);
-  const int tiles = cdiv(S, R);
-  R = cdiv(S, tiles);  // balance the tiles
-  const size_t lds = (size_t)(R + 6) * D * esz;
+  int R1, tiles1, R2, tiles2;
+  dwconv_tiling(S1, D, esz, R1, tiles1);
+  dwconv_tiling(S2, D, esz, R2, tiles2);
+  VMR_CHECK(R1 > 0 && R2 > 0, "vmr_ln_dwconv_fwd: D too large for the LDS tile");
+  const size_t lds = (size_t)(max(R1, R2) + 6) * D * esz;
   const void* fn = nullptr;
   if (dtype == VMR_BF16) LN_DISPATCH(D, fn = (const void*)ln_dwconv_fwd_kernel<bf16_t, MC>);
   else LN_DISPATCH(D, fn = (const void*)ln_dwconv_fwd_kernel<float, MC>);
@@ -568,14 +595,50 @@ extern "C" int vmr_ln_dwconv_fwd(const void* x, const float* gamma, const float*
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vmr_fail(-5, "vmr_ln_dwconv_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
+  const int nb1 = B1 * tiles1, nb = nb1 + B2 * tiles2;
+  const int64_t rows1 = (int64_t)B1 * S1;
   if (dtype == VMR_BF16)
-    LN_DISPATCH(D, hipLaunchKernelGGL((ln_dwconv_fwd_kernel<bf16_t, MC>), dim3(B * tiles), dim3(256), lds,
+    LN_DISPATCH(D, hipLaunchKernelGGL((ln_dwconv_fwd_kernel<bf16_t, MC>), dim3(nb), dim3(256), lds,
                                       (hipStream_t)stream, (const bf16_t*)x, gamma, beta, eps, w, (bf16_t*)u, mean,
-                                      rstd, S, D, R, tiles));
+                                      rstd, S1, D, R1, tiles1, nb1, S2, R2, tiles2, rows1));
   else
-    LN_DISPATCH(D, hipLaunchKernelGGL((ln_dwconv_fwd_kernel<float, MC>), dim3(B * tiles), dim3(256), lds,
+    LN_DISPATCH(D, hipLaunchKernelGGL((ln_dwconv_fwd_kernel<float, MC>), dim3(nb), dim3(256), lds,
                                       (hipStream_t)stream, (const float*)x, gamma, beta, eps, w, (float*)u, mean, rstd,
-                                      S, D, R, tiles));
+                                      S1, D, R1, tiles1, nb1, S2, R2, tiles2, rows1));
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_ln_dwconv_fwd(const void* x, const float* gamma, const float* beta, float eps, const float* w,
+                                 void* u, float* mean, float* rstd, int B, int S, int D, int dtype, void* stream) {
+  return vmr_ln_dwconv_fwd2(x, gamma, beta, eps, w, u, mean, rstd, B, S, 0, 0, D, dtype, stream);
+}
+
+extern "C" int vmr_dwconv_bwd2(const void* du, const void* x, const float* gamma, const float* beta,
+                               const float* mean, const float* rstd, const float* w, void* dn, float* dw,
+                               float* workspace, int B1, int S1, int B2, int S2, int D, int dtype, void* stream) {
+  VMR_CHECK(du && x && gamma && beta && mean && rstd && w && dn && dw && workspace, "vmr_dwconv_bwd: null pointer");
+  VMR_CHECK(D % 2 == 0, "vmr_dwconv_bwd: D %% 2 != 0");
+  VMR_CHECK(B1 >= 0 && S1 >= 0 && B2 >= 0 && S2 >= 0, "vmr_dwconv_bwd: negative shape");
+  if (B1 == 0 || S1 == 0) { B1 = 0; S1 = S1 > 0 ? S1 : 1; }
+  if (B2 == 0 || S2 == 0) { B2 = 0; S2 = S2 > 0 ? S2 : 1; }
+  if (B1 + B2 == 0) return 0;
+  const int slices = cdiv(D, DWB_SLICE);
+  const int bps1 = VMR_DWCONV_BWD_BPS(S1), bps2 = VMR_DWCONV_BWD_BPS(S2);
+  const int nb1 = B1 * slices * bps1, nb = nb1 + B2 * slices * bps2;
+  const int prow1 = B1 * bps1, prows = prow1 + B2 * bps2;
+  const int64_t rows1 = (int64_t)B1 * S1;
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(dwconv_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)du, (const bf16_t*)x, gamma, beta, mean, rstd, w, (bf16_t*)dn, workspace, S1, D,
+                       slices, bps1, nb1, S2, bps2, rows1, prow1);
+  else
+    hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)du, (const float*)x, gamma, beta, mean, rstd, w, (float*)dn, workspace, S1, D,
+                       slices, bps1, nb1, S2, bps2, rows1, prow1);
+  VMR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colreduce_kernel, dim3(cdiv(D * 7, 256), cdiv(prows, 16)), dim3(256), 0, (hipStream_t)stream,
+                     workspace, dw, dw, prows, D * 7, 0, 0);
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -583,22 +646,5 @@ extern "C" int vmr_ln_dwconv_fwd(const void* x, const float* gamma, const float*
 extern "C" int vmr_dwconv_bwd(const void* du, const void* x, const float* gamma, const float* beta,
                               const float* mean, const float* rstd, const float* w, void* dn, float* dw,
                               float* workspace, int B, int S, int D, int dtype, void* stream) {
-  VMR_CHECK(du && x && gamma && beta && mean && rstd && w && dn && dw && workspace, "vmr_dwconv_bwd: null pointer");
-  VMR_CHECK(D % 2 == 0, "vmr_dwconv_bwd: D %% 2 != 0");
-  if (B == 0 || S == 0) return 0;
-  const int slices = cdiv(D, DWB_SLICE);
-  const int bps = VMR_DWCONV_BWD_BPS(S);
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(dwconv_bwd_kernel<bf16_t>, dim3(B * slices * bps), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)du, (const bf16_t*)x, gamma, beta, mean, rstd, w, (bf16_t*)dn, workspace, S, D,
-                       slices, bps);
-  else
-    hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(B * slices * bps), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)du, (const float*)x, gamma, beta, mean, rstd, w, (float*)dn, workspace, S, D,
-                       slices, bps);
-  VMR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colreduce_kernel, dim3(cdiv(D * 7, 256), cdiv(B * bps, 16)), dim3(256), 0, (hipStream_t)stream,
-                     workspace, dw, dw, B * bps, D * 7, 0, 0);
-  VMR_LAUNCH_CHECK();
-  return 0;
+  return vmr_dwconv_bwd2(du, x, gamma, beta, mean, rstd, w, dn, dw, workspace, B, S, 0, 0, D, dtype, stream);
 }

@@ -822,11 +822,12 @@ class _LnDwConv(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         w2 = w.detach().reshape(D, 7).contiguous()
         r = 0
-        for (B, S) in segs:
-            L.check(L.lib().vmr_ln_dwconv_fwd(x[r:].data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, w2.data_ptr(),
-                                              u[r:].data_ptr(), mean[r:].data_ptr(), rstd[r:].data_ptr(), B, S, D,
-                                              L.dtype_code(x), L.stream_ptr()), "vmr_ln_dwconv_fwd")
-            r += B * S
+        for i in range(0, len(segs), 2):   # two sequence groups (clips + sentences) per launch
+            (B1, S1), (B2, S2) = segs[i], (segs[i + 1] if i + 1 < len(segs) else (0, 0))
+            L.check(L.lib().vmr_ln_dwconv_fwd2(x[r:].data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, w2.data_ptr(),
+                                               u[r:].data_ptr(), mean[r:].data_ptr(), rstd[r:].data_ptr(), B1, S1,
+                                               B2, S2, D, L.dtype_code(x), L.stream_ptr()), "vmr_ln_dwconv_fwd2")
+            r += B1 * S1 + B2 * S2
         ctx.save_for_backward(x, gamma, beta, w2, mean, rstd)
         ctx.meta = (segs, tuple(w.shape))
         ctx.params = (gamma, beta, w)
@@ -847,14 +848,15 @@ class _LnDwConv(torch.autograd.Function):
         direct = mg is not None and mb is not None and mw is not None
         dw = mw if direct else torch.zeros(D, 7, device=x.device, dtype=torch.float32)
         r = 0
-        ws = torch.empty(max(max(b * ((sq + 63) // 64) for b, sq in segs) * D * 7, L.ln_bwd_ws_floats(rows, D)),
+        ws = torch.empty(max(sum(b * ((sq + 63) // 64) for b, sq in segs) * D * 7, L.ln_bwd_ws_floats(rows, D)),
                          device=x.device,
                          dtype=torch.float32)
-        for (B, S) in segs:
-            L.check(lib.vmr_dwconv_bwd(du[r:].data_ptr(), x[r:].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                       mean[r:].data_ptr(), rstd[r:].data_ptr(), w2.data_ptr(), dn[r:].data_ptr(),
-                                       dw.data_ptr(), ws.data_ptr(), B, S, D, dt, st), "vmr_dwconv_bwd")
-            r += B * S
+        for i in range(0, len(segs), 2):
+            (B1, S1), (B2, S2) = segs[i], (segs[i + 1] if i + 1 < len(segs) else (0, 0))
+            L.check(lib.vmr_dwconv_bwd2(du[r:].data_ptr(), x[r:].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                        mean[r:].data_ptr(), rstd[r:].data_ptr(), w2.data_ptr(), dn[r:].data_ptr(),
+                                        dw.data_ptr(), ws.data_ptr(), B1, S1, B2, S2, D, dt, st), "vmr_dwconv_bwd2")
+            r += B1 * S1 + B2 * S2
         dx = torch.empty_like(x)
         dg = mg if direct else torch.zeros(D, device=x.device, dtype=torch.float32)
         db = mb if direct else torch.zeros_like(dg)
