@@ -1,0 +1,40 @@
+import sys, os, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vmrframe_amd import ops, _lib as L
+dev="cuda"
+def bench(M,N,K,ta,tb,flags=0,splitk=1,iters=50, epi=False, tag=""):
+    dt=torch.bfloat16
+    # rotate through several operand sets so the inputs are not L2/MALL-hot from the previous launch
+    nset = 6
+    As=[(torch.randn(K,M,device=dev) if ta else torch.randn(M,K,device=dev)).to(dt) for _ in range(nset)]
+    Bs=[(torch.randn(K,N,device=dev) if tb else torch.randn(N,K,device=dev)).to(dt) for _ in range(nset)]
+    acc = bool(flags & (L.EPI_ACCUM|L.EPI_SLAB))
+    Cs=[torch.zeros(M*max(1,splitk),N,device=dev,dtype=torch.float32 if acc else dt) for _ in range(nset)]
+    descs=[]
+    keep=[]
+    for i in range(nset):
+        d=L.GemmDesc(); d.A,d.B,d.C=As[i].data_ptr(),Bs[i].data_ptr(),Cs[i].data_ptr()
+        d.lda,d.ldb,d.ldc,d.ldr=As[i].stride(0),Bs[i].stride(0),N,N
+        d.M,d.N,d.K,d.transA,d.transB,d.dtype=M,N,K,ta,tb,1
+        f=flags
+        if epi:
+            bias=torch.randn(N,device=dev); res=torch.randn(M,N,device=dev).to(dt); aux=torch.empty_like(res); keep+= [bias,res,aux]
+            f |= L.EPI_BIAS|L.EPI_RELU|L.EPI_DROPOUT|L.EPI_RESIDUAL|L.EPI_AUX
+            d.bias,d.residual,d.aux=bias.data_ptr(),res.data_ptr(),aux.data_ptr(); d.drop_p=0.2; d.drop_seed=77
+        d.flags=f; d.alpha=1.0; d.Z1=d.Z2=1; d.splitk=splitk
+        descs.append(d)
+    lib=L.lib(); st=torch.cuda.current_stream().cuda_stream
+    for i in range(6): lib.vmr_gemm(C.byref(descs[i%nset]), st)
+    torch.cuda.synchronize()
+    g=torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        st2=torch.cuda.current_stream().cuda_stream
+        for i in range(iters): lib.vmr_gemm(C.byref(descs[i%nset]), st2)
+    g.replay(); torch.cuda.synchronize()
+    e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+    t=e0.elapsed_time(e1)*1e-3/iters
+    print(f"v={os.environ.get('VMR_GEMM_DMA','3')} {tag} M{M} N{N} K{K} ta{ta} tb{tb} sk{splitk} epi{int(epi)}: {t*1e6:7.1f} us {2*M*N*K/t/1e12:7.1f} TF", flush=True)
+for (M,N,K,ta,tb) in [(8192,1024,1024,0,0),(9472,1024,1024,0,0),(9472,3072,1024,0,0),(8192,3072,1024,0,0),(9472,2048,1024,0,0),(8192,2048,1024,0,0),(8192,1024,4096,0,0),(9472,1024,2048,0,0),(1280,1024,4096,0,0)]:
+    bench(M,N,K,ta,tb,iters=30)

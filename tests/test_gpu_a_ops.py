@@ -43,10 +43,12 @@ def test_gemm_exact_integer_all_layouts(dev, dt, shape):
             assert torch.equal(out, ref), (dt, shape, ta, tb)
 
 
-@pytest.mark.parametrize("shape", [(512, 256, 128), (768, 384, 192), (9472, 1024, 128), (1024, 1024, 2368)])
+@pytest.mark.parametrize("shape", [(512, 256, 128), (768, 384, 192), (9472, 1024, 128), (1024, 1024, 2368),
+                                   (9472, 2048, 192)])
 def test_gemm_lds_dma_kernels_exact(dev, shape):
-    """The interior LDS-DMA kernels (128x128 and 160x128 tiles, all four layouts), including the ragged last
-    row tile of the tall variant at [9472 x 1024] and fused epilogues with dropout."""
+    """The interior LDS-DMA kernels (128x128 / 160x128 tiles, all four layouts, and the 512-thread 320x128 tile the
+    cost model picks for the two-round [9472 x 2048] x.W^T product), including the ragged last row tile at
+    M = 9472 and fused epilogues with dropout."""
     ops = _ops()
     from vmrframe_amd import _lib as L
     M, N, K = shape
@@ -83,6 +85,25 @@ def test_gemm_lds_dma_kernels_exact(dev, shape):
         h = torch.relu(A.float() @ B.float().t() + bias) * mask
         assert torch.equal(aux, h.to(dt)), (shape, tb)
         assert torch.equal(out, (h + res.float()).to(dt)), (shape, tb)
+
+
+@pytest.mark.parametrize("shape", [(1024, 1024, 2112, 8), (256, 128, 1024, 4), (1024, 1024, 8192, 8)])
+def test_gemm_splitk_slabs_colsum(dev, shape):
+    """Weight-gradient shape: dW = A^T.B with split-K slabs (plain fp32 partials + vmr_splitk_reduce) and the
+    bias gradient (column sums of A^T) riding on the product."""
+    ops = _ops()
+    from vmrframe_amd import _lib as L
+    M, N, K, sk = shape
+    torch.manual_seed(K)
+    dt = torch.bfloat16
+    A, B = _ints(K, M, dt, dev), _ints(K, N, dt, dev)
+    ws = torch.empty(sk, M, N, device=dev)
+    cs = torch.ones(M, device=dev)
+    ops.gemm(A, B, ws, M, N, K, 1, 1, M, N, N, dtype=L.BF16, flags=L.EPI_SLAB, splitk=sk, a_colsum=cs)
+    dst = torch.ones(M, N, device=dev)
+    L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, M * N, N, N, L.stream_ptr()), "reduce")
+    assert torch.equal(dst - 1, A.float().t() @ B.float())
+    assert torch.equal(cs - 1, A.float().sum(0))
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])

@@ -292,6 +292,8 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int t16, i
   } else {
     const int g = lane >> 4, ii = lane & 15, q = ii >> 2, p = ii & 3;
     const int r = kk * 32 + 8 * g + q;
+    lds += (t16 >> 3) * (BK * 256);   // a 256-wide operand = two [BK][128] images back to back
+    t16 &= 7;
     const int a0 = r * 256 + ((t16 ^ swz_tr(r)) << 5) + p * 8;
     const int a1 = (r + 4) * 256 + ((t16 ^ swz_tr(r + 4)) << 5) + p * 8;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -394,15 +396,16 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 
 // one operand tile (128 rows x BK, or BK x 128 for the transposed image) = 128*BK*2 bytes = NB 1-KiB blocks
 // (ROWS = 160 for the 160-row A tile of the ragged-M variant: rows past rmax re-read row rmax)
-template <bool KC, int BK, int ROWS = 128>
+template <bool KC, int BK, int ROWS = 128, int NW = 4>
 __device__ __forceinline__ void dma_operand(const bf16_t* __restrict__ P, int64_t ld, int r0, int k0,
                                             unsigned char* lds, int wid, int lane, int rmax = 0x7fffffff) {
-  constexpr int NB = ROWS * BK * 2 / 1024;  // 8 (BK=32) or 16 (BK=64) blocks, NB/4 per wave
-  static_assert(NB % 4 == 0, "operand blocks must divide over the 4 waves");
-  static_assert(ROWS == 128 || (KC && BK == 64), "tall tiles: k-contiguous BK=64 image only");
+  constexpr int NB = ROWS * BK * 2 / 1024;  // 8 (BK=32) or 16 (BK=64) blocks per 128 rows, NB/NW per wave
+  static_assert(NB % NW == 0, "operand blocks must divide over the waves");
+  static_assert(ROWS == 128 || BK == 64, "tall / wide tiles: BK=64 images only");
+  static_assert(KC || ROWS % 128 == 0, "transposed image: whole [BK][128] images");
 #pragma unroll
-  for (int jj = 0; jj < NB / 4; ++jj) {
-    const int j = wid * (NB / 4) + jj;
+  for (int jj = 0; jj < NB / NW; ++jj) {
+    const int j = wid * (NB / NW) + jj;
     const bf16_t* src;
     if (KC) {
       if (BK == 64) {       // 128-B rows: one wave-instruction = 8 whole rows = 8 full cache lines
@@ -415,23 +418,24 @@ __device__ __forceinline__ void dma_operand(const bf16_t* __restrict__ P, int64_
         src = P + (int64_t)(r0 + row) * ld + k0 + c * 8;
       }
     } else {
-      const int r = 4 * j + (lane >> 4);
+      constexpr int BPI = BK / 4;                  // 1-KiB blocks per [BK][128] image
+      const int r = 4 * (j % BPI) + (lane >> 4);
       const int ph16 = lane & 15;
       const int c32 = (ph16 >> 1) ^ swz_tr(r);
-      src = P + (int64_t)(k0 + r) * ld + r0 + (c32 * 2 + (ph16 & 1)) * 8;
+      src = P + (int64_t)(k0 + r) * ld + r0 + (j / BPI) * 128 + (c32 * 2 + (ph16 & 1)) * 8;
     }
     __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)(lds + j * 1024), 16, 0, 0);
   }
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
+#define VMR_VMCNT_CASE(n) else if (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-  else static_assert(N == 0 || N == 4 || N == 8 || N == 9 || N == 16 || N == 18, "add the immediate");
+  VMR_VMCNT_CASE(4); VMR_VMCNT_CASE(6); VMR_VMCNT_CASE(7); VMR_VMCNT_CASE(8); VMR_VMCNT_CASE(9);
+  VMR_VMCNT_CASE(12); VMR_VMCNT_CASE(14); VMR_VMCNT_CASE(16); VMR_VMCNT_CASE(18);
+  else static_assert(N == 0 || N == 4 || N == 6 || N == 7 || N == 8 || N == 9 || N == 12 || N == 14 || N == 16 || N == 18,
+                     "add the immediate");
+#undef VMR_VMCNT_CASE
 }
 
 // Register-direct epilogue of the LDS-DMA kernel (bf16 output, interior tiles).  The MFMAs are issued
@@ -502,14 +506,20 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
 // MT = 16-row MFMA tiles per wave along M: 4 -> the 128x128 tile; 5 -> a 160x128 tile (A not
 // transposed, register-direct epilogue only, ragged last row tile allowed) that turns the 592-tile,
 // 1.16-round grids of the packed [9472 x 1024] products into ONE round of 480 workgroups.
-template <bool TA, bool TB, int BK, int NST, int MT = 4>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
+// WM = waves along M: 2 -> 256 threads, two workgroups per CU; 4 -> 512 threads, ONE 256x128 (MT = 4) or
+// 320x128 (MT = 5) workgroup per CU.  The K loop is bound by the L2 -> LDS fill (measured: the loop without
+// MFMAs takes 90 % of the full time, ~60 GB/s per CU), so bytes per flop decide: one wide tile per CU
+// fetches (256 + 128) rows per K-step where two 128x128 tiles fetch 2 x (128 + 128).
+template <bool TA, bool TB, int BK, int NST, int MT = 4, int WM = 2>
+__global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(MT == 4 || (!TA && BK == 64), "tall tile: A row-major, BK = 64");
-  constexpr int TBM = MT * 32;               // tile rows
+  static_assert(WM == 2 || WM == 4, "2 or 4 waves along M");
+  constexpr int NW = 2 * WM;                 // waves
+  constexpr int TBM = MT * 16 * WM;          // tile rows
   constexpr int OPA = TBM * BK * 2;          // A operand bytes per stage
   constexpr int OPB = 128 * BK * 2;          // B operand bytes per stage
-  constexpr int LPS = (OPA + OPB) / 1024 / 4;  // loads per wave per K-step (A + B)
+  constexpr int LPS = (OPA + OPB) / 1024 / NW;  // loads per wave per K-step (A + B)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
@@ -536,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
   // order, so every counted wait below also covers them): their HBM latency hides under the whole
   // K loop instead of being exposed once per tile.
   bf16x4 rres[MT][4];
-  const bool direct = MT != 4 || !(g.flags & VMR_EPI_ACCUM);   // atomics keep the LDS-staged, 256-B-per-wave shape
+  const bool direct = MT != 4 || WM != 2 || !(g.flags & VMR_EPI_ACCUM);   // atomics keep the LDS-staged, 256-B-per-wave shape
   if (direct && (g.flags & VMR_EPI_RESIDUAL)) {
     const bf16_t* Rsd = reinterpret_cast<const bf16_t*>(g.residual) + coff;
 #pragma unroll
@@ -551,8 +561,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) {
     if (s < nk) {
-      dma_operand<!TA, BK, TBM>(A, g.lda, m0, k_begin + s * BK, smem + s * (OPA + OPB), wid, lane, g.M - 1);
-      dma_operand<!TB, BK>(B, g.ldb, n0, k_begin + s * BK, smem + s * (OPA + OPB) + OPA, wid, lane);
+      dma_operand<!TA, BK, TBM, NW>(A, g.lda, m0, k_begin + s * BK, smem + s * (OPA + OPB), wid, lane, g.M - 1);
+      dma_operand<!TB, BK, 128, NW>(B, g.ldb, n0, k_begin + s * BK, smem + s * (OPA + OPB) + OPA, wid, lane);
     }
   }
   // Software-pipelined fragment reads: the ds_reads of the next 32-deep k-substep are in flight while
@@ -597,8 +607,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
     if (kt + NST - 1 < nk) {
       unsigned char* dst = smem + ((kt + NST - 1) % NST) * (OPA + OPB);
       const int k0 = k_begin + (kt + NST - 1) * BK;
-      dma_operand<!TA, BK, TBM>(A, g.lda, m0, k0, dst, wid, lane, g.M - 1);
-      dma_operand<!TB, BK>(B, g.ldb, n0, k0, dst + OPA, wid, lane);
+      dma_operand<!TA, BK, TBM, NW>(A, g.lda, m0, k0, dst, wid, lane, g.M - 1);
+      dma_operand<!TB, BK, 128, NW>(B, g.ldb, n0, k0, dst + OPA, wid, lane);
     }
     const unsigned char* cur = smem + (kt % NST) * (OPA + OPB);
 #pragma unroll
@@ -627,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(vmr_gemm_t g, int
                     rres, reinterpret_cast<bf16_t*>(g.aux) + coff);
     return;
   }
-  if constexpr (MT == 4) {
+  if constexpr (MT == 4 && WM == 2) {
   __syncthreads();
   epilogue<bf16_t, true, true, true>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
                          (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM))
@@ -793,6 +803,18 @@ constexpr int TALL_SMEM = 2 * (160 * 64 * 2 + 128 * 64 * 2);   // 73,728 B: two 
 gemm_fn pick_tall(int tb) {
   return tb ? (gemm_fn)gemm_bf16_dma_kernel<false, true, 64, 2, 5> : (gemm_fn)gemm_bf16_dma_kernel<false, false, 64, 2, 5>;
 }
+// one 512-thread workgroup per CU: 320x128 tiles (A row-major, ragged M allowed)
+gemm_fn pick_wide_tall() { return (gemm_fn)gemm_bf16_dma_kernel<false, false, 64, 2, 5, 4>; }
+inline int set_smem_once(gemm_fn fn, int smem) {   // > 64 KiB of dynamic LDS must be opted into once per kernel
+  static thread_local const void* done[48];
+  static thread_local int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done[i] == reinterpret_cast<const void*>(fn)) return 0;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  if (e != hipSuccess) return vmr_fail(-5, "vmr_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  if (ndone < 48) done[ndone++] = reinterpret_cast<const void*>(fn);
+  return 0;
+}
 // rounds of the 512 resident workgroups (2 per CU) a grid needs, in units of one full 128x128 round:
 // a last round that leaves every CU at most one workgroup runs about twice as fast
 inline double rounds_cost(int64_t tiles, double tile_weight) {
@@ -868,6 +890,32 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   if (g_tall < 0) {
     const char* e = getenv("VMR_GEMM_TALL");
     g_tall = e ? atoi(e) : 1;
+  }
+  // wide tiles (ONE 512-thread 320x128 workgroup per CU, 256 per round): 22 % fewer L2 -> LDS bytes per flop than two
+  // 160x128 workgroups.  Measured (scratch/gemm_ksweep.py): a win only for row-major x.W^T products that need two or
+  // more rounds ([9472 x 2048 x 1024]: 65 -> 59 us); single-round grids and transposed-operand layouts lose 3-15 %
+  // (one workgroup per CU leaves nothing to run while its 8 waves sit at the K-step barrier), so they never take it.
+  static int g_wide = -1;
+  if (g_wide < 0) {
+    const char* e = getenv("VMR_GEMM_WIDE");
+    g_wide = e ? atoi(e) : 1;
+  }
+  const bool tall_ok = g_tall && g_gemm_dma >= 2 && al && g.dtype == VMR_BF16 && !g.transA && g.N % BN == 0 && g.K % 64 == 0 &&
+                       g.K >= 128 && g.splitk == 1 && !(g.flags & VMR_EPI_ACCUM) && g.M % 8 == 0 &&
+                       (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));
+  const double c128 = dma_ok ? rounds_cost((int64_t)tiles_m * tiles_n * Z, 1.0) : 1e30;
+  const double c160 = (tall_ok && dma_ok) ? rounds_cost((int64_t)cdiv(g.M, 160) * tiles_n * Z, 1.25) : 1e30;
+  if (g_wide && tall_ok && dma_ok && !g.transB && g.M >= 320) {
+    const int tm = cdiv(g.M, 320);
+    const int64_t rounds = ((int64_t)tm * tiles_n * Z + 255) / 256;
+    if (rounds >= 2 && (double)rounds * 1.25 * 0.9 < (c128 < c160 ? c128 : c160) - 1e-9) {
+      gemm_fn wf = pick_wide_tall();
+      const int smem = 2 * (320 + 128) * 128;
+      if (int rc = set_smem_once(wf, smem)) return rc;
+      hipLaunchKernelGGL(wf, dim3((unsigned)(tm * tiles_n), 1, (unsigned)Z), dim3(512), smem, (hipStream_t)stream, g, tm, tiles_n);
+      VMR_LAUNCH_CHECK();
+      return 0;
+    }
   }
   if (g_tall && g_gemm_dma >= 2 && al && g.dtype == VMR_BF16 && !g.transA && g.N % BN == 0 && g.K % 64 == 0 && g.K >= 128 &&
       g.splitk == 1 && !(g.flags & VMR_EPI_ACCUM) && g.M % 8 == 0 &&
