@@ -256,13 +256,6 @@ class SeqPAN(nn.Module):
         """Conv1D with <= 8 output channels -> fp32 logits (matrix-vector kernels, ops.narrow_linear)."""
         return ops.narrow_linear(x, self.P(prefix + ".conv1d.weight"), self.P(prefix + ".conv1d.bias"))
 
-    def _lin_cat2(self, a, b, prefix):
-        """Conv1D(cat([a, b], 1)) without the concat: a.W[:, :D]^T + b.W[:, D:]^T + bias."""
-        W, bias = self.P(prefix + ".conv1d.weight"), self.P(prefix + ".conv1d.bias")
-        D = a.shape[1]
-        first = ops.linear(a, W, bias, self._cache, kslice=(0, D))
-        return ops.linear(b, W, None, self._cache, kslice=(D, D + b.shape[1]), residual=first)
-
     def _ln(self, x, prefix, eps, **kw):
         return ops.layer_norm(x, self.P(prefix + ".weight"), self.P(prefix + ".bias"), eps, self._cache, **kw)
 
@@ -311,18 +304,21 @@ class SeqPAN(nn.Module):
         m = prefix + ".dual_multihead_attention"
         W = lambda n: self.P(f"{m}.{n}.conv1d.weight")
         Bv = lambda n: self.P(f"{m}.{n}.conv1d.bias")
+        # (tee=True: the op also returns its input; the NEXT consumer of that tensor takes the returned alias, so the
+        #  gradients of a multiply-used tensor chain through fused epilogues instead of autograd's add passes)
         n1, Xr = self._ln(X, prefix + ".layer_norm_1", 1e-6, drop=dc.next(prefix + ".ln1"), tee=True)
-        nt = self._ln(X, prefix + ".layer_norm_t", 1e-6)
-        qkv = ops.linear(n1, [W("query"), W("f_key"), W("f_value")],
-                         self._group_bias([f"{m}.{n}.conv1d.bias" for n in ("query", "f_key", "f_value")]), c)
+        nt, Xr = self._ln(Xr, prefix + ".layer_norm_t", 1e-6, tee=True)
+        qkv, n1 = ops.linear(n1, [W("query"), W("f_key"), W("f_value")],
+                             self._group_bias([f"{m}.{n}.conv1d.bias" for n in ("query", "f_key", "f_value")]), c,
+                             tee=True)
         kv = ops.linear(nt, [W("t_key"), W("t_value")],
                         self._group_bias([f"{m}.{n}.conv1d.bias" for n in ("t_key", "t_value")]), c)
         so, xo = ops.dual_attention(qkv, kv, vmask, tmask, B, T, Lq, H,
                                     [dc.next(prefix + f".attn{i}") for i in range(4)])
         sval = ops.linear(so, W("s_dense"), Bv("s_dense"), c)
         xval = ops.linear(xo, W("x_dense"), Bv("x_dense"), c)
-        sscore = ops.linear(sval, W("s_gate"), Bv("s_gate"), c)
-        xscore = ops.linear(xval, W("x_gate"), Bv("x_gate"), c)
+        sscore, sval = ops.linear(sval, W("s_gate"), Bv("s_gate"), c, tee=True)
+        xscore, xval = ops.linear(xval, W("x_gate"), Bv("x_gate"), c, tee=True)
         gated = ops.cross_gate(sscore, sval, xscore, xval)                      # cross gating (:374)
         # guided_dense(...) + n1 : the BiLinear input a+b, added in the GEMM epilogue
         bl_in = ops.linear(gated, W("guided_dense"), Bv("guided_dense"), c, residual=n1)
@@ -441,14 +437,18 @@ class SeqPAN(nn.Module):
         fuse2 = ops.linear(ms, self.P("label_embs"), None, self._cache, residual=fuse,
                            rowscale=vmask.reshape(-1))
         # predictor (reference layers.py:659-671)
-        sfeat = self._predict_encoder(fuse2, vmask, B, T, dc, "pred.s")
-        efeat = self._predict_encoder(sfeat, vmask, B, T, dc, "pred.e")
-        sn = self._ln(sfeat, "predictor.start_layer_norm", 1e-6)
-        en = self._ln(efeat, "predictor.end_layer_norm", 1e-6)
         # start/end_hidden(cat[features, fuse2]) as two K=D GEMMs on column slices of the weight (the second
-        # accumulates through the residual input): no [Nv, 2D] concat copies
-        sh = self._lin_cat2(sn, fuse2, "predictor.start_hidden")
-        eh = self._lin_cat2(en, fuse2, "predictor.end_hidden")
+        # accumulates through the residual input): no [Nv, 2D] concat copies.  The fuse2 halves come first so that
+        # fuse2's three consumers chain their gradients (tee) instead of meeting in two autograd add passes.
+        Ws, We = self.P("predictor.start_hidden.conv1d.weight"), self.P("predictor.end_hidden.conv1d.weight")
+        ps, fuse2 = ops.linear(fuse2, Ws, None, self._cache, kslice=(D, 2 * D), tee=True)
+        pe, fuse2 = ops.linear(fuse2, We, None, self._cache, kslice=(D, 2 * D), tee=True)
+        sfeat = self._predict_encoder(fuse2, vmask, B, T, dc, "pred.s")
+        sn, sfeat = self._ln(sfeat, "predictor.start_layer_norm", 1e-6, tee=True)
+        efeat = self._predict_encoder(sfeat, vmask, B, T, dc, "pred.e")
+        en = self._ln(efeat, "predictor.end_layer_norm", 1e-6)
+        sh = ops.linear(sn, Ws, self.P("predictor.start_hidden.conv1d.bias"), self._cache, kslice=(0, D), residual=ps)
+        eh = ops.linear(en, We, self.P("predictor.end_hidden.conv1d.bias"), self._cache, kslice=(0, D), residual=pe)
         slogits = self._head(sh, "predictor.start_dense").reshape(B, T)
         elogits = self._head(eh, "predictor.end_dense").reshape(B, T)
         self.last_drop_sites = dc.sites

@@ -288,7 +288,7 @@ class _Linear(torch.autograd.Function):
     the compute-dtype copy comes from the WeightCache."""
 
     @staticmethod
-    def forward(ctx, x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, kslice, res_div, *weights):
+    def forward(ctx, x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, kslice, res_div, tee, *weights):
         L.require_gpu(x)
         assert x.dim() == 2 and x.stride(1) == 1
         W = cache.get(weights, x.dtype, 0 if kslice is not None else x.shape[1])
@@ -335,10 +335,12 @@ class _Linear(torch.autograd.Function):
         ctx.kslice, ctx.res_div = kslice, res_div
         assert res_div == 1 or aux is None
         assert bias2 is None or (bias is not None and Np == N)
+        if tee:   # second output = x itself: its other consumer's gradient arrives here and rides on the dX epilogue
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxtra=None):
         x, W, h, rowscale = ctx.saved_tensors
         relu, drop, has_bias, has_res, wshapes = ctx.meta
         M, N = dy.shape
@@ -390,7 +392,16 @@ class _Linear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             few = mm_few_tiles(dz, W, 0, 1)
-            dx = few.to(dz.dtype) if few is not None else mm(dz, W, 0, 1)                       # [M,N] . [N,Kp]
+            if few is not None:
+                dx = (few if dxtra is None else few + dxtra).to(dz.dtype)
+            elif dxtra is not None:          # tee: dX = dz.W + (gradient of x's other consumer), one epilogue
+                dxtra = dxtra.contiguous()
+                assert dxtra.shape == x.shape and dxtra.dtype == dz.dtype
+                dx = mm(dz, W, 0, 1, flags=L.EPI_RESIDUAL, residual=dxtra, ldr=dxtra.stride(0))
+            else:
+                dx = mm(dz, W, 0, 1)                                                            # [M,N] . [N,Kp]
+        elif dxtra is not None:
+            dx = dxtra
         # dW = dz^T . x  -> fp32 [N,Kp], split-K over the M (token) dimension
         sk = splitk_for(N, Kp, M)
         slots = [main_grad(w) for w in ctx.weights]
@@ -426,7 +437,7 @@ class _Linear(torch.autograd.Function):
             if db is not None and Np != N:
                 db = db[:N]
             return (dx, *_bias_grads(db, bgrad, has_b2, ctx.bias_scale), None, dres, None, None, None, None, None, None,
-                    *([None] * len(wshapes)))
+                    None, *([None] * len(wshapes)))
         if sk > 1:
             dW = torch.zeros(N, Kp, device=dy.device, dtype=torch.float32)
             gemm(dz, x, dW, N, Kp, M, 1, 1, dz.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_ACCUM, splitk=sk)
@@ -449,7 +460,7 @@ class _Linear(torch.autograd.Function):
         if db is not None and Np != N:
             db = db[:N]
         return (dx, *_bias_grads(db, bgrad, has_b2, ctx.bias_scale), None, dres, None, None, None, None, None, None,
-                *grads)
+                None, *grads)
 
 
 def _bias_grads(db, bgrad, has_b2, bias_scale):
@@ -460,11 +471,14 @@ def _bias_grads(db, bgrad, has_b2, bias_scale):
 
 
 def linear(x, weights, bias, cache, *, relu=False, drop=NO_DROP, residual=None, rowscale=None, bias2=None,
-           bias_scale=1.0, kslice=None, res_div=1):
-    """y = drop(act(x.W[:, kslice]^T + bias_scale*bias + bias2)) + residual[row // res_div]."""
+           bias_scale=1.0, kslice=None, res_div=1, tee=False):
+    """y = drop(act(x.W[:, kslice]^T + bias_scale*bias + bias2)) + residual[row // res_div].
+    tee=True returns (y, x): hand that x to the tensor's OTHER consumer, whose gradient then joins dX inside the
+    backward GEMM's epilogue instead of through a separate autograd add pass."""
     if isinstance(weights, torch.Tensor):
         weights = [weights]
-    return _Linear.apply(x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, kslice, res_div, *weights)
+    return _Linear.apply(x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, kslice, res_div, tee,
+                         *weights)
 
 
 class _WeightedPool(torch.autograd.Function):
