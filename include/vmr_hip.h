@@ -55,6 +55,8 @@ int vmr_sizeof_gemm_desc(void); /* ABI guard for foreign-language bindings of vm
 #define VMR_EPI_ACCUM 64    /* C (fp32) += result, via atomics (split-K safe)  */
 #define VMR_EPI_ROWSCALE 128 /* multiply row m by rowscale[m] (fp32) at the end */
 #define VMR_EPI_SLAB 256     /* split-K without atomics: split ks writes fp32 C + ks*M*ldc (then vmr_splitk_reduce) */
+#define VMR_EPI_RES_PRE 512  /* with VMR_EPI_RESIDUAL: the residual joins the PRE-activation, act(x.W^T + b + residual),
+                               * instead of being added after activation / dropout (BAN map2d_proj on a concatenation) */
 
 typedef struct {
   const void* A;
@@ -378,6 +380,32 @@ int vmr_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay
               by transformers' linear warm-up/decay multiplier of step_dev[0] (utils/utils.py:95-96),
               evaluated on the device so a captured hipGraph replays the schedule */,
               int64_t n, void* stream);
+
+/* ------------------------------------------------ BAN 2-D proposal map (N2)
+ * Replaces the diagonal loops of SparseMaxPool / DenseMaxPool (models/BANlib/model.py:226-290) and
+ * SparseBoundaryCat (:293-325) feeding map2d_proj (models/BAN.py:87-93).  Only the cells the reference's mask2d
+ * keeps exist, in compact cell-major order: the main diagonal (i, i), then diagonal k = 1..ndiag at offset
+ * o_k = grow[0] + .. + grow[k-1] (cells (i, i + o_k), i ascending) -- the order of the reference's `maskij`.
+ * grow[k] = MaxPool1d kernel size - 1 of pooler k (1 | 2 | 4 for pooling_counts levels 0 | 1 | 2; all 1 for
+ * DenseMaxPool); `grow` is the device copy, `grow_host` the host copy of the same int32 array.
+ *   M[b, c, :] = max_{t in [i_c, j_c]} x[b, t, :]          x: [B, N, F] (fuse_feature), M: [B, C, F]
+ *   R[b, c, :] = ps[b, i_c, :] + pe[b, j_c, :]             ps / pe: [B, N, F] views with row stride ldp (the start /
+ *                                                           end thirds of map2d_proj applied per frame); R, ps, pe
+ *                                                           may all be NULL
+ * C = vmr_map2d_cells(grow_host, ndiag, N).  N <= 160, F % 64 == 0.
+ * Backward: dx[b, t, :] = sum of dM over the cells whose arg-max frame is t (first frame wins ties, as the chained
+ * MaxPool1d backward does); dps[b, i, :] = sum_{c: i_c = i} dR, dpe[b, j, :] = sum_{c: j_c = j} dR. */
+int vmr_map2d_cells(const int32_t* grow_host, int ndiag, int N);
+int vmr_map2d_pool_fwd(const void* x, const void* ps, const void* pe, int64_t ldp, const int32_t* grow,
+                       const int32_t* grow_host, int ndiag, void* M, void* R, int B, int N, int F, int dtype,
+                       void* stream);
+int vmr_map2d_pool_bwd(const void* x, const void* dM, const void* dR, const int32_t* grow,
+                       const int32_t* grow_host, int ndiag, void* dx, void* dps, void* dpe, int64_t ldp, int B,
+                       int N, int F, int dtype, void* stream);
+/* dense [B, N, N, W] <- compact [B, C, W]: cell_of[i*N + j] = compact index or -1; cells off the mask get fill[W]
+ * (fp32, nullable = 0): what the reference computes there from an all-zero input (tmap / map2d_proj of BAN.forward). */
+int vmr_map2d_scatter(const void* cells, const int32_t* cell_of, const float* fill, void* out, int B, int N, int W,
+                      int64_t C, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -287,15 +287,79 @@ def staging_case():
     print("g_staging: ok", len(out), "arrays")
 
 
+def ban_map_case():
+    """The BAN proposal-map stage built from the REAL reference classes (models/BANlib/model.py SparseMaxPool,
+    SparseBoundaryCat, DenseMaxPool, NaivePredictor; wiring of models/BAN.py:38-65,87-99) in eval mode, with
+    gradients of a fixed random functional of its outputs."""
+    from oracle import ban_map_ref as BR
+    import_reference()
+    bm = importlib.import_module("models.BANlib.model")
+    B, N, F, Cd, pc = 2, 16, 64, 8, [3, 2, 2]
+    rng = np.random.default_rng(77)
+    w = BR.make_weights(F, Cd, 77)
+    hidden_b = torch.tensor(np.maximum(rng.standard_normal((B, N, F)), 0).astype(np.float32), requires_grad=True)
+    fuse = rng.standard_normal((B, N, F)).astype(np.float32)
+    fuse[1, 11:] = 0.0                                                    # padded frames of a shorter clip: exact ties
+    fuse = torch.tensor(fuse, requires_grad=True)
+    boundary = bm.SparseBoundaryCat(pc, N, "cpu")
+    content = bm.SparseMaxPool(pc, N, "cpu")
+    map2d_proj = torch.nn.Sequential(torch.nn.Linear(3 * F, F), torch.nn.ReLU(inplace=True), torch.nn.Dropout(0.1))
+    predictor = bm.NaivePredictor(F, F, intermediate=True)
+    contrast = torch.nn.Sequential(torch.nn.Linear(F, Cd), torch.nn.ReLU(inplace=True), torch.nn.Linear(Cd, Cd))
+    mods = {"map2d_proj": map2d_proj, "predictor": predictor, "contrast_encoder": contrast}
+    params = {}
+    for pre, m in mods.items():
+        m.eval()
+        for k, v in m.named_parameters():
+            v.data.copy_(torch.from_numpy(w[f"{pre}.{k}"]))
+            params[f"{pre}.{k}"] = v
+    assert sorted(params) == sorted(w)
+    # models/BAN.py:87-99
+    s_e, _ = boundary(hidden_b.permute(0, 2, 1), hidden_b.permute(0, 2, 1))
+    c, mask = content(fuse.permute(0, 2, 1))
+    c = c.permute(0, 2, 3, 1)
+    s_e = s_e.permute(0, 2, 3, 1)
+    map2d = map2d_proj(torch.cat([s_e, c], dim=-1))
+    tmap = predictor(map2d)
+    proj = contrast(c)
+    g1 = torch.tensor(rng.standard_normal((B, N, N)).astype(np.float32))
+    g2 = torch.tensor(rng.standard_normal((B, N, N, Cd)).astype(np.float32))
+    g3 = torch.tensor(rng.standard_normal((B, N, N, F)).astype(np.float32))
+    m3 = mask[None, :, :, None].float()
+    func = (tmap * g1 * mask.float()).sum() + (proj * g2 * m3).sum() + (map2d * g3 * m3).sum()
+    func.backward()
+    iou = torch.tensor(rng.uniform(0, 1, (B, N, N)).astype(np.float32))
+    lb = torch.nn.functional.binary_cross_entropy_with_logits(
+        tmap.detach().masked_select(mask), ((iou - 0.5) / 0.5).clamp(0, 1).masked_select(mask))
+    # dense (DenseMaxPool) content map alone, same input
+    dense, dmask = bm.DenseMaxPool(N, "cpu")(fuse.detach().permute(0, 2, 1))
+    out = {"B": B, "N": N, "F": F, "Cd": Cd, "pooling_counts": np.asarray(pc), "hidden_b": hidden_b.detach().numpy(),
+           "fuse": fuse.detach().numpy(), "tmap": tmap.detach().numpy(), "map2d": map2d.detach().numpy(),
+           "map2d_proj": proj.detach().numpy(), "mask": mask.numpy(), "g1": g1.numpy(), "g2": g2.numpy(), "g3": g3.numpy(),
+           "d_hidden_b": hidden_b.grad.numpy(), "d_fuse": fuse.grad.numpy(), "iou": iou.numpy(), "loss_bce": lb.numpy(),
+           "content_dense": dense.permute(0, 2, 3, 1).numpy(), "mask_dense": dmask.numpy(),
+           "content_sparse": c.detach().numpy(), "boundary_sparse": s_e.detach().numpy()}
+    for k, v in params.items():
+        out["w." + k] = w[k]
+        out["dw." + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, "g_ban_map.npz"), **out)
+    print("wrote g_ban_map.npz", {k: np.asarray(v).shape for k, v in out.items() if k in ("tmap", "map2d", "map2d_proj")})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true")
     ap.add_argument("--only-metrics", action="store_true")
+    ap.add_argument("--only-ban", action="store_true")
     args = ap.parse_args()
     torch.manual_seed(0)
+    if args.only_ban:
+        ban_map_case()
+        return
     mods = import_reference()
     metrics_case(mods)
     staging_case()
+    ban_map_case()
     if args.only_metrics:
         return
     # g_tiny: everything stored (weights, intermediates, per-parameter grads)

@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a GPU box hands the job a 16-CPU share of a much larger host: with torch's default (one thread per host
+    # core) every small CPU op of the oracle stalls in an oversubscribed OpenMP team
+    try:
+        import torch
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, min(16, n)))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -121,3 +121,42 @@ def test_oracle_infer_and_iou_metrics_match_reference_fixture():
     ious = R.append_ious([], g["gts"], g["props"])
     assert np.array_equal(np.asarray(ious, np.float64), g["ious"])
     assert np.allclose(R.get_i345_mi(ious), g["summary"], rtol=0, atol=1e-12)
+
+
+def _ban_golden():
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "g_ban_map.npz"))
+    W = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")}
+    return z, W
+
+
+def test_ban_map_oracle():
+    """Row N2: oracle/ban_map_ref.py against the fixture generated from the reference's own SparseMaxPool /
+    SparseBoundaryCat / DenseMaxPool / NaivePredictor classes (outputs, masks, loss_bce, gradients)."""
+    from oracle import ban_map_ref as BR
+    z, W = _ban_golden()
+    pc = [int(v) for v in z["pooling_counts"]]
+    N = int(z["N"])
+    assert np.array_equal(BR.mask2d(pc, N).numpy(), z["mask"])
+    assert np.array_equal(BR.mask2d(None, N).numpy(), z["mask_dense"])
+    fuse = torch.from_numpy(z["fuse"]).requires_grad_(True)
+    hb = torch.from_numpy(z["hidden_b"]).requires_grad_(True)
+    assert np.array_equal(BR.content_map(fuse.detach(), pc).numpy(), z["content_sparse"])      # max is exact
+    assert np.array_equal(BR.content_map(fuse.detach(), None).numpy(), z["content_dense"])
+    assert np.array_equal(BR.boundary_map(hb.detach(), hb.detach(), pc).numpy(), z["boundary_sparse"])
+    P = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    out = BR.stage_forward(P, hb, fuse, pc)
+    assert _md(out["tmap"].detach(), z["tmap"]) < TOL
+    assert _md(out["map2d"].detach(), z["map2d"]) < TOL
+    assert _md(out["map2d_proj"].detach(), z["map2d_proj"]) < TOL
+    mask = out["map2d_mask"]
+    m3 = mask[None, :, :, None].float()
+    func = (out["tmap"] * torch.from_numpy(z["g1"]) * mask.float()).sum() + \
+        (out["map2d_proj"] * torch.from_numpy(z["g2"]) * m3).sum() + (out["map2d"] * torch.from_numpy(z["g3"]) * m3).sum()
+    func.backward()
+    assert _md(hb.grad, z["d_hidden_b"]) < 5e-4
+    assert _md(fuse.grad, z["d_fuse"]) < 5e-4                       # includes the tie rows (padded frames)
+    for k, v in P.items():
+        assert _md(v.grad, z["dw." + k]) < 2e-3 * max(1.0, float(np.abs(z["dw." + k]).max())), k
+    lb = BR.loss_bce(out["tmap"].detach(), torch.from_numpy(z["iou"]), mask, 0.5, 1.0)
+    assert abs(float(lb) - float(z["loss_bce"])) < 1e-5

@@ -23,8 +23,8 @@ def ln_bwd_ws_floats(rows: int, D: int) -> int:
     """== VMR_LN_BWD_WS_FLOATS(rows, D)"""
     return ((rows + 7) // 8) * 2 * (512 if D <= 512 else (1024 if D <= 1024 else 2048))
 
-EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_AUX, EPI_OUT_F32, EPI_ACCUM, EPI_ROWSCALE, EPI_SLAB = \
-    1, 2, 4, 8, 16, 32, 64, 128, 256
+EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_AUX, EPI_OUT_F32, EPI_ACCUM, EPI_ROWSCALE, EPI_SLAB, EPI_RES_PRE = \
+    1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 
 class GemmDesc(C.Structure):
@@ -91,6 +91,10 @@ SIGNATURES = {
     "vmr_embedding_bwd": [_P, _P, _P, _L, _I, _L, _L, _P],
     "vmr_eltwise": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "vmr_splitk_reduce": [_P, _P, _I, _L, _I, _L, _P],
+    "vmr_map2d_cells": [_P, _I, _I],
+    "vmr_map2d_pool_fwd": [_P, _P, _P, _L, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "vmr_map2d_pool_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "vmr_map2d_scatter": [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     "vmr_sumsq": [_P, _P, _L, _P],
     "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P, _F, _F, _L, _P],
 }

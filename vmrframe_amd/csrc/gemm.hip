@@ -132,10 +132,22 @@ __device__ __forceinline__ void epilogue_half(const vmr_gemm_t& g, const float* 
         for (int e = 0; e < 8; ++e) keep |= (uint32_t)vmr_keep(seed, idx0 + e, thresh) << e;
       }
     }
+    float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (flags & VMR_EPI_RESIDUAL) {
+      if (res_vec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rv[e] = rres[pass][e];
+      } else {
+        const T* rp = Rsd + (int64_t)(gm / g.res_div) * g.ldr + gn;
+        for (int e = 0; e < nvalid; ++e) rv[e] = to_f<T>(rp[e]);
+      }
+    }
+    const bool res_pre = (flags & VMR_EPI_RES_PRE) != 0;   // residual joins the pre-activation (before ReLU / dropout)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float x = v[e] * g.alpha;
       if ((flags & VMR_EPI_BIAS) && e < nvalid) x += g.bias_scale * g.bias[gn + e] + (g.bias2 ? g.bias2[gn + e] : 0.f);
+      if (res_pre) x += rv[e];
       if (flags & VMR_EPI_RELU) x = fmaxf(x, 0.0f);
       if (flags & VMR_EPI_DROPOUT) x = ((keep >> e) & 1) ? x * dscale : 0.0f;
       v[e] = x;
@@ -146,14 +158,9 @@ __device__ __forceinline__ void epilogue_half(const vmr_gemm_t& g, const float* 
       if (vec) Vec8<T>::store(ap, v);
       else for (int e = 0; e < nvalid; ++e) ap[e] = from_f<T>(v[e]);
     }
-    if (flags & VMR_EPI_RESIDUAL) {
-      if (res_vec) {
+    if ((flags & VMR_EPI_RESIDUAL) && !res_pre) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rres[pass][e];
-      } else {
-        const T* rp = Rsd + (int64_t)(gm / g.res_div) * g.ldr + gn;
-        for (int e = 0; e < nvalid; ++e) v[e] += to_f<T>(rp[e]);
-      }
+      for (int e = 0; e < 8; ++e) v[e] += rv[e];
     }
     if (flags & VMR_EPI_ROWSCALE) {
       const float rs = g.rowscale[gm];
@@ -475,6 +482,7 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float x = acc[i][j][e] * g.alpha + bias4[j][e];
+        if (flags & VMR_EPI_RES_PRE) x += (float)rres[i][j][e];
         if (flags & VMR_EPI_RELU) x = fmaxf(x, 0.0f);
         v[e] = x;
       }
@@ -487,7 +495,7 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
         v[3] = (h.y >> 16) >= thresh ? v[3] * dscale : 0.f;
       }
       if (flags & VMR_EPI_AUX) Vec4<bf16_t>::store(Aux + (int64_t)gm * g.ldr + gn, v);
-      if (flags & VMR_EPI_RESIDUAL) {
+      if ((flags & VMR_EPI_RESIDUAL) && !(flags & VMR_EPI_RES_PRE)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += (float)rres[i][j][e];
       }
@@ -849,6 +857,7 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   VMR_CHECK(!g.a_colsum || (g.transA && g.Z1 * g.Z2 == 1), "vmr_gemm: a_colsum needs transA and Z1*Z2 == 1");
   VMR_CHECK(g.res_div == 1 || !(g.flags & VMR_EPI_AUX), "vmr_gemm: res_div with aux (aux shares ldr) is not supported");
   VMR_CHECK(!(g.flags & VMR_EPI_RESIDUAL) || g.residual, "vmr_gemm: residual flag without pointer");
+  VMR_CHECK(!(g.flags & VMR_EPI_RES_PRE) || (g.flags & VMR_EPI_RESIDUAL), "vmr_gemm: VMR_EPI_RES_PRE needs VMR_EPI_RESIDUAL");
   VMR_CHECK(!(g.flags & VMR_EPI_AUX) || g.aux, "vmr_gemm: aux flag without pointer");
   VMR_CHECK(!(g.flags & VMR_EPI_ROWSCALE) || g.rowscale, "vmr_gemm: rowscale flag without pointer");
   VMR_CHECK(!(g.flags & VMR_EPI_DROPOUT) || (g.drop_p >= 0.f && g.drop_p < 1.f), "vmr_gemm: bad drop_p");

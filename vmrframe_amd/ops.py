@@ -288,7 +288,8 @@ class _Linear(torch.autograd.Function):
     the compute-dtype copy comes from the WeightCache."""
 
     @staticmethod
-    def forward(ctx, x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, kslice, res_div, tee, *weights):
+    def forward(ctx, x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, kslice, res_div, tee, res_pre,
+                *weights):
         L.require_gpu(x)
         assert x.dim() == 2 and x.stride(1) == 1
         W = cache.get(weights, x.dtype, 0 if kslice is not None else x.shape[1])
@@ -312,8 +313,9 @@ class _Linear(torch.autograd.Function):
             flags |= L.EPI_DROPOUT
         if residual is not None:
             assert residual.is_contiguous() and residual.shape[1] == N and residual.shape[0] * res_div == M
-            flags |= L.EPI_RESIDUAL
-        if relu and (residual is not None) and any(t.requires_grad for t in (x, *weights)):
+            flags |= L.EPI_RESIDUAL | (L.EPI_RES_PRE if res_pre else 0)
+        res_pre = bool(res_pre and residual is not None)
+        if relu and (residual is not None) and not res_pre and any(t.requires_grad for t in (x, *weights)):
             aux = torch.empty_like(y)   # post-dropout ReLU output: the backward's mask
             flags |= L.EPI_AUX
         if rowscale is not None:
@@ -332,8 +334,9 @@ class _Linear(torch.autograd.Function):
         ctx.weights = weights
         ctx.bias_param = bias
         ctx.bias2_param, ctx.bias_scale = bias2, bias_scale
-        ctx.kslice, ctx.res_div = kslice, res_div
+        ctx.kslice, ctx.res_div, ctx.res_pre = kslice, res_div, res_pre
         assert res_div == 1 or aux is None
+        assert not (res_pre and rowscale is not None)
         assert bias2 is None or (bias is not None and Np == N)
         if tee:   # second output = x itself: its other consumer's gradient arrives here and rides on the dX epilogue
             return y, x.view_as(x)
@@ -355,7 +358,7 @@ class _Linear(torch.autograd.Function):
         if rowscale is not None:
             dyb = dyb * rowscale[:, None].to(dyb.dtype)
         dres = dyb if has_res else None      # (has_res implies Np == N)
-        if has_res and ctx.res_div > 1:      # broadcast residual: its gradient is the sum over each row group
+        if has_res and ctx.res_div > 1 and not ctx.res_pre:      # broadcast residual: its gradient is the sum over each row group
             dres = dyb.view(M // ctx.res_div, ctx.res_div, Np).sum(1, dtype=torch.float32).to(dyb.dtype)
         Kp = x.shape[1]
         dt = L.dtype_code(dyb)
@@ -389,6 +392,10 @@ class _Linear(torch.autograd.Function):
                 L.check(lib.vmr_relu_bwd_bias(0, dyb.data_ptr(), None, None, db.data_ptr(), M, Np, Np, 1.0, dt, 0.0, 0,
                                               None, _ptr(db2), dbs, st), "vmr_relu_bwd_bias")
         dz = dzb[:, :N] if Np != N else dzb
+        if has_res and ctx.res_pre:          # the residual sat inside the activation: its gradient is dz, not dy
+            dres = dzb
+            if ctx.res_div > 1:
+                dres = dzb.view(M // ctx.res_div, ctx.res_div, Np).sum(1, dtype=torch.float32).to(dzb.dtype)
         dx = None
         if ctx.needs_input_grad[0]:
             few = mm_few_tiles(dz, W, 0, 1)
@@ -437,7 +444,7 @@ class _Linear(torch.autograd.Function):
             if db is not None and Np != N:
                 db = db[:N]
             return (dx, *_bias_grads(db, bgrad, has_b2, ctx.bias_scale), None, dres, None, None, None, None, None, None,
-                    None, *([None] * len(wshapes)))
+                    None, None, *([None] * len(wshapes)))
         if sk > 1:
             dW = torch.zeros(N, Kp, device=dy.device, dtype=torch.float32)
             gemm(dz, x, dW, N, Kp, M, 1, 1, dz.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_ACCUM, splitk=sk)
@@ -460,7 +467,7 @@ class _Linear(torch.autograd.Function):
         if db is not None and Np != N:
             db = db[:N]
         return (dx, *_bias_grads(db, bgrad, has_b2, ctx.bias_scale), None, dres, None, None, None, None, None, None,
-                None, *grads)
+                None, None, *grads)
 
 
 def _bias_grads(db, bgrad, has_b2, bias_scale):
@@ -471,14 +478,15 @@ def _bias_grads(db, bgrad, has_b2, bias_scale):
 
 
 def linear(x, weights, bias, cache, *, relu=False, drop=NO_DROP, residual=None, rowscale=None, bias2=None,
-           bias_scale=1.0, kslice=None, res_div=1, tee=False):
+           bias_scale=1.0, kslice=None, res_div=1, tee=False, res_pre=False):
     """y = drop(act(x.W[:, kslice]^T + bias_scale*bias + bias2)) + residual[row // res_div].
+    res_pre=True moves the residual inside the activation: y = drop(act(x.W^T + bias + residual)).
     tee=True returns (y, x): hand that x to the tensor's OTHER consumer, whose gradient then joins dX inside the
     backward GEMM's epilogue instead of through a separate autograd add pass."""
     if isinstance(weights, torch.Tensor):
         weights = [weights]
     return _Linear.apply(x, bias, bias2, bias_scale, residual, cache, relu, drop, rowscale, kslice, res_div, tee,
-                         *weights)
+                         res_pre, *weights)
 
 
 class _WeightedPool(torch.autograd.Function):
@@ -1435,3 +1443,118 @@ def dropout_mask(n: int, p: float, seed: int, device) -> torch.Tensor:
     m = torch.empty(n, device=device, dtype=torch.float32)
     L.check(L.lib().vmr_dropout_mask(m.data_ptr(), n, p, seed, L.stream_ptr()), "vmr_dropout_mask")
     return m
+
+
+# ---------------------------------------------------------------------------
+# BAN 2-D proposal map (csrc/map2d.hip)
+# ---------------------------------------------------------------------------
+class Map2dLayout:
+    """Cell layout of the reference's mask2d (models/BANlib/model.py:226-325): `grow[k]` = MaxPool1d kernel
+    size - 1 of pooler k; cells in `maskij` order (main diagonal, then one diagonal per pooler)."""
+
+    def __init__(self, N: int, pooling_counts=None, device=None):
+        if pooling_counts is None:                       # DenseMaxPool: every diagonal, MaxPool1d(2, 1) each
+            grow = [1] * (N - 1)
+        else:                                            # SparseMaxPool / SparseBoundaryCat
+            assert len(pooling_counts) <= 3, "the reference's 4th level (kernel 7, stride 8) does not run"
+            grow = []
+            for lvl, c in enumerate(pooling_counts):
+                grow += [1 if lvl == 0 else 2 * lvl] * c
+        self.N = N
+        self.grow_host = np.asarray(grow, dtype=np.int32)
+        off = np.cumsum(self.grow_host)
+        assert len(off) == 0 or off[-1] < N, "pooling_counts reach past the sequence"
+        ii, jj = [np.arange(N)], [np.arange(N)]
+        for o in off:
+            ii.append(np.arange(0, N - o)); jj.append(np.arange(o, N))
+        self.ii, self.jj = np.concatenate(ii), np.concatenate(jj)
+        self.C = int(self.ii.size)
+        cell_of = -np.ones((N, N), dtype=np.int32)
+        cell_of[self.ii, self.jj] = np.arange(self.C, dtype=np.int32)
+        self.mask2d_host = cell_of >= 0
+        self.device = None
+        if device is not None:
+            self.to(device)
+
+    def to(self, device):
+        if self.device != device:
+            self.grow = torch.from_numpy(self.grow_host).to(device)
+            cell_of = -np.ones((self.N, self.N), dtype=np.int32)
+            cell_of[self.ii, self.jj] = np.arange(self.C, dtype=np.int32)
+            self.cell_of = torch.from_numpy(cell_of).to(device)
+            self.mask2d = torch.from_numpy(self.mask2d_host).to(device)
+            self.ii_t = torch.from_numpy(self.ii).to(device)
+            self.jj_t = torch.from_numpy(self.jj).to(device)
+            self.device = device
+        return self
+
+
+class _Map2dPool(torch.autograd.Function):
+    """(M, R): M[b,c] = max of x[b, i_c..j_c]; R[b,c] = ps[b,i_c] + pe[b,j_c] (compact cells)."""
+
+    @staticmethod
+    def forward(ctx, x, ps, pe, layout):
+        L.require_gpu(x)
+        B, N, F = x.shape
+        assert N == layout.N
+        x = x.contiguous()
+        M = torch.empty(B, layout.C, F, device=x.device, dtype=x.dtype)
+        R = None
+        if ps is not None:
+            ps, pe = ps.contiguous(), pe.contiguous()
+            assert ps.shape == (B * N, F) and pe.shape == (B * N, F) and ps.dtype == x.dtype
+            R = torch.empty_like(M)
+        L.check(L.lib().vmr_map2d_pool_fwd(x.data_ptr(), _ptr(ps), _ptr(pe), F, layout.grow.data_ptr(),
+                                           layout.grow_host.ctypes.data, len(layout.grow_host), M.data_ptr(), _ptr(R), B, N,
+                                           F, L.dtype_code(x), L.stream_ptr()), "vmr_map2d_pool_fwd")
+        ctx.save_for_backward(x)
+        ctx.layout, ctx.has_p = layout, ps is not None
+        return (M, R) if R is not None else M
+
+    @staticmethod
+    def backward(ctx, dM, dR=None):
+        (x,) = ctx.saved_tensors
+        layout = ctx.layout
+        B, N, F = x.shape
+        dM = dM.contiguous()
+        dx = torch.empty_like(x)
+        dps = dpe = None
+        if ctx.has_p:
+            dR = dR.contiguous()
+            dps = torch.empty(B * N, F, device=x.device, dtype=x.dtype)
+            dpe = torch.empty_like(dps)
+        L.check(L.lib().vmr_map2d_pool_bwd(x.data_ptr(), dM.data_ptr(), _ptr(dR) if ctx.has_p else None,
+                                           layout.grow.data_ptr(), layout.grow_host.ctypes.data, len(layout.grow_host),
+                                           dx.data_ptr(), _ptr(dps), _ptr(dpe), F, B, N, F, L.dtype_code(x),
+                                           L.stream_ptr()), "vmr_map2d_pool_bwd")
+        return dx, dps, dpe, None
+
+
+def map2d_pool(x, ps, pe, layout: Map2dLayout):
+    return _Map2dPool.apply(x, ps, pe, layout)
+
+
+class _Map2dScatter(torch.autograd.Function):
+    """dense [B,N,N,W] from compact cells [B,C,W]; off-mask cells = fill[W] (a constant: no gradient)."""
+
+    @staticmethod
+    def forward(ctx, cells, fill, layout):
+        L.require_gpu(cells)
+        B, Cc, W = cells.shape
+        assert Cc == layout.C
+        cells = cells.contiguous()
+        fill = None if fill is None else fill.detach().float().contiguous()
+        out = torch.empty(B, layout.N, layout.N, W, device=cells.device, dtype=cells.dtype)
+        L.check(L.lib().vmr_map2d_scatter(cells.data_ptr(), layout.cell_of.data_ptr(), _ptr(fill), out.data_ptr(), B,
+                                          layout.N, W, Cc, L.dtype_code(cells), L.stream_ptr()), "vmr_map2d_scatter")
+        ctx.layout = layout
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lay = ctx.layout
+        return dout[:, lay.ii_t, lay.jj_t, :].contiguous(), None, None
+
+
+def map2d_scatter(cells, fill, layout: Map2dLayout):
+    return _Map2dScatter.apply(cells, fill, layout)
