@@ -50,6 +50,8 @@ gM, gR = torch.randn_like(M), torch.randn_like(R)
 tb = timeit(lambda: torch.autograd.grad([M, R], [xr, psr, per], [gM, gR], retain_graph=True), 20)
 bytb = (2 * B * C * F + 4 * B * N * F) * 2
 print(f"map2d_pool_bwd (+dp): {tb*1e6:.1f} us  {bytb/tb/1e12:.2f} TB/s  (algorithmic {bytb/1e6:.0f} MB)")
+if "--no-torch-prof" in sys.argv:
+    sys.exit(0)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     step(True); torch.cuda.synchronize()
