@@ -147,6 +147,29 @@ int vmr_dwconv_bwd2(const void* du, const void* x, const float* gamma, const flo
                     const float* mean, const float* rstd, const float* w, void* dn, float* dw,
                     float* workspace, int B1, int S1, int B2, int S2, int D, int dtype, void* stream);
 
+/* Deferred parameter-gradient reductions.  The LayerNorm / depthwise-conv backward kernels leave per-workgroup
+ * partial rows in `workspace`; the plain entry points reduce them at once (one small launch each, 38 per SeqPAN
+ * step), the *_deferred forms only report how many partial rows they wrote (*nblocks) and the caller reduces ALL of
+ * a backward pass's partials with ONE vmr_colreduce_batched launch before the optimizer reads the gradients
+ * (workspaces must stay alive, and distinct, until then).  Item for vmr_layernorm_bwd_deferred: {workspace, dgamma,
+ * dbeta, nblocks, D, D, slots = D <= 512 ? 512 : D <= 1024 ? 1024 : 2048}; for vmr_dwconv_bwd2_deferred:
+ * {workspace, dw, dw, nblocks, 7*D, 0, 0}.  out += sum (accumulating, like the plain forms). */
+typedef struct {
+  const float* part;
+  float* out0;
+  float* out1;
+  int32_t nblocks, n0, n1, slots;
+} vmr_colreduce_item_t;
+#define VMR_COLREDUCE_MAX_ITEMS 64   /* per launch (items travel as kernel arguments); longer lists are chunked */
+int vmr_layernorm_bwd_deferred(const void* dy, const void* x, const float* gamma, const float* mean,
+                               const float* rstd, const void* dres, void* dx, float* dpos, float* workspace,
+                               int S, int64_t rows, int D, int dtype, float drop_p, uint32_t drop_seed,
+                               const uint32_t* drop_step, int32_t* nblocks, void* stream);
+int vmr_dwconv_bwd2_deferred(const void* du, const void* x, const float* gamma, const float* beta,
+                             const float* mean, const float* rstd, const float* w, void* dn, float* workspace,
+                             int B1, int S1, int B2, int S2, int D, int dtype, int32_t* nblocks, void* stream);
+int vmr_colreduce_batched(const vmr_colreduce_item_t* items /* host array */, int n, void* stream);
+
 /* ----------------------------------------------------------- masked softmax
  * P[z,r,:] = softmax_c( scale*S[z,r,c] + term ) with dropout on P.
  *   mode 0 (DualMultiAttention, layers.py:346-357): z=(b,h);

@@ -170,7 +170,9 @@ def test_flat_arena_direct_accumulation_and_fused_adamw(dev):
                     continue
                 if float(p.grad.abs().max()) < 1e-5 * gmax_it:
                     continue   # analytically-zero gradient (softmax-shift terms such as w4Q): pure rounding noise
-                tol = 2e-3 * float(p.grad.abs().max()) + 1e-6
+                # it == 1: both models still hold identical weights; later the AdamW steps have turned fp32
+                # summation-order noise into +-lr weight differences, so the gradients are compared more loosely
+                tol = (2e-3 if it == 1 else 6e-3) * float(p.grad.abs().max()) + 2e-6
                 assert float((p.grad - q.grad * clip).abs().max()) <= tol, (it, n)
         topt.step(); fopt.step()
     gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)

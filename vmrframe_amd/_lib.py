@@ -27,6 +27,12 @@ EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_AUX, EPI_OUT_F32, EPI_ACCUM, 
     1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 
+class ColReduceItem(C.Structure):
+    """== vmr_colreduce_item_t"""
+    _fields_ = [("part", C.c_void_p), ("out0", C.c_void_p), ("out1", C.c_void_p), ("nblocks", C.c_int32),
+                ("n0", C.c_int32), ("n1", C.c_int32), ("slots", C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
                 ("bias", C.c_void_p), ("residual", C.c_void_p), ("aux", C.c_void_p),
@@ -54,6 +60,9 @@ SIGNATURES = {
     "vmr_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _U, _P, _P],
     "vmr_ln_dwconv_fwd": [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vmr_dwconv_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vmr_layernorm_bwd_deferred": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _U, _P, _P, _P],
+    "vmr_dwconv_bwd2_deferred": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "vmr_colreduce_batched": [_P, _I, _P],
     "vmr_ln_dwconv_fwd2": [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_dwconv_bwd2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_softmax_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _F, _U, _P, _P],

@@ -514,14 +514,15 @@ extern "C" int vmr_layernorm_fwd(const void* x, const float* gamma, const float*
   return 0;
 }
 
-extern "C" int vmr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                 const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                                 float* dpos, float* workspace, int S, int64_t rows, int D, int dtype, float drop_p,
-                                 uint32_t drop_seed, const uint32_t* drop_step, void* stream) {
+static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean,
+                       const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                       float* dpos, float* workspace, int S, int64_t rows, int D, int dtype, float drop_p,
+                       uint32_t drop_seed, const uint32_t* drop_step, void* stream, bool defer, int* nblocks) {
   if (int rc = ln_check(D)) return rc;
   VMR_CHECK(dy && x && gamma && mean && rstd && dx, "vmr_layernorm_bwd: null pointer");
   VMR_CHECK((dgamma == nullptr) == (dbeta == nullptr), "vmr_layernorm_bwd: dgamma/dbeta must come together");
-  VMR_CHECK(!dgamma || workspace, "vmr_layernorm_bwd: dgamma/dbeta need the workspace (VMR_LN_BWD_WS_FLOATS(rows, D))");
+  VMR_CHECK(!(dgamma || defer) || workspace, "vmr_layernorm_bwd: dgamma/dbeta need the workspace (VMR_LN_BWD_WS_FLOATS(rows, D))");
+  if (nblocks) *nblocks = 0;
   if (rows == 0) return 0;
   // persistent grid: at most g_lnb_grid workgroups (never more than ceil(rows/8): the workspace bound)
   static int g_lnb_grid = 0;
@@ -530,7 +531,8 @@ extern "C" int vmr_layernorm_bwd(const void* dy, const void* x, const float* gam
     g_lnb_grid = e && atoi(e) > 0 ? atoi(e) : 768;   // 3 resident workgroups x 256 CUs at D = 1024
   }
   const int grid = (int)min((int64_t)min(g_lnb_grid, VMR_LN_BWD_MAX_BLOCKS), (rows + LNB_ROWS - 1) / LNB_ROWS);
-  float* part = dgamma ? workspace : nullptr;
+  float* part = (dgamma || defer) ? workspace : nullptr;
+  if (nblocks) *nblocks = grid;
   const int maxc = D <= 512 ? 1 : (D <= 1024 ? 2 : 4);
   const int slots = maxc * 8 * 64;
   const size_t lds = (size_t)4 * 2 * slots * sizeof(float);
@@ -554,12 +556,29 @@ extern "C" int vmr_layernorm_bwd(const void* dy, const void* x, const float* gam
                          drop_seed, drop_step);
     VMR_LAUNCH_CHECK();
   }
-  if (part) {
+  if (part && !defer) {
     hipLaunchKernelGGL(colreduce_kernel, dim3(cdiv(2 * D, 256), cdiv(grid, 16)), dim3(256), 0, (hipStream_t)stream,
                        part, dgamma, dbeta, grid, D, D, slots);
     VMR_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int vmr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                 const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                 float* dpos, float* workspace, int S, int64_t rows, int D, int dtype, float drop_p,
+                                 uint32_t drop_seed, const uint32_t* drop_step, void* stream) {
+  return ln_bwd_impl(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dpos, workspace, S, rows, D, dtype, drop_p, drop_seed,
+                     drop_step, stream, false, nullptr);
+}
+
+extern "C" int vmr_layernorm_bwd_deferred(const void* dy, const void* x, const float* gamma, const float* mean,
+                                          const float* rstd, const void* dres, void* dx, float* dpos, float* workspace,
+                                          int S, int64_t rows, int D, int dtype, float drop_p, uint32_t drop_seed,
+                                          const uint32_t* drop_step, int32_t* nblocks, void* stream) {
+  VMR_CHECK(nblocks, "vmr_layernorm_bwd_deferred: null nblocks");
+  return ln_bwd_impl(dy, x, gamma, mean, rstd, dres, dx, nullptr, nullptr, dpos, workspace, S, rows, D, dtype, drop_p,
+                     drop_seed, drop_step, stream, true, nblocks);
 }
 
 // tile height for one sequence group: 16-row LDS tiles (10 output rows + halo): 32 KiB at D=1024 bf16
@@ -614,10 +633,12 @@ extern "C" int vmr_ln_dwconv_fwd(const void* x, const float* gamma, const float*
   return vmr_ln_dwconv_fwd2(x, gamma, beta, eps, w, u, mean, rstd, B, S, 0, 0, D, dtype, stream);
 }
 
-extern "C" int vmr_dwconv_bwd2(const void* du, const void* x, const float* gamma, const float* beta,
-                               const float* mean, const float* rstd, const float* w, void* dn, float* dw,
-                               float* workspace, int B1, int S1, int B2, int S2, int D, int dtype, void* stream) {
-  VMR_CHECK(du && x && gamma && beta && mean && rstd && w && dn && dw && workspace, "vmr_dwconv_bwd: null pointer");
+static int dwconv_bwd2_impl(const void* du, const void* x, const float* gamma, const float* beta,
+                            const float* mean, const float* rstd, const float* w, void* dn, float* dw,
+                            float* workspace, int B1, int S1, int B2, int S2, int D, int dtype, void* stream, bool defer,
+                            int* nblocks) {
+  VMR_CHECK(du && x && gamma && beta && mean && rstd && w && dn && (dw || defer) && workspace, "vmr_dwconv_bwd: null pointer");
+  if (nblocks) *nblocks = 0;
   VMR_CHECK(D % 2 == 0, "vmr_dwconv_bwd: D %% 2 != 0");
   VMR_CHECK(B1 >= 0 && S1 >= 0 && B2 >= 0 && S2 >= 0, "vmr_dwconv_bwd: negative shape");
   if (B1 == 0 || S1 == 0) { B1 = 0; S1 = S1 > 0 ? S1 : 1; }
@@ -637,9 +658,73 @@ extern "C" int vmr_dwconv_bwd2(const void* du, const void* x, const float* gamma
                        (const float*)du, (const float*)x, gamma, beta, mean, rstd, w, (float*)dn, workspace, S1, D,
                        slices, bps1, nb1, S2, bps2, rows1, prow1);
   VMR_LAUNCH_CHECK();
+  if (nblocks) *nblocks = prows;
+  if (defer) return 0;
   hipLaunchKernelGGL(colreduce_kernel, dim3(cdiv(D * 7, 256), cdiv(prows, 16)), dim3(256), 0, (hipStream_t)stream,
                      workspace, dw, dw, prows, D * 7, 0, 0);
   VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_dwconv_bwd2(const void* du, const void* x, const float* gamma, const float* beta,
+                               const float* mean, const float* rstd, const float* w, void* dn, float* dw,
+                               float* workspace, int B1, int S1, int B2, int S2, int D, int dtype, void* stream) {
+  return dwconv_bwd2_impl(du, x, gamma, beta, mean, rstd, w, dn, dw, workspace, B1, S1, B2, S2, D, dtype, stream, false, nullptr);
+}
+
+extern "C" int vmr_dwconv_bwd2_deferred(const void* du, const void* x, const float* gamma, const float* beta,
+                                        const float* mean, const float* rstd, const float* w, void* dn, float* workspace,
+                                        int B1, int S1, int B2, int S2, int D, int dtype, int32_t* nblocks, void* stream) {
+  VMR_CHECK(nblocks, "vmr_dwconv_bwd2_deferred: null nblocks");
+  return dwconv_bwd2_impl(du, x, gamma, beta, mean, rstd, w, dn, nullptr, workspace, B1, S1, B2, S2, D, dtype, stream, true, nblocks);
+}
+
+// ---- batched second stage: every deferred column reduction of a backward pass in ONE launch (blockIdx.z = item)
+struct ColItems {
+  vmr_colreduce_item_t it[VMR_COLREDUCE_MAX_ITEMS];
+};
+
+__global__ __launch_bounds__(256) void colreduce_batched_kernel(ColItems items) {
+  const vmr_colreduce_item_t& q = items.it[blockIdx.z];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int n = q.n0 + q.n1;
+  const int b0 = blockIdx.y * 16;
+  if (j >= n || b0 >= q.nblocks) return;
+  int64_t src = j, stride = n;
+  if (q.slots) {  // ln_bwd's permuted partial rows (see colreduce_kernel)
+    const int h = j >= q.n0, jj = h ? j - q.n0 : j;
+    const int e = jj & 7, cl = jj >> 3, lane = cl & 63, c = cl >> 6;
+    src = (int64_t)h * q.slots + (c * 8 + e) * 64 + lane;
+    stride = 2 * (int64_t)q.slots;
+  }
+  float v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = (b0 + k < q.nblocks) ? q.part[(int64_t)(b0 + k) * stride + src] : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += v[k];
+  atomicAdd(j < q.n0 ? &q.out0[j] : &q.out1[j - q.n0], s);
+}
+
+extern "C" int vmr_colreduce_batched(const vmr_colreduce_item_t* items, int n, void* stream) {
+  VMR_CHECK(items || n == 0, "vmr_colreduce_batched: null items");
+  for (int base = 0; base < n; base += VMR_COLREDUCE_MAX_ITEMS) {
+    const int cnt = min(VMR_COLREDUCE_MAX_ITEMS, n - base);
+    ColItems ci;
+    memset(&ci, 0, sizeof(ci));
+    int maxn = 0, maxb = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const vmr_colreduce_item_t& q = items[base + i];
+      VMR_CHECK(q.part && q.out0 && (q.out1 || q.n1 == 0) && q.nblocks >= 0 && q.n0 >= 0 && q.n1 >= 0,
+                "vmr_colreduce_batched: bad item %d", base + i);
+      ci.it[i] = q;
+      maxn = max(maxn, q.n0 + q.n1);
+      maxb = max(maxb, q.nblocks);
+    }
+    if (maxn == 0 || maxb == 0) continue;
+    hipLaunchKernelGGL(colreduce_batched_kernel, dim3(cdiv(maxn, 256), cdiv(maxb, 16), cnt), dim3(256), 0, (hipStream_t)stream, ci);
+    VMR_LAUNCH_CHECK();
+  }
   return 0;
 }
 

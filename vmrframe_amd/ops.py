@@ -164,6 +164,35 @@ def main_grad(p):
 
 
 # ---------------------------------------------------------------------------
+# deferred parameter-gradient reductions (LayerNorm gamma/beta, depthwise-conv weights)
+# ---------------------------------------------------------------------------
+DEFER_COLREDUCE = os.environ.get("VMR_DEFER_COLREDUCE", "1") != "0"
+_deferred: List[tuple] = []      # (partials tensor kept alive, out0, out1, nblocks, n0, n1, slots)
+
+
+def _defer_colreduce(part, out0, out1, nblocks, n0, n1, slots):
+    """Queue the second stage of a parameter-gradient reduction; all queued items of one backward pass run as ONE
+    launch when the autograd engine finishes the pass (queue_callback), i.e. before anything can read the arena."""
+    if not _deferred:
+        torch.autograd.Variable._execution_engine.queue_callback(flush_colreduce)
+    _deferred.append((part, out0, out1, int(nblocks), int(n0), int(n1), int(slots)))
+
+
+def flush_colreduce():
+    if not _deferred:
+        return
+    items = (L.ColReduceItem * len(_deferred))()
+    for it, (part, o0, o1, nb, n0, n1, sl) in zip(items, _deferred):
+        it.part, it.out0, it.out1 = part.data_ptr(), o0.data_ptr(), o1.data_ptr()
+        it.nblocks, it.n0, it.n1, it.slots = nb, n0, n1, sl
+    n = len(_deferred)
+    try:
+        L.check(L.lib().vmr_colreduce_batched(items, n, L.stream_ptr()), "vmr_colreduce_batched")
+    finally:
+        _deferred.clear()
+
+
+# ---------------------------------------------------------------------------
 # compute-dtype weight cache
 # ---------------------------------------------------------------------------
 class WeightCache:
@@ -813,6 +842,16 @@ class _LayerNorm(torch.autograd.Function):
         db = mb if direct else torch.zeros_like(dg)
         dpos = torch.zeros(pshape, device=x.device, dtype=torch.float32) if pshape else None
         ws = torch.empty(L.ln_bwd_ws_floats(rows, D), device=x.device, dtype=torch.float32)
+        if direct and DEFER_COLREDUCE:
+            # gradients accumulate into the arena: leave the partial rows in ws, reduce them with every other
+            # deferred reduction of this backward pass in one launch
+            nb = C.c_int32(0)
+            L.check(L.lib().vmr_layernorm_bwd_deferred(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                                       rstd.data_ptr(), _ptr(dres), dx.data_ptr(), _ptr(dpos), ws.data_ptr(),
+                                                       S, rows, D, L.dtype_code(x), drop[0], drop[1], _ptr(drop[2]),
+                                                       C.byref(nb), L.stream_ptr()), "vmr_layernorm_bwd_deferred")
+            _defer_colreduce(ws, dg, db, nb.value, D, D, 512 if D <= 512 else (1024 if D <= 1024 else 2048))
+            return dx, None, None, None, dpos, None, None, None, None
         L.check(L.lib().vmr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                           rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                           _ptr(dpos), ws.data_ptr(), S, rows, D, L.dtype_code(x), drop[0], drop[1],
@@ -870,6 +909,29 @@ class _LnDwConv(torch.autograd.Function):
         direct = mg is not None and mb is not None and mw is not None
         dw = mw if direct else torch.zeros(D, 7, device=x.device, dtype=torch.float32)
         r = 0
+        defer = direct and DEFER_COLREDUCE
+        dx = torch.empty_like(x)
+        dg = mg if direct else torch.zeros(D, device=x.device, dtype=torch.float32)
+        db = mb if direct else torch.zeros_like(dg)
+        if defer:
+            # partial rows of both kernels stay in their own workspaces until the end-of-backward batched reduction
+            nb = C.c_int32(0)
+            for i in range(0, len(segs), 2):
+                (B1, S1), (B2, S2) = segs[i], (segs[i + 1] if i + 1 < len(segs) else (0, 0))
+                wsc = torch.empty((B1 * ((S1 + 63) // 64) + B2 * ((S2 + 63) // 64)) * D * 7, device=x.device,
+                                  dtype=torch.float32)
+                L.check(lib.vmr_dwconv_bwd2_deferred(du[r:].data_ptr(), x[r:].data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                     mean[r:].data_ptr(), rstd[r:].data_ptr(), w2.data_ptr(),
+                                                     dn[r:].data_ptr(), wsc.data_ptr(), B1, S1, B2, S2, D, dt, C.byref(nb), st),
+                        "vmr_dwconv_bwd2_deferred")
+                _defer_colreduce(wsc, dw, dw, nb.value, 7 * D, 0, 0)
+                r += B1 * S1 + B2 * S2
+            wsl = torch.empty(L.ln_bwd_ws_floats(rows, D), device=x.device, dtype=torch.float32)
+            L.check(lib.vmr_layernorm_bwd_deferred(dn.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                                   rstd.data_ptr(), _ptr(dres), dx.data_ptr(), None, wsl.data_ptr(), 0, rows, D,
+                                                   dt, 0.0, 0, None, C.byref(nb), st), "vmr_layernorm_bwd_deferred")
+            _defer_colreduce(wsl, dg, db, nb.value, D, D, 512 if D <= 512 else (1024 if D <= 1024 else 2048))
+            return dx, None, None, None, None, None, None
         ws = torch.empty(max(sum(b * ((sq + 63) // 64) for b, sq in segs) * D * 7, L.ln_bwd_ws_floats(rows, D)),
                          device=x.device,
                          dtype=torch.float32)
@@ -879,9 +941,6 @@ class _LnDwConv(torch.autograd.Function):
                                         mean[r:].data_ptr(), rstd[r:].data_ptr(), w2.data_ptr(), dn[r:].data_ptr(),
                                         dw.data_ptr(), ws.data_ptr(), B1, S1, B2, S2, D, dt, st), "vmr_dwconv_bwd2")
             r += B1 * S1 + B2 * S2
-        dx = torch.empty_like(x)
-        dg = mg if direct else torch.zeros(D, device=x.device, dtype=torch.float32)
-        db = mb if direct else torch.zeros_like(dg)
         L.check(lib.vmr_layernorm_bwd(dn.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                       _ptr(dres), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, ws.data_ptr(), 0,
                                       rows, D, dt, 0.0, 0, None, st), "vmr_layernorm_bwd")
