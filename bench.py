@@ -26,6 +26,8 @@ import torch  # noqa: E402
 CFG2 = dict(B=64, T=128, L=20, D=1024, V=500, num_words=4002, num_chars=60, C=8, droprate=0.2)
 # BASELINE configs[3] ("next" row N1): BaseFast path, T=256, D=1024, V=1024 -- NOT the headline metric
 CFG4 = dict(B=64, T=256, L=20, D=1024, V=1024, num_words=4002, num_chars=60, C=8, droprate=0.2)
+# BASELINE configs[4] ("next" row N2, first slice): the BAN 2-D proposal-map stage alone -- NOT the headline metric
+CFG5 = dict(B=64, N=128, F=512, Cd=128, pooling=[31, 16, 16], min_iou=0.5, max_iou=1.0)
 TRAIN_GFLOP_PER_CLIP = 58.0      # 19.34 GFLOP fwd (FlopCounter on the reference) x 3
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
@@ -120,8 +122,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of whole-step hipGraph replay")
-    ap.add_argument("--workload", default="seqpan", choices=["seqpan", "basefast"],
-                    help="seqpan = BASELINE configs[1] (headline); basefast = configs[3] (T=256)")
+    ap.add_argument("--workload", default="seqpan", choices=["seqpan", "basefast", "banmap"],
+                    help="seqpan = BASELINE configs[1] (headline); basefast = configs[3] (T=256); banmap = the BAN "
+                         "proposal-map stage of configs[4]")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,24 +144,40 @@ def main():
         dp.init_process_group_from_env(os.environ.get("VMR_DIST_BACKEND", "nccl"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
-    a = CFG2 if args.workload == "seqpan" else CFG4
-    Model, engine = (V.SeqPAN, V.train_engine_SeqPAN) if args.workload == "seqpan" else \
-        (V.BaseFast, V.train_engine_BaseFast)
-    torch.manual_seed(1234)                      # reference main.py:41
-    cfg = make_cfg(a, args.dtype)
-    cfg.device = dev
-    rng = np.random.default_rng(1234)
-    glove = rng.standard_normal((a["num_words"] - 2, 300)).astype(np.float32)
-    model = Model(cfg, glove).to(dev)
-    model.sync_timing = False                    # the reference's in-forward wall-clock syncs are instrumentation
-    model.base_seed = 1234 + rank                # per-rank dropout / Gumbel streams
-    torch.manual_seed(1234 + rank)
+    if args.workload == "banmap":
+        from oracle import seqpan_ref as R   # (attribute-dict helper only)
+        a = CFG5
+        engine = V.train_engine_ProposalMap2D
+        torch.manual_seed(1234)
+        cfg = R.Cfg(device=dev, dense_outputs=True, loss=R.Cfg(min_iou=a["min_iou"], max_iou=a["max_iou"]))
+        model = V.ProposalMap2D(a["F"], a["Cd"], a["N"], a["pooling"]).to(dev)
+        model.base_seed = 1234 + rank
+        torch.manual_seed(1234 + rank)
+    else:
+        a = CFG2 if args.workload == "seqpan" else CFG4
+        Model, engine = (V.SeqPAN, V.train_engine_SeqPAN) if args.workload == "seqpan" else \
+            (V.BaseFast, V.train_engine_BaseFast)
+        torch.manual_seed(1234)                      # reference main.py:41
+        cfg = make_cfg(a, args.dtype)
+        cfg.device = dev
+        rng = np.random.default_rng(1234)
+        glove = rng.standard_normal((a["num_words"] - 2, 300)).astype(np.float32)
+        model = Model(cfg, glove).to(dev)
+        model.sync_timing = False                    # the reference's in-forward wall-clock syncs are instrumentation
+        model.base_seed = 1234 + rank                # per-rank dropout / Gumbel streams
+        torch.manual_seed(1234 + rank)
     dp.broadcast_parameters(model)
     total_steps = args.steps + args.warmup
     opt = FlatAdamW(model, lr=1e-4, weight_decay=0.01, max_norm=1.0, warmup_steps=0.0 * total_steps,
                     total_steps=10 * total_steps)
     reducer = dp.GradReducer(model, opt, use_hooks=args.no_graph)
-    batch = {k: v.to(dev) for k, v in synth(a, 1234 + rank).items()}   # weak scaling: 64 clips per GPU
+    if args.workload == "banmap":
+        gen = torch.Generator().manual_seed(1234 + rank)
+        batch = {"hidden_b": torch.relu(torch.randn(a["B"], a["N"], a["F"], generator=gen)).to(dev),   # post-ReLU features
+                 "fuse_feature": torch.tanh(torch.randn(a["B"], a["N"], a["F"], generator=gen)).to(dev),  # LSTM-range
+                 "iou2ds": torch.rand(a["B"], a["N"], a["N"], generator=gen).to(dev)}
+    else:
+        batch = {k: v.to(dev) for k, v in synth(a, 1234 + rank).items()}   # weak scaling: 64 clips per GPU
     model.train()
 
     def eager_step():
@@ -225,7 +244,7 @@ def main():
         gs = timer.summary()
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "seqpan":   # the PMC passes were taken on the headline workload
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -239,16 +258,22 @@ def main():
                         "launches_per_step": gs["launches"] / timed_steps_for_hook, "avg_launch_us": round(gs["avg_us"], 2),
                         "flops_per_launch": gs["flops_per_launch"],
                         "algorithmic_bytes_per_launch": gs["bytes_per_launch"]}   # A + W + C in bf16 (no epilogue operands)
-        out = {"metric": "clips/sec (train step) at BxT=64x128, D=1024" if args.workload == "seqpan"
-               else "clips/sec (train step), BaseFast at BxT=64x256, D=1024", "value": round(value, 2),
+        metric = {"seqpan": "clips/sec (train step) at BxT=64x128, D=1024",
+                  "basefast": "clips/sec (train step), BaseFast at BxT=64x256, D=1024",
+                  "banmap": "clips/sec (train step), BAN proposal-map stage at N=128, F=512"}[args.workload]
+        wl = {"seqpan": ("SeqPAN anet/C3D synthetic features (configs[1]): B=64 clips/GPU, T=128, "
+                         "L=20, D=1024, V=500, droprate 0.2; full train step "
+                         "(fwd+losses+bwd+allreduce+clip+AdamW+schedule)"),
+              "basefast": ("BaseFast path (configs[3], next-row N1): B=64 clips/GPU, T=256, L=20, D=1024, "
+                           "V=1024, droprate 0.2; full train step"),
+              "banmap": ("BAN 2-D proposal-map stage (configs[4], next-row N2 first slice; models/BAN.py:87-99 + loss_bce): "
+                         "B=64 clips/GPU, N=128, fuse_dim 512, contrast 128, pooling_counts [31,16,16], bf16, dropout 0.1, "
+                         "dense tmap / map2d_proj outputs; fwd+loss+bwd+clip+AdamW")}[args.workload]
+        out = {"metric": metric, "value": round(value, 2),
                "unit": "clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": ("SeqPAN anet/C3D synthetic features (configs[1]): B=64 clips/GPU, T=128, "
-                                       "L=20, D=1024, V=500, droprate 0.2; full train step "
-                                       "(fwd+losses+bwd+allreduce+clip+AdamW+schedule)") if args.workload == "seqpan"
-                          else ("BaseFast path (configs[3], next-row N1): B=64 clips/GPU, T=256, L=20, D=1024, "
-                                "V=1024, droprate 0.2; full train step"),
+               "config": {"workload": wl,
                           "global_batch": a["B"] * world, "parallelism": f"dp{world}"},
                "step_mfma_frac": round(value * TRAIN_GFLOP_PER_CLIP * 1e9 / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
                "final_loss": round(final_loss, 4), "hipgraph": not args.no_graph,

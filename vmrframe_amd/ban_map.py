@@ -117,6 +117,17 @@ def bce_map_loss(tmap_cells: torch.Tensor, iou2d: torch.Tensor, layout: ops.Map2
     return torch.nn.functional.binary_cross_entropy_with_logits(tmap_cells.float(), tgt.float())
 
 
+def train_engine_ProposalMap2D(model: "ProposalMap2D", data, configs, runtype="train"):
+    """The stage's share of reference models/BAN.py:208-219 (`train_engine_BAN`): forward + loss_bce, same
+    (model, batch, configs, runtype) -> (loss, output) shape as the other engines.  data: `hidden_b`, `fuse_feature`
+    [B,N,F] (what BAN's encoders hand to the stage) and `iou2ds` [B,N,N]."""
+    data = {k: v.to(configs.device) for k, v in data.items()}
+    out = model(data["hidden_b"], data["fuse_feature"], dense_outputs=bool(configs.get("dense_outputs", True)) if isinstance(configs, dict)
+                else bool(getattr(configs, "dense_outputs", True)))
+    loss = bce_map_loss(out["tmap_cells"], data["iou2ds"], model.layout, configs.loss.min_iou, configs.loss.max_iou)
+    return loss, out
+
+
 def infer_tmap(tmap: torch.Tensor, video_seq_len: torch.Tensor):
     """infer_BAN (reference models/BAN.py:303-316): arg-max row / column of the upper-triangular score map."""
     outer = torch.triu(tmap, diagonal=0)
