@@ -64,6 +64,25 @@ __device__ __forceinline__ TileCoord tile_coord(const vmr_gemm_t& g, int tiles_m
   return t;
 }
 
+// Column owned by lane quad q = lane >> 4 in MFMA tile j of the wave's 64-column slab.  PERM (the weight operand
+// is row-major, W [N][K]: the x.W^T products): the LDS-DMA source rows of W are permuted (perm_row128 below) so that
+// tile j, MFMA row r holds weight row (j>>1)*32 + (r>>2)*8 + (j&1)*4 + (r&3): a lane's 4 values of tiles 2k and
+// 2k+1 are then 8 CONSECUTIVE columns, and C / aux / residual move as 16-byte accesses (half the epilogue's
+// memory instructions; the 4 lanes of a row cover a 64-byte segment per instruction).
+template <bool PERM>
+__device__ __forceinline__ int quad_col(int j, int q) {
+  return PERM ? ((j >> 1) * 32 + q * 8 + (j & 1) * 4) : (j * 16 + q * 4);
+}
+__device__ __forceinline__ int perm_row128(int rho) {   // LDS row of the [128][BK] weight tile -> weight row
+  const int j = (rho >> 4) & 3, r = rho & 15;
+  return (rho & 64) | ((j >> 1) << 5) | ((r >> 2) << 3) | ((j & 1) << 2) | (r & 3);
+}
+
+// residual values of the lane, as loaded: 8 bytes per (i, j) quad; with PERM quads 2k and 2k+1 came as one 16-byte load
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+
 // swizzle of the [k][128] (M/N-contiguous) bf16 image: 32-B chunk index ^= f(k)
 __device__ __forceinline__ int swz_tr(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
@@ -180,7 +199,7 @@ __device__ __forceinline__ void epilogue_half(const vmr_gemm_t& g, const float* 
 }
 
 // caller has passed the barrier that ends the K loop
-template <typename T, bool ALIGNED, bool FULL = false, bool TRANSPOSED = false>
+template <typename T, bool ALIGNED, bool FULL = false, bool TRANSPOSED = false, bool PERM = false>
 __device__ __forceinline__ void epilogue(const vmr_gemm_t& g, float* cst, const f32x4 (&acc)[4][4], int wm, int wn,
                                          int lane, int m0, int n0, int zb, T* __restrict__ C,
                                          const T* __restrict__ Rsd, T* __restrict__ Aux) {
@@ -190,8 +209,9 @@ __device__ __forceinline__ void epilogue(const vmr_gemm_t& g, float* cst, const 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (TRANSPOSED) {   // acc[i][j][r] = C[i*16 + (lane&15)][j*16 + (lane>>4)*4 + r]: one 16-byte LDS write
-          *reinterpret_cast<f32x4*>(&cst[(wm * 64 + i * 16 + (lane & 15)) * CST_LD + wn * 64 + j * 16 + (lane >> 4) * 4]) =
-              acc[i][j];
+          // (PERM: the weight rows were permuted on their way into LDS, see quad_col in the register-direct epilogue)
+          const int cq = PERM ? ((j >> 1) * 32 + (lane >> 4) * 8 + (j & 1) * 4) : (j * 16 + (lane >> 4) * 4);
+          *reinterpret_cast<f32x4*>(&cst[(wm * 64 + i * 16 + (lane & 15)) * CST_LD + wn * 64 + cq]) = acc[i][j];
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -403,13 +423,14 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 
 // one operand tile (128 rows x BK, or BK x 128 for the transposed image) = 128*BK*2 bytes = NB 1-KiB blocks
 // (ROWS = 160 for the 160-row A tile of the ragged-M variant: rows past rmax re-read row rmax)
-template <bool KC, int BK, int ROWS = 128, int NW = 4>
+template <bool KC, int BK, int ROWS = 128, int NW = 4, bool PERM = false>
 __device__ __forceinline__ void dma_operand(const bf16_t* __restrict__ P, int64_t ld, int r0, int k0,
                                             unsigned char* lds, int wid, int lane, int rmax = 0x7fffffff) {
   constexpr int NB = ROWS * BK * 2 / 1024;  // 8 (BK=32) or 16 (BK=64) blocks per 128 rows, NB/NW per wave
   static_assert(NB % NW == 0, "operand blocks must divide over the waves");
   static_assert(ROWS == 128 || BK == 64, "tall / wide tiles: BK=64 images only");
   static_assert(KC || ROWS % 128 == 0, "transposed image: whole [BK][128] images");
+  static_assert(!PERM || (KC && BK == 64 && ROWS == 128), "row permutation: the k-contiguous 128-row weight tile");
 #pragma unroll
   for (int jj = 0; jj < NB / NW; ++jj) {
     const int j = wid * (NB / NW) + jj;
@@ -418,7 +439,8 @@ __device__ __forceinline__ void dma_operand(const bf16_t* __restrict__ P, int64_
       if (BK == 64) {       // 128-B rows: one wave-instruction = 8 whole rows = 8 full cache lines
         const int row = 8 * j + (lane >> 3);
         const int c = (lane & 7) ^ (row & 7);
-        src = P + (int64_t)min(r0 + row, rmax) * ld + k0 + c * 8;
+        const int grow = PERM ? perm_row128(row) : row;   // (weight tile of the x.W^T products: see quad_col)
+        src = P + (int64_t)min(r0 + grow, rmax) * ld + k0 + c * 8;
       } else {              // 64-B rows
         const int row = 16 * j + (lane >> 2);
         const int c = (lane & 3) ^ swz_kc32(row);
@@ -450,21 +472,22 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // bias / residual / aux / C move as 8-byte accesses straight from the accumulators -- no LDS staging,
 // no workgroup barrier (a wave's stores overlap the other waves' and the co-resident workgroup's
 // MFMAs), and one dropout hash serves exactly the lane's 4 elements.
-template <int MT>
+template <int MT, bool PERM>
 __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4 (&acc)[MT][4], int wm, int wn, int lane,
                                                 int m0, int n0, int zb, bf16_t* __restrict__ C,
-                                                const bf16x4 (&rres)[MT][4], bf16_t* __restrict__ Aux) {
+                                                const u32x2 (&rres)[MT][4], bf16_t* __restrict__ Aux) {
   const int flags = g.flags;
   const int rbase = m0 + wm * (MT * 16) + (lane & 15);
-  const int cbase = n0 + wn * 64 + (lane >> 4) * 4;
+  const int q = lane >> 4;
+  const int cw = n0 + wn * 64;
   f32x4 bias4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
   {
     bias4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (flags & VMR_EPI_BIAS) {
-      bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + cbase + j * 16) * g.bias_scale;
-      if (g.bias2) bias4[j] += *reinterpret_cast<const f32x4*>(g.bias2 + cbase + j * 16);
+      bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + cw + quad_col<PERM>(j, q)) * g.bias_scale;
+      if (g.bias2) bias4[j] += *reinterpret_cast<const f32x4*>(g.bias2 + cw + quad_col<PERM>(j, q));
     }
   }
   const uint32_t thresh = vmr_drop_thresh(g.drop_p);
@@ -475,14 +498,16 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
     const int gm = rbase + i * 16;
     if (MT != 4 && gm >= g.M) continue;   // ragged last tile of the 160-row variant
     const float rs = (flags & VMR_EPI_ROWSCALE) ? g.rowscale[gm] : 1.0f;
+    float out[4][4], ax[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int gn = cbase + j * 16;
+      const int gn = cw + quad_col<PERM>(j, q);
+      const float r4[4] = {bf16_lo(rres[i][j][0]), bf16_hi(rres[i][j][0]), bf16_lo(rres[i][j][1]), bf16_hi(rres[i][j][1])};
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float x = acc[i][j][e] * g.alpha + bias4[j][e];
-        if (flags & VMR_EPI_RES_PRE) x += (float)rres[i][j][e];
+        if (flags & VMR_EPI_RES_PRE) x += r4[e];
         if (flags & VMR_EPI_RELU) x = fmaxf(x, 0.0f);
         v[e] = x;
       }
@@ -494,19 +519,44 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
         v[2] = (h.y & 0xFFFFu) >= thresh ? v[2] * dscale : 0.f;
         v[3] = (h.y >> 16) >= thresh ? v[3] * dscale : 0.f;
       }
-      if (flags & VMR_EPI_AUX) Vec4<bf16_t>::store(Aux + (int64_t)gm * g.ldr + gn, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ax[j][e] = v[e];
       if ((flags & VMR_EPI_RESIDUAL) && !(flags & VMR_EPI_RES_PRE)) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)rres[i][j][e];
+        for (int e = 0; e < 4; ++e) v[e] += r4[e];
       }
       if (flags & VMR_EPI_ROWSCALE) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= rs;
       }
-      if (flags & VMR_EPI_OUT_F32)   // fp32 result / split-K slab: one 16-byte store per quad
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (int64_t)gm * g.ldc + gn) = (f32x4){v[0], v[1], v[2], v[3]};
-      else
-        Vec4<bf16_t>::store(C + (int64_t)gm * g.ldc + gn, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[j][e] = v[e];
+    }
+    if (flags & VMR_EPI_OUT_F32) {   // fp32 result / split-K slab: one 16-byte store per quad
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (int64_t)gm * g.ldc + cw + quad_col<PERM>(j, q)) =
+            (f32x4){out[j][0], out[j][1], out[j][2], out[j][3]};
+    } else if (PERM) {               // quads 2k, 2k+1 are 8 consecutive columns: 16-byte stores
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int gn = cw + quad_col<PERM>(2 * k, q);
+        const float o8[8] = {out[2 * k][0], out[2 * k][1], out[2 * k][2], out[2 * k][3],
+                             out[2 * k + 1][0], out[2 * k + 1][1], out[2 * k + 1][2], out[2 * k + 1][3]};
+        Vec8<bf16_t>::store(C + (int64_t)gm * g.ldc + gn, o8);
+        if (flags & VMR_EPI_AUX) {
+          const float a8[8] = {ax[2 * k][0], ax[2 * k][1], ax[2 * k][2], ax[2 * k][3],
+                               ax[2 * k + 1][0], ax[2 * k + 1][1], ax[2 * k + 1][2], ax[2 * k + 1][3]};
+          Vec8<bf16_t>::store(Aux + (int64_t)gm * g.ldr + gn, a8);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gn = cw + quad_col<PERM>(j, q);
+        Vec4<bf16_t>::store(C + (int64_t)gm * g.ldc + gn, out[j]);
+        if (flags & VMR_EPI_AUX) Vec4<bf16_t>::store(Aux + (int64_t)gm * g.ldr + gn, ax[j]);
+      }
     }
   }
 }
@@ -553,24 +603,35 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_bf16_dma_ker
   // The residual quads of the register-direct epilogue are requested FIRST (oldest in the vmcnt
   // order, so every counted wait below also covers them): their HBM latency hides under the whole
   // K loop instead of being exposed once per tile.
-  bf16x4 rres[MT][4];
+  // weight operand row-major and BK = 64: its LDS rows are permuted so the epilogue moves 16 bytes per lane (quad_col)
+  constexpr bool PERM = !TB && BK == 64;
+  u32x2 rres[MT][4];
   const bool direct = MT != 4 || WM != 2 || !(g.flags & VMR_EPI_ACCUM);   // atomics keep the LDS-staged, 256-B-per-wave shape
   if (direct && (g.flags & VMR_EPI_RESIDUAL)) {
     const bf16_t* Rsd = reinterpret_cast<const bf16_t*>(g.residual) + coff;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+      const bf16_t* rrow = Rsd + (int64_t)(min(m0 + wm * (MT * 16) + (lane & 15) + i * 16, g.M - 1) / g.res_div) * g.ldr +
+                           n0 + wn * 64;
+      if constexpr (PERM) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        rres[i][j] = *reinterpret_cast<const bf16x4*>(
-            Rsd + (int64_t)(min(m0 + wm * (MT * 16) + (lane & 15) + i * 16, g.M - 1) / g.res_div) * g.ldr + n0 + wn * 64 +
-            (lane >> 4) * 4 + j * 16);
+        for (int k = 0; k < 2; ++k) {
+          const uint4 w = *reinterpret_cast<const uint4*>(rrow + quad_col<true>(2 * k, lane >> 4));
+          rres[i][2 * k] = (u32x2){w.x, w.y};
+          rres[i][2 * k + 1] = (u32x2){w.z, w.w};
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rres[i][j] = *reinterpret_cast<const u32x2*>(rrow + quad_col<false>(j, lane >> 4));
+      }
+    }
   }
 
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) {
     if (s < nk) {
       dma_operand<!TA, BK, TBM, NW>(A, g.lda, m0, k_begin + s * BK, smem + s * (OPA + OPB), wid, lane, g.M - 1);
-      dma_operand<!TB, BK, 128, NW>(B, g.ldb, n0, k_begin + s * BK, smem + s * (OPA + OPB) + OPA, wid, lane);
+      dma_operand<!TB, BK, 128, NW, PERM>(B, g.ldb, n0, k_begin + s * BK, smem + s * (OPA + OPB) + OPA, wid, lane);
     }
   }
   // Software-pipelined fragment reads: the ds_reads of the next 32-deep k-substep are in flight while
@@ -616,7 +677,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_bf16_dma_ker
       unsigned char* dst = smem + ((kt + NST - 1) % NST) * (OPA + OPB);
       const int k0 = k_begin + (kt + NST - 1) * BK;
       dma_operand<!TA, BK, TBM, NW>(A, g.lda, m0, k0, dst, wid, lane, g.M - 1);
-      dma_operand<!TB, BK, 128, NW>(B, g.ldb, n0, k0, dst + OPA, wid, lane);
+      dma_operand<!TB, BK, 128, NW, PERM>(B, g.ldb, n0, k0, dst + OPA, wid, lane);
     }
     const unsigned char* cur = smem + (kt % NST) * (OPA + OPB);
 #pragma unroll
@@ -639,7 +700,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_bf16_dma_ker
     }
   }
   if (direct) {
-    epilogue_direct<MT>(g, acc, wm, wn, lane, m0, n0, tc.zb,
+    epilogue_direct<MT, PERM>(g, acc, wm, wn, lane, m0, n0, tc.zb,
                     (g.flags & VMR_EPI_OUT_F32) ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
                                                 : reinterpret_cast<bf16_t*>(g.C) + coff,
                     rres, reinterpret_cast<bf16_t*>(g.aux) + coff);
@@ -647,7 +708,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_bf16_dma_ker
   }
   if constexpr (MT == 4 && WM == 2) {
   __syncthreads();
-  epilogue<bf16_t, true, true, true>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
+  epilogue<bf16_t, true, true, true, PERM>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
                          (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM))
                              ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
                              : reinterpret_cast<bf16_t*>(g.C) + coff,
