@@ -147,6 +147,17 @@ int vmr_dwconv_bwd2(const void* du, const void* x, const float* gamma, const flo
                     const float* mean, const float* rstd, const float* w, void* dn, float* dw,
                     float* workspace, int B1, int S1, int B2, int S2, int D, int dtype, void* stream);
 
+/* Batched bf16 transpose: dst[c*rows + r] = src[r*cols + c] for every item, one launch per 64 items (the list
+ * travels as kernel arguments).  The optimizer keeps a K-major copy of every weight matrix this way, so the input-
+ * gradient products dX = dY.W (backward of Conv1D, models/layers.py:15-26) run as row-major-weight products. */
+typedef struct {
+  const void* src;
+  void* dst;
+  int32_t rows, cols;
+} vmr_transpose_item_t;
+#define VMR_TRANSPOSE_MAX_ITEMS 64
+int vmr_transpose_batched(const vmr_transpose_item_t* items /* host array */, int n, void* stream);
+
 /* Deferred parameter-gradient reductions.  The LayerNorm / depthwise-conv backward kernels leave per-workgroup
  * partial rows in `workspace`; the plain entry points reduce them at once (one small launch each, 38 per SeqPAN
  * step), the *_deferred forms only report how many partial rows they wrote (*nblocks) and the caller reduces ALL of

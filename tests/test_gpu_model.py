@@ -204,3 +204,44 @@ def test_basefast_fp32_vs_golden(dev, name):
         mine = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
         assert abs(mine - float(z["gnorm"])) < 3e-3 * float(z["gnorm"])
     assert model.P("dual_attention_block_2.dense_2.conv1d.weight").grad is None
+
+
+def test_bf16_input_gradients_on_k_major_weight_copies(dev):
+    """bf16 + flat arena: the optimizer keeps a K-major (transposed) copy of every weight matrix (one batched
+    transpose per step) and the dX products read it instead of the transposed-read layout.  Two models stepped in
+    lockstep, one with the copies and one without, must stay within bf16 noise of each other; the copies themselves
+    must equal the transposed bf16 mirrors exactly."""
+    import vmrframe_amd as V
+    from vmrframe_amd import ops
+    from vmrframe_amd.optim import FlatAdamW
+    z, cfg, batch, g, weights = load_golden("g_small")
+    cfg.device = dev
+
+    def fresh():
+        m = build(cfg, weights, "bf16", dev)
+        m.gumbel_override = g.to(dev)
+        m.eval()
+        return m
+    ma, mb = fresh(), fresh()
+    oa, ob = FlatAdamW(ma, lr=1e-3, max_norm=1.0), FlatAdamW(mb, lr=1e-3, max_norm=1.0)
+    try:
+        for it in range(3):
+            for m, o, use in ((ma, oa, True), (mb, ob, False)):
+                ops.USE_WT = use
+                loss, _ = V.train_engine_SeqPAN(m, batch, cfg, "train")
+                o.zero_grad(); loss.backward(); o.step()
+            if it == 0:
+                continue
+            n_views = 0
+            for p in ma.parameters():
+                for key, view in (getattr(p, "_vmr_wt_views", None) or {}).items():
+                    rows, cols = view.shape[1], view.shape[0]
+                    src = oa.arena.flat_w[oa.arena.offsets[[n for n, q in ma.named_parameters() if q is p][0]]:][:rows * cols]
+                    assert torch.equal(view, src.view(rows, cols).t()), "K-major copy != transposed bf16 mirror"
+                    n_views += 1
+            assert n_views > 20
+            ga, gb = oa.arena.flat_g, ob.arena.flat_g
+            rel = float((ga - gb).norm() / gb.norm())
+            assert rel < 2e-2, (it, rel)
+    finally:
+        ops.USE_WT = True

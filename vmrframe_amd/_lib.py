@@ -33,6 +33,11 @@ class ColReduceItem(C.Structure):
                 ("n0", C.c_int32), ("n1", C.c_int32), ("slots", C.c_int32)]
 
 
+class TransposeItem(C.Structure):
+    """== vmr_transpose_item_t"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
                 ("bias", C.c_void_p), ("residual", C.c_void_p), ("aux", C.c_void_p),
@@ -63,6 +68,7 @@ SIGNATURES = {
     "vmr_layernorm_bwd_deferred": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _U, _P, _P, _P],
     "vmr_dwconv_bwd2_deferred": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "vmr_colreduce_batched": [_P, _I, _P],
+    "vmr_transpose_batched": [_P, _I, _P],
     "vmr_ln_dwconv_fwd2": [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_dwconv_bwd2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_softmax_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _F, _U, _P, _P],

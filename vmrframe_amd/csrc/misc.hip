@@ -291,6 +291,56 @@ int launch_cast(const void* src, void* dst, int dst_dtype, int64_t rows, int col
 
 }  // namespace
 
+// ---- batched bf16 transpose: dst[c][r] = src[r][c] for every item of the list in one launch (blockIdx.z = item).
+// Keeps a K-major copy of every weight matrix next to its bf16 mirror, so the dX = dz.W products run as x.W'^T with
+// the row-major-weight kernel (k-contiguous fragment reads, 16-byte epilogue) instead of the transposed-read layout.
+struct TransItems {
+  vmr_transpose_item_t it[VMR_TRANSPOSE_MAX_ITEMS];
+};
+
+__global__ __launch_bounds__(256) void transpose_batched_kernel(TransItems items) {
+  __shared__ unsigned short tile[64][66];
+  const vmr_transpose_item_t& q = items.it[blockIdx.z];
+  const int tr = (q.rows + 63) / 64, tc = (q.cols + 63) / 64;
+  const unsigned short* src = reinterpret_cast<const unsigned short*>(q.src);
+  unsigned short* dst = reinterpret_cast<unsigned short*>(q.dst);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+    const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int r = r0 + ty + 4 * k, c = c0 + tx;
+      tile[ty + 4 * k][tx] = (r < q.rows && c < q.cols) ? src[(int64_t)r * q.cols + c] : (unsigned short)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int c = c0 + ty + 4 * k, r = r0 + tx;
+      if (r < q.rows && c < q.cols) dst[(int64_t)c * q.rows + r] = tile[tx][ty + 4 * k];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int vmr_transpose_batched(const vmr_transpose_item_t* items, int n, void* stream) {
+  VMR_CHECK(items || n == 0, "vmr_transpose_batched: null items");
+  for (int base = 0; base < n; base += VMR_TRANSPOSE_MAX_ITEMS) {
+    const int cnt = min(VMR_TRANSPOSE_MAX_ITEMS, n - base);
+    TransItems ti;
+    memset(&ti, 0, sizeof(ti));
+    int64_t maxt = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const vmr_transpose_item_t& q = items[base + i];
+      VMR_CHECK(q.src && q.dst && q.rows > 0 && q.cols > 0, "vmr_transpose_batched: bad item %d", base + i);
+      ti.it[i] = q;
+      maxt = max(maxt, (int64_t)((q.rows + 63) / 64) * ((q.cols + 63) / 64));
+    }
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3((unsigned)min(maxt, (int64_t)1024), 1, cnt), dim3(256), 0, (hipStream_t)stream, ti);
+    VMR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 extern "C" int vmr_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t rows, int cols,
                         int64_t ld_src, int64_t ld_dst, float drop_p, uint32_t drop_seed,
                         const uint32_t* drop_step, void* stream) {

@@ -167,6 +167,7 @@ def main_grad(p):
 # deferred parameter-gradient reductions (LayerNorm gamma/beta, depthwise-conv weights)
 # ---------------------------------------------------------------------------
 DEFER_COLREDUCE = os.environ.get("VMR_DEFER_COLREDUCE", "1") != "0"
+USE_WT = os.environ.get("VMR_USE_WT", "1") != "0"     # dX products on the K-major weight copies
 _deferred: List[tuple] = []      # (partials tensor kept alive, out0, out1, nblocks, n0, n1, slots)
 
 
@@ -208,6 +209,14 @@ class WeightCache:
         """Forget the cast copies (the masters changed); mirror-backed entries stay valid because
         the optimizer kernel rewrites the mirror in place."""
         self.store = {k: v for k, v in self.store.items() if getattr(v[1], "_vmr_mirror", False)}
+
+    @staticmethod
+    def get_t(params: Sequence[torch.Tensor], dtype: torch.dtype) -> Optional[torch.Tensor]:
+        """K-major copy [K, sum N] of the (grouped) weight, if the optimizer arena keeps one (optim.FlatArena:
+        bf16, refreshed by one batched transpose per step); None otherwise."""
+        if dtype != torch.bfloat16 or not USE_WT:
+            return None
+        return (getattr(params[0], "_vmr_wt_views", None) or {}).get(tuple(id(p) for p in params))
 
     def get(self, params: Sequence[torch.Tensor], dtype: torch.dtype, kpad: int = 0) -> torch.Tensor:
         """kpad > K: zero-pad the copy's K to kpad columns (an input padded to a multiple of 64 elements keeps
@@ -430,12 +439,20 @@ class _Linear(torch.autograd.Function):
             few = mm_few_tiles(dz, W, 0, 1)
             if few is not None:
                 dx = (few if dxtra is None else few + dxtra).to(dz.dtype)
-            elif dxtra is not None:          # tee: dX = dz.W + (gradient of x's other consumer), one epilogue
-                dxtra = dxtra.contiguous()
-                assert dxtra.shape == x.shape and dxtra.dtype == dz.dtype
-                dx = mm(dz, W, 0, 1, flags=L.EPI_RESIDUAL, residual=dxtra, ldr=dxtra.stride(0))
             else:
-                dx = mm(dz, W, 0, 1)                                                            # [M,N] . [N,Kp]
+                # K-major weight copy from the optimizer arena: dX = dz . Wt^T runs on the row-major-weight kernel
+                Wt = WeightCache.get_t(ctx.weights, dz.dtype) if Np == N else None
+                if Wt is not None and ctx.kslice is not None:
+                    Wt = Wt[ctx.kslice[0]:ctx.kslice[1]]
+                if Wt is not None and tuple(Wt.shape) != (Kp, N):
+                    Wt = None                # (K-padded inputs use a padded cast copy of W, not the arena mirror)
+                Bm, tb = (Wt, 0) if Wt is not None else (W, 1)
+                if dxtra is not None:        # tee: dX = dz.W + (gradient of x's other consumer), one epilogue
+                    dxtra = dxtra.contiguous()
+                    assert dxtra.shape == x.shape and dxtra.dtype == dz.dtype
+                    dx = mm(dz, Bm, 0, tb, flags=L.EPI_RESIDUAL, residual=dxtra, ldr=dxtra.stride(0))
+                else:
+                    dx = mm(dz, Bm, 0, tb)                                                      # [M,N] . [N,Kp]
         elif dxtra is not None:
             dx = dxtra
         # dW = dz^T . x  -> fp32 [N,Kp], split-K over the M (token) dimension

@@ -65,12 +65,44 @@ class FlatArena:
         self.names: List[str] = [n for n, _ in named]
         self.offsets = offs
         self.flat_w = None
+        self._t_count = 0
         if bf16_mirror:
             # bf16 copy of every master weight, refreshed by the fused AdamW kernel itself
             self.flat_w = self.flat_p.to(torch.bfloat16)
             for n, p in named:
                 o, k = offs[n], p.numel()
                 p._vmr_w16 = self.flat_w[o:o + k].view(p.shape)
+            # K-major (transposed) bf16 copy of every weight MATRIX as the GEMMs use it -- a whole group [sum N, K]
+            # for grouped projections, a single [N, K] otherwise -- rewritten after each optimizer step by ONE
+            # batched transpose launch (refresh_transposed): the dX products then read weights k-contiguously
+            self.flat_wt = torch.zeros_like(self.flat_w)
+            items = []
+            grouped = set()
+            for grp in groups:
+                if all(g in have for g in grp) and len(grp) > 1:
+                    ps = [have[g] for g in grp]
+                    K = ps[0].numel() // ps[0].shape[0]
+                    if all(q.dim() >= 2 and q.numel() // q.shape[0] == K and q.numel() % 8 == 0 for q in ps):
+                        items.append((grp[0], ps, sum(q.shape[0] for q in ps), K))
+                        grouped.update(grp)
+            for n, p in named:
+                if n not in grouped and p.dim() >= 2 and min(p.shape[0], p.numel() // p.shape[0]) >= 64:
+                    items.append((n, [p], p.shape[0], p.numel() // p.shape[0]))
+            self._t_items = (L.TransposeItem * len(items))()
+            for it, (n0, ps, rows, cols) in zip(self._t_items, items):
+                o = offs[n0]
+                it.src, it.dst = self.flat_w[o:].data_ptr(), self.flat_wt[o:].data_ptr()
+                it.rows, it.cols = rows, cols
+                view = self.flat_wt[o:o + rows * cols].view(cols, rows)
+                key = tuple(id(q) for q in ps)
+                d = getattr(ps[0], "_vmr_wt_views", None) or {}
+                d[key] = view
+                ps[0]._vmr_wt_views = d
+            self._t_count = len(items)
+
+    def refresh_transposed(self):
+        if getattr(self, "_t_count", 0):
+            L.check(L.lib().vmr_transpose_batched(self._t_items, self._t_count, L.stream_ptr()), "vmr_transpose_batched")
 
 
 class FlatAdamW:
@@ -94,6 +126,7 @@ class FlatAdamW:
         dev = self.arena.flat_p.device
         self.gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.step_t = torch.full((1,), self.t, device=dev, dtype=torch.int32)
+        self.arena.refresh_transposed()
 
     @property
     def grad_arena(self):
@@ -130,6 +163,7 @@ class FlatAdamW:
                               self.gnorm_sq.data_ptr(), self.max_norm, self.base_lr,
                               self.betas[0], self.betas[1], self.eps, self.wd, 0, self.step_t.data_ptr(),
                               self.warmup_steps, float(self.total_steps), n, st), "vmr_adamw")
+        A.refresh_transposed()       # K-major weight copies follow the bf16 mirror the kernel just rewrote
         self.step_t += 1             # scheduler.step() of the reference loop
         self.t += 1
         if hasattr(self.model, "_cache"):   # the masters changed under the compute-dtype weight cache
