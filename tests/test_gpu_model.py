@@ -208,40 +208,40 @@ def test_basefast_fp32_vs_golden(dev, name):
 
 def test_bf16_input_gradients_on_k_major_weight_copies(dev):
     """bf16 + flat arena: the optimizer keeps a K-major (transposed) copy of every weight matrix (one batched
-    transpose per step) and the dX products read it instead of the transposed-read layout.  Two models stepped in
-    lockstep, one with the copies and one without, must stay within bf16 noise of each other; the copies themselves
-    must equal the transposed bf16 mirrors exactly."""
+    transpose per step) and the dX products read it instead of the transposed-read layout.  The copies must equal
+    the transposed bf16 mirrors exactly, and the gradients of ONE model at fixed weights must agree between the two
+    dX paths to bf16 noise (two backward passes; comparing two models across optimizer steps would mostly measure
+    how Adam amplifies the summation-order noise of near-zero gradients)."""
     import vmrframe_amd as V
     from vmrframe_amd import ops
     from vmrframe_amd.optim import FlatAdamW
     z, cfg, batch, g, weights = load_golden("g_small")
     cfg.device = dev
-
-    def fresh():
-        m = build(cfg, weights, "bf16", dev)
-        m.gumbel_override = g.to(dev)
-        m.eval()
-        return m
-    ma, mb = fresh(), fresh()
-    oa, ob = FlatAdamW(ma, lr=1e-3, max_norm=1.0), FlatAdamW(mb, lr=1e-3, max_norm=1.0)
+    m = build(cfg, weights, "bf16", dev)
+    m.gumbel_override = g.to(dev)
+    m.eval()
+    opt = FlatAdamW(m, lr=1e-3, max_norm=1.0)
     try:
-        for it in range(3):
-            for m, o, use in ((ma, oa, True), (mb, ob, False)):
-                ops.USE_WT = use
-                loss, _ = V.train_engine_SeqPAN(m, batch, cfg, "train")
-                o.zero_grad(); loss.backward(); o.step()
-            if it == 0:
-                continue
-            n_views = 0
-            for p in ma.parameters():
-                for key, view in (getattr(p, "_vmr_wt_views", None) or {}).items():
-                    rows, cols = view.shape[1], view.shape[0]
-                    src = oa.arena.flat_w[oa.arena.offsets[[n for n, q in ma.named_parameters() if q is p][0]]:][:rows * cols]
-                    assert torch.equal(view, src.view(rows, cols).t()), "K-major copy != transposed bf16 mirror"
-                    n_views += 1
-            assert n_views > 20
-            ga, gb = oa.arena.flat_g, ob.arena.flat_g
-            rel = float((ga - gb).norm() / gb.norm())
-            assert rel < 2e-2, (it, rel)
+        for it in range(2):                       # step 0 builds the arena, step 1 moves the weights once more
+            loss, _ = V.train_engine_SeqPAN(m, batch, cfg, "train")
+            opt.zero_grad(); loss.backward(); opt.step()
+        n_views = 0
+        names = {id(q): n for n, q in m.named_parameters()}
+        for p in m.parameters():
+            for key, view in (getattr(p, "_vmr_wt_views", None) or {}).items():
+                rows, cols = view.shape[1], view.shape[0]
+                src = opt.arena.flat_w[opt.arena.offsets[names[id(p)]]:][:rows * cols]
+                assert torch.equal(view, src.view(rows, cols).t()), "K-major copy != transposed bf16 mirror"
+                n_views += 1
+        assert n_views > 20
+        grads = []
+        for use in (True, False, True):
+            ops.USE_WT = use
+            loss, _ = V.train_engine_SeqPAN(m, batch, cfg, "train")
+            opt.zero_grad(); loss.backward()
+            grads.append(opt.arena.flat_g.clone())
+        noise = float((grads[0] - grads[2]).norm() / grads[2].norm())      # same path twice: atomics-order noise
+        rel = float((grads[0] - grads[1]).norm() / grads[1].norm())
+        assert rel < max(5e-3, 5 * noise), (rel, noise)
     finally:
         ops.USE_WT = True

@@ -304,19 +304,40 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(TransItems items
   const int tr = (q.rows + 63) / 64, tc = (q.cols + 63) / 64;
   const unsigned short* src = reinterpret_cast<const unsigned short*>(q.src);
   unsigned short* dst = reinterpret_cast<unsigned short*>(q.dst);
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  // 4-byte accesses on both sides when rows and cols are even (every weight matrix of the model): a wave moves two
+  // 128-byte row segments per instruction
+  const bool even = ((q.rows | q.cols) & 1) == 0;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // pair of columns, row within a pass of 8
   for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
     const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int r = r0 + ty + 4 * k, c = c0 + tx;
-      tile[ty + 4 * k][tx] = (r < q.rows && c < q.cols) ? src[(int64_t)r * q.cols + c] : (unsigned short)0;
+    for (int k = 0; k < 8; ++k) {
+      const int r = r0 + ty + 8 * k, c = c0 + 2 * tx;
+      unsigned short a = 0, b = 0;
+      if (r < q.rows) {
+        if (even && c + 1 < q.cols) {
+          const uint32_t w = *reinterpret_cast<const uint32_t*>(src + (int64_t)r * q.cols + c);
+          a = (unsigned short)(w & 0xFFFFu); b = (unsigned short)(w >> 16);
+        } else {
+          if (c < q.cols) a = src[(int64_t)r * q.cols + c];
+          if (c + 1 < q.cols) b = src[(int64_t)r * q.cols + c + 1];
+        }
+      }
+      tile[ty + 8 * k][2 * tx] = a;
+      tile[ty + 8 * k][2 * tx + 1] = b;
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int c = c0 + ty + 4 * k, r = r0 + tx;
-      if (r < q.rows && c < q.cols) dst[(int64_t)c * q.rows + r] = tile[tx][ty + 4 * k];
+    for (int k = 0; k < 8; ++k) {
+      const int c = c0 + ty + 8 * k, r = r0 + 2 * tx;      // dst row c, elements r, r+1
+      if (c < q.cols) {
+        const unsigned short a = tile[2 * tx][ty + 8 * k], b = tile[2 * tx + 1][ty + 8 * k];
+        if (even && r + 1 < q.rows) *reinterpret_cast<uint32_t*>(dst + (int64_t)c * q.rows + r) = (uint32_t)a | ((uint32_t)b << 16);
+        else {
+          if (r < q.rows) dst[(int64_t)c * q.rows + r] = a;
+          if (r + 1 < q.rows) dst[(int64_t)c * q.rows + r + 1] = b;
+        }
+      }
     }
     __syncthreads();
   }
