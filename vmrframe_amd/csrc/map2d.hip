@@ -285,24 +285,29 @@ __global__ __launch_bounds__(64) void map2d_dp_kernel(const T* __restrict__ dR, 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void map2d_scatter_kernel(const T* __restrict__ cells, const int* __restrict__ cell_of,
                                                             const float* __restrict__ fill, T* __restrict__ out, int N,
-                                                            int W, int64_t C, int64_t total) {
-  const int wv = W / VEC;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int w = (int)(idx % wv) * VEC;
-    const int64_t bij = idx / wv;
-    const int ij = (int)(bij % ((int64_t)N * N));
-    const int64_t b = bij / ((int64_t)N * N);
+                                                            int W, int64_t C, int64_t ncell /* B*N*N */) {
+  // one thread = one VEC-wide piece of one dense cell; threads of a cell are consecutive (32-bit index math only)
+  const int wv = W / VEC;                       // pieces per cell
+  const int cpb = 256 / wv > 0 ? 256 / wv : 1;  // cells per workgroup pass
+  const int piece = threadIdx.x % wv, sub = threadIdx.x / wv;
+  const int NN = N * N;
+  for (int64_t cell0 = (int64_t)blockIdx.x * cpb; cell0 < ncell; cell0 += (int64_t)gridDim.x * cpb) {
+    const int64_t cell = cell0 + sub;
+    if (sub >= cpb || cell >= ncell) continue;
+    const int b = (int)(cell / NN), ij = (int)(cell - (int64_t)b * NN);
     const int c = cell_of[ij];
+    const int w = piece * VEC;
+    T* o = out + cell * W + w;
     if (VEC == 8) {
       float v[8];
-      if (c >= 0) Vec8<T>::load(cells + (b * C + c) * W + w, v);
+      if (c >= 0) Vec8<T>::load(cells + ((int64_t)b * C + c) * W + w, v);
       else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fill ? fill[w + e] : 0.f;
       }
-      Vec8<T>::store(out + bij * W + w, v);
+      Vec8<T>::store(o, v);
     } else {
-      out[bij * W + w] = c >= 0 ? cells[(b * C + c) * W + w] : from_f<T>(fill ? fill[w] : 0.f);
+      *o = c >= 0 ? cells[((int64_t)b * C + c) * W + w] : from_f<T>(fill ? fill[w] : 0.f);
     }
   }
 }
@@ -394,10 +399,13 @@ extern "C" int vmr_map2d_pool_bwd(const void* x, const void* dM, const void* dR,
 extern "C" int vmr_map2d_scatter(const void* cells, const int32_t* cell_of, const float* fill, void* out, int B, int N,
                                  int W, int64_t C, int dtype, void* stream) {
   VMR_CHECK(cells && cell_of && out, "vmr_map2d_scatter: null pointer");
-  const bool v8 = W % 8 == 0;
-  const int64_t total = (int64_t)B * N * N * (v8 ? W / 8 : W);
+  const bool v8 = W % 8 == 0 && W / 8 <= 256;
+  VMR_CHECK(v8 || W <= 256, "vmr_map2d_scatter: W too large for the scalar path");
+  const int64_t total = (int64_t)B * N * N;         // dense cells
   if (total == 0) return 0;
-  const int grid = (int)min((int64_t)65535, (total + 255) / 256);
+  const int wv = v8 ? W / 8 : W;
+  const int cpb = 256 / wv > 0 ? 256 / wv : 1;
+  const int grid = (int)min((int64_t)65535, (total + cpb - 1) / cpb);
   if (dtype == VMR_BF16) {
     if (v8) hipLaunchKernelGGL((map2d_scatter_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)cells,
                                cell_of, fill, (bf16_t*)out, N, W, C, total);
