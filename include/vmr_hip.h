@@ -97,6 +97,11 @@ typedef struct {
 } vmr_gemm_t;
 
 int vmr_gemm(const vmr_gemm_t* g, void* stream);
+/* Two INDEPENDENT products in one launch when both qualify for the single-round LDS-DMA tiles -- g1: row-major
+ * operands without split-K (the input gradient dX = dY.W on the K-major weight copy), g2: both operands transposed,
+ * split-K slabs (the weight gradient dW = dY^T.x) -- so that one problem's fill overlaps the other's store drain;
+ * otherwise exactly vmr_gemm(g1) followed by vmr_gemm(g2). */
+int vmr_gemm2(const vmr_gemm_t* g1, const vmr_gemm_t* g2, void* stream);
 
 /* ------------------------------------------------------------- LayerNorm
  * y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim D, optional

@@ -32,17 +32,18 @@ struct TileCoord {
   int tm, tn, zb, ks;
 };
 
-__device__ __forceinline__ TileCoord tile_coord(const vmr_gemm_t& g, int tiles_m, int tiles_n) {
+__device__ __forceinline__ TileCoord tile_coord(const vmr_gemm_t& g, int tiles_m, int tiles_n, int bid_x, int bid_z,
+                                                int grid_z) {
   // XCD-aware bijective remap: blocks with equal blockIdx.x % 8 share an XCD/L2;
   // give each XCD a contiguous run of logical tiles (n fastest), so the tiles that
   // re-read one A row-panel hit the same L2.
-  if (g.splitk > 1 && gridDim.z == 1) {
+  if (g.splitk > 1 && grid_z == 1) {
     // split-K, unbatched: the K split rides in blockIdx.x (ks = bid % splitk).  Workgroups go to the 8 XCDs round-
     // robin by linear id, so with splitk = 8 each XCD owns ONE K slab of both operands for all output tiles: a
     // [K/8 x M] and a [K/8 x N] panel (2.4 MB each at cfg2) stay in that XCD's L2 and HBM reads each operand once.
     // (With ks in blockIdx.z every XCD swept all K slabs of one operand: 8x the HBM / Infinity-Cache traffic.)
     TileCoord t;
-    const int bid = blockIdx.x, sk = g.splitk;
+    const int bid = bid_x, sk = g.splitk;
     t.ks = bid % sk;
     const int tile = bid / sk;
     t.tm = tile / tiles_n;
@@ -51,7 +52,7 @@ __device__ __forceinline__ TileCoord tile_coord(const vmr_gemm_t& g, int tiles_m
     return t;
   }
   const int nblk = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
+  const int bid = bid_x;
   const int q = nblk >> 3, r = nblk & 7;
   const int xcd = bid & 7, idx = bid >> 3;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -59,8 +60,8 @@ __device__ __forceinline__ TileCoord tile_coord(const vmr_gemm_t& g, int tiles_m
   t.tm = logical / tiles_n;
   t.tn = logical - t.tm * tiles_n;
   const int sk = g.splitk > 1 ? g.splitk : 1;
-  t.zb = blockIdx.z / sk;
-  t.ks = blockIdx.z - t.zb * sk;
+  t.zb = bid_z / sk;
+  t.ks = bid_z - t.zb * sk;
   return t;
 }
 
@@ -82,6 +83,10 @@ __device__ __forceinline__ int perm_row128(int rho) {   // LDS row of the [128][
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 __device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+
+__device__ __forceinline__ TileCoord tile_coord(const vmr_gemm_t& g, int tiles_m, int tiles_n) {
+  return tile_coord(g, tiles_m, tiles_n, blockIdx.x, blockIdx.z, gridDim.z);
+}
 
 // swizzle of the [k][128] (M/N-contiguous) bf16 image: 32-B chunk index ^= f(k)
 __device__ __forceinline__ int swz_tr(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
@@ -569,8 +574,8 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
 // MFMAs takes 90 % of the full time, ~60 GB/s per CU), so bytes per flop decide: one wide tile per CU
 // fetches (256 + 128) rows per K-step where two 128x128 tiles fetch 2 x (128 + 128).
 template <bool TA, bool TB, int BK, int NST, int MT = 4, int WM = 2>
-__global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void gemm_dma_body(const vmr_gemm_t& g, int tiles_m, int tiles_n, unsigned char* smem, int bid_x,
+                                              int bid_z, int grid_z) {
   static_assert(MT == 4 || (!TA && BK == 64), "tall tile: A row-major, BK = 64");
   static_assert(WM == 2 || WM == 4, "2 or 4 waves along M");
   constexpr int NW = 2 * WM;                 // waves
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_bf16_dma_ker
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
-  const TileCoord tc = tile_coord(g, tiles_m, tiles_n);
+  const TileCoord tc = tile_coord(g, tiles_m, tiles_n, bid_x, bid_z, grid_z);
   const int m0 = tc.tm * TBM, n0 = tc.tn * BN;
   const int z1 = tc.zb / g.Z2, z2 = tc.zb - z1 * g.Z2;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A) + z1 * g.sA1 + z2 * g.sA2;
@@ -715,6 +720,26 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_bf16_dma_ker
                          reinterpret_cast<const bf16_t*>(g.residual) + coff,
                          reinterpret_cast<bf16_t*>(g.aux) + coff);
   }
+}
+
+template <bool TA, bool TB, int BK, int NST, int MT = 4, int WM = 2>
+__global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gemm_dma_body<TA, TB, BK, NST, MT, WM>(g, tiles_m, tiles_n, smem, blockIdx.x, blockIdx.z, gridDim.z);
+}
+
+// Two independent products in ONE launch: workgroups [0, nblk2) run problem 2 (a split-K weight-gradient product
+// dW = dz^T.x writing slabs), the rest problem 1 (an x.W^T-layout product: the input gradient dX = dz.Wt^T).  Single-round
+// grids run every workgroup in phase (fill, K loop, epilogue burst); back to back in one grid, the second problem's
+// workgroups start their DMA under the first's store drain and one launch gap disappears.
+template <int MT1>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dma2_kernel(vmr_gemm_t g1, int tm1, int tn1, vmr_gemm_t g2, int tm2, int tn2,
+                                                                int nblk2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // the split-K weight-gradient workgroups go first (measured: 9.32 vs 9.37 ms/step the other way round; alternating
+  // the two problems in groups of 8 workgroups was worse than either, 9.53)
+  if ((int)blockIdx.x < nblk2) gemm_dma_body<true, true, 64, 2, 4, 2>(g2, tm2, tn2, smem, blockIdx.x, 0, 1);
+  else gemm_dma_body<false, false, 64, 2, MT1, 2>(g1, tm1, tn1, smem, blockIdx.x - nblk2, 0, 1);
 }
 
 // ----------------------------------------------------------------- f32 kernel
@@ -899,6 +924,19 @@ Pick pick_dma(int ta, int tb, int variant) {
 inline bool mult(int64_t v, int64_t m) { return (v % m) == 0; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+bool gemm_aligned(const vmr_gemm_t& g) {   // 16-byte accesses everywhere
+  const int v = g.dtype == VMR_BF16 ? 8 : 4;  // elements per 16 B
+  bool al = aligned16(g.A) && aligned16(g.B) && aligned16(g.C) && mult(g.lda, v) && mult(g.ldb, v) &&
+            mult(g.ldc, 8) && mult(g.sA1, v) && mult(g.sA2, v) && mult(g.sB1, v) && mult(g.sB2, v) &&
+            mult(g.sC1, 8) && mult(g.sC2, 8);
+  if (g.flags & (VMR_EPI_RESIDUAL | VMR_EPI_AUX)) {
+    al = al && mult(g.ldr, 8);
+    if (g.flags & VMR_EPI_RESIDUAL) al = al && aligned16(g.residual);
+    if (g.flags & VMR_EPI_AUX) al = al && aligned16(g.aux);
+  }
+  return al;
+}
+
 }  // namespace
 
 extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
@@ -930,15 +968,8 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
             (long long)g.ldb, (long long)g.ldc);
   const int v = g.dtype == VMR_BF16 ? 8 : 4;  // elements per 16 B
   const int vc = (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM)) ? 4 : v;
-  bool al = aligned16(g.A) && aligned16(g.B) && aligned16(g.C) && mult(g.lda, v) && mult(g.ldb, v) &&
-            mult(g.ldc, 8) && mult(g.sA1, v) && mult(g.sA2, v) && mult(g.sB1, v) && mult(g.sB2, v) &&
-            mult(g.sC1, 8) && mult(g.sC2, 8);
   (void)vc;
-  if (g.flags & (VMR_EPI_RESIDUAL | VMR_EPI_AUX)) {
-    al = al && mult(g.ldr, 8);
-    if (g.flags & VMR_EPI_RESIDUAL) al = al && aligned16(g.residual);
-    if (g.flags & VMR_EPI_AUX) al = al && aligned16(g.aux);
-  }
+  bool al = gemm_aligned(g);
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
   if (g_gemm_bk == 0) {
     const char* e = getenv("VMR_GEMM_BK");
@@ -1032,5 +1063,67 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   if (colsum_fallback)   // A is stored [K][M]: a plain column-sum pass (vmr_relu_bwd_bias mode 0 accumulates)
     return vmr_relu_bwd_bias(0, g.A, nullptr, nullptr, colsum_fallback, g.K, g.M, g.lda, 1.0f, g.dtype, 0.f, 0, nullptr, nullptr,
                              1.0f, stream);
+  return 0;
+}
+
+// Two independent bf16 products in one launch where both take the single-round LDS-DMA tiles (see
+// gemm_bf16_dma2_kernel): g1 = an x.W^T-layout product without split-K (the input gradient on the K-major weight copy),
+// g2 = a transposed-operand split-K slab product (the weight gradient).  Anything else falls back to two vmr_gemm calls.
+extern "C" int vmr_gemm2(const vmr_gemm_t* p1, const vmr_gemm_t* p2, void* stream) {
+  VMR_CHECK(p1 && p2, "vmr_gemm2: null descriptor");
+  static int g_merge = -1;
+  if (g_merge < 0) {
+    const char* e = getenv("VMR_GEMM_MERGE");
+    g_merge = e ? atoi(e) : 1;
+  }
+  vmr_gemm_t g1 = *p1, g2 = *p2;
+  auto norm = [](vmr_gemm_t& g) {
+    if (g.Z1 <= 0) g.Z1 = 1;
+    if (g.Z2 <= 0) g.Z2 = 1;
+    if (g.splitk <= 0) g.splitk = 1;
+    if (g.flags & VMR_EPI_SLAB) g.flags |= VMR_EPI_OUT_F32;
+    if (g.bias_scale == 0.f) g.bias_scale = 1.f;
+    if (g.res_div <= 0) g.res_div = 1;
+  };
+  norm(g1); norm(g2);
+  auto basic = [](const vmr_gemm_t& g) {
+    return g.dtype == VMR_BF16 && g.A && g.B && g.C && g.Z1 * g.Z2 == 1 && g.M > 0 && g.N % BN == 0 && g.K % 64 == 0 &&
+           !(g.flags & VMR_EPI_ACCUM) && gemm_aligned(g) && g.lda >= (g.transA ? g.M : g.K) && g.ldb >= (g.transB ? g.N : g.K) &&
+           g.ldc >= g.N && (!(g.flags & VMR_EPI_BIAS) || (g.bias && aligned16(g.bias) && aligned16(g.bias2))) &&
+           (!(g.flags & VMR_EPI_RESIDUAL) || g.residual) && (!(g.flags & VMR_EPI_AUX) || g.aux) &&
+           (!(g.flags & VMR_EPI_ROWSCALE) || g.rowscale);
+  };
+  bool ok = g_merge && basic(g1) && basic(g2);
+  // problem 1: row-major operands, no split; 128- or 160-row tiles exactly as vmr_gemm would pick, single round
+  int mt1 = 4, tm1 = 0;
+  const int tn1 = g1.N / BN;
+  if (ok) {
+    ok = !g1.transA && !g1.transB && g1.splitk == 1 && g1.K >= 128 && g1.M % 8 == 0 && !(g1.flags & VMR_EPI_SLAB);
+    const double c128 = g1.M % BM == 0 ? rounds_cost((int64_t)(g1.M / BM) * tn1, 1.0) : 1e30;
+    const double c160 = rounds_cost((int64_t)cdiv(g1.M, 160) * tn1, 1.25);
+    mt1 = c160 < c128 - 1e-9 ? 5 : 4;
+    tm1 = mt1 == 5 ? cdiv(g1.M, 160) : g1.M / BM;
+    ok = ok && (mt1 == 5 || g1.M % BM == 0) && (int64_t)tm1 * tn1 <= 512;
+  }
+  // problem 2: both operands transposed, split-K slabs
+  const int tm2 = g2.M / BM, tn2 = g2.N / BN;
+  ok = ok && g2.transA && g2.transB && g2.splitk > 1 && (g2.flags & VMR_EPI_SLAB) && g2.M % BM == 0 &&
+       g2.K >= 128 * g2.splitk && (int64_t)tm2 * tn2 * g2.splitk <= 1024 && (!g2.a_colsum || true);
+  if (!ok) {
+    if (int rc = vmr_gemm(p1, stream)) return rc;
+    return vmr_gemm(p2, stream);
+  }
+  const int nblk1 = tm1 * tn1, nblk2 = tm2 * tn2 * g2.splitk;
+  const int smem = TALL_SMEM;   // >= both variants' two-stage rings (direct epilogues: no staging tile)
+  if (mt1 == 5) {
+    if (int rc = set_smem_once((gemm_fn)(void*)gemm_bf16_dma2_kernel<5>, smem)) return rc;
+    hipLaunchKernelGGL(gemm_bf16_dma2_kernel<5>, dim3(nblk1 + nblk2), dim3(256), smem, (hipStream_t)stream, g1, tm1, tn1, g2, tm2,
+                       tn2, nblk2);
+  } else {
+    if (int rc = set_smem_once((gemm_fn)(void*)gemm_bf16_dma2_kernel<4>, smem)) return rc;
+    hipLaunchKernelGGL(gemm_bf16_dma2_kernel<4>, dim3(nblk1 + nblk2), dim3(256), smem, (hipStream_t)stream, g1, tm1, tn1, g2, tm2,
+                       tn2, nblk2);
+  }
+  VMR_LAUNCH_CHECK();
   return 0;
 }

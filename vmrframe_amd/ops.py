@@ -73,7 +73,8 @@ class DropCtx:
 # ---------------------------------------------------------------------------
 def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=None, residual=None, aux=None,
          ldr=0, rowscale=None, alpha=1.0, Z1=1, Z2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, drop=NO_DROP,
-         bias2=None, bias_scale=1.0, res_div=1, a_colsum=None):
+         bias2=None, bias_scale=1.0, res_div=1, a_colsum=None, defer=False):
+    global _PENDING_GEMM
     d = L.GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cmat.data_ptr()
     d.bias, d.residual, d.aux, d.rowscale = _ptr(bias), _ptr(residual), _ptr(aux), _ptr(rowscale)
@@ -90,10 +91,36 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
     d.bias2, d.bias_scale, d.res_div = _ptr(bias2), bias_scale, res_div
     d.a_colsum = _ptr(a_colsum)
     if GEMM_HOOK is not None:
+        flush_pending_gemm()
         GEMM_HOOK(lambda: L.check(L.lib().vmr_gemm(C.byref(d), L.stream_ptr()), "vmr_gemm"), M, N, K, ta, tb,
                   Z1 * Z2, dtype)
         return
+    if defer and MERGE_DX_DW:
+        # held back: the next split-K slab product (the layer's weight gradient) takes it along in ONE launch
+        flush_pending_gemm()
+        _PENDING_GEMM = (d, (A, B, Cmat, bias, residual, aux, rowscale, bias2, a_colsum, drop))
+        return
+    if _PENDING_GEMM is not None:
+        pd, keep = _PENDING_GEMM
+        _PENDING_GEMM = None
+        if ta and tb and splitk > 1 and (flags & L.EPI_SLAB) and Z1 * Z2 == 1:
+            L.check(L.lib().vmr_gemm2(C.byref(pd), C.byref(d), L.stream_ptr()), "vmr_gemm2")
+            return
+        L.check(L.lib().vmr_gemm(C.byref(pd), L.stream_ptr()), "vmr_gemm")
     L.check(L.lib().vmr_gemm(C.byref(d), L.stream_ptr()), "vmr_gemm")
+
+
+MERGE_DX_DW = os.environ.get("VMR_MERGE_DX_DW", "1") != "0"
+_PENDING_GEMM = None     # (descriptor, tensors kept alive) of a deferred dX product
+
+
+def flush_pending_gemm():
+    """Launch a held-back product on its own (nothing came along to share its launch)."""
+    global _PENDING_GEMM
+    if _PENDING_GEMM is not None:
+        pd, keep = _PENDING_GEMM
+        _PENDING_GEMM = None
+        L.check(L.lib().vmr_gemm(C.byref(pd), L.stream_ptr()), "vmr_gemm")
 
 
 def mm(a: torch.Tensor, b: torch.Tensor, ta: int, tb: int, *, out=None, out_f32=False, **kw) -> torch.Tensor:
@@ -447,12 +474,14 @@ class _Linear(torch.autograd.Function):
                 if Wt is not None and tuple(Wt.shape) != (Kp, N):
                     Wt = None                # (K-padded inputs use a padded cast copy of W, not the arena mirror)
                 Bm, tb = (Wt, 0) if Wt is not None else (W, 1)
+                # (held back: launched together with the first weight-gradient slab product below, vmr_gemm2)
+                hold = Wt is not None and DW_SIDE_STREAM is None
                 if dxtra is not None:        # tee: dX = dz.W + (gradient of x's other consumer), one epilogue
                     dxtra = dxtra.contiguous()
                     assert dxtra.shape == x.shape and dxtra.dtype == dz.dtype
-                    dx = mm(dz, Bm, 0, tb, flags=L.EPI_RESIDUAL, residual=dxtra, ldr=dxtra.stride(0))
+                    dx = mm(dz, Bm, 0, tb, flags=L.EPI_RESIDUAL, residual=dxtra, ldr=dxtra.stride(0), defer=hold)
                 else:
-                    dx = mm(dz, Bm, 0, tb)                                                      # [M,N] . [N,Kp]
+                    dx = mm(dz, Bm, 0, tb, defer=hold)                                          # [M,N] . [N,Kp]
         elif dxtra is not None:
             dx = dxtra
         # dW = dz^T . x  -> fp32 [N,Kp], split-K over the M (token) dimension
@@ -489,8 +518,10 @@ class _Linear(torch.autograd.Function):
                     r += n
             if db is not None and Np != N:
                 db = db[:N]
+            flush_pending_gemm()
             return (dx, *_bias_grads(db, bgrad, has_b2, ctx.bias_scale), None, dres, None, None, None, None, None, None,
                     None, None, *([None] * len(wshapes)))
+        flush_pending_gemm()
         if sk > 1:
             dW = torch.zeros(N, Kp, device=dy.device, dtype=torch.float32)
             gemm(dz, x, dW, N, Kp, M, 1, 1, dz.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_ACCUM, splitk=sk)
