@@ -111,6 +111,7 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
 
 
 MERGE_DX_DW = os.environ.get("VMR_MERGE_DX_DW", "1") != "0"
+GROUP_DW = os.environ.get("VMR_GROUP_DW", "1") != "0"      # one weight-gradient product per grouped projection
 _PENDING_GEMM = None     # (descriptor, tensors kept alive) of a deferred dX product
 
 
@@ -496,9 +497,18 @@ class _Linear(torch.autograd.Function):
                 side.wait_stream(torch.cuda.current_stream())
                 dz.record_stream(side)
                 x.record_stream(side)
+            # a grouped projection (q|k|v, ...) whose gradient slots sit back to back in the arena gets ONE
+            # [sum N, K] weight-gradient product (and one slab reduction) instead of one per member
+            if GROUP_DW and len(slots) > 1 and ks is None and all(k == Kp for k in kfull) and \
+                    all(a_.data_ptr() + a_.numel() * 4 == b_.data_ptr() for a_, b_ in zip(slots[:-1], slots[1:])):
+                ntot = sum(shp[0] for shp in wshapes)
+                slots = [torch.as_strided(slots[0], (ntot, Kp), (Kp, 1))]
+                wshapes_, kfull_ = [(ntot, Kp)], [Kp]
+            else:
+                wshapes_, kfull_ = wshapes, kfull
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 r = 0
-                for g_, shp, kf in zip(slots, wshapes, kfull):
+                for g_, shp, kf in zip(slots, wshapes_, kfull_):
                     n = shp[0]
                     a = dz[:, r:r + n]
                     sk_ = splitk_for(n, Kp, M)
