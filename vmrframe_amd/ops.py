@@ -168,19 +168,25 @@ def bmm4(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, ta: int, tb: int, *,
          sC=(c.stride(0), c.stride(1)), **kw)
 
 
-SPLITK_TARGET = int(os.environ.get("VMR_SPLITK_TARGET", "512"))   # workgroups to aim for in dW products
+# workgroups to aim for in dW products.  512 when the product runs alone (8 splits for a 64-tile [1024 x 1024]
+# gradient: two workgroups per CU); 384 when it shares its launch with the layer's single-round dX product (4 splits:
+# half the slab traffic, the dX workgroups fill the other slots: 9.35 -> 9.27 ms/step at cfg2, but 8.7 -> 9.5 ms for
+# BaseFast at T = 256, whose dX grids are multi-round and never merge)
+SPLITK_TARGET = int(os.environ.get("VMR_SPLITK_TARGET", "512"))
+SPLITK_TARGET_MERGED = int(os.environ.get("VMR_SPLITK_TARGET_MERGED", "384"))
 USE_SLABS = os.environ.get("VMR_SPLITK_SLABS", "1") != "0"
 FUSED_ATTENTION = os.environ.get("VMR_FUSED_ATTN", "1") != "0"   # csrc/attention.hip forward (bf16, hd 128/256)
 FUSED_ATTENTION_BWD = os.environ.get("VMR_FUSED_ATTN_BWD", "1") != "0"   # csrc/attention_bwd.hip
 FUSED_CQ_SCORE = os.environ.get("VMR_FUSED_CQ", "1") != "0"   # csrc/cqscore.hip
 
 
-def splitk_for(M: int, N: int, K: int) -> int:
+def splitk_for(M: int, N: int, K: int, target: int = 0) -> int:
     """dW products have few output tiles and a long K (= tokens): split K until the grid has about
     one workgroup per CU; every split costs one more fp32 atomic pass over the [M,N] output."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     sk = 1
-    while tiles * sk * 2 <= SPLITK_TARGET and K // (sk * 2) >= 512:
+    target = target or SPLITK_TARGET
+    while tiles * sk * 2 <= target and K // (sk * 2) >= 512:
         sk *= 2
     return sk
 
@@ -511,7 +517,9 @@ class _Linear(torch.autograd.Function):
                 for g_, shp, kf in zip(slots, wshapes_, kfull_):
                     n = shp[0]
                     a = dz[:, r:r + n]
-                    sk_ = splitk_for(n, Kp, M)
+                    # (a held-back single-round dX product will share this launch: fewer, longer splits)
+                    merged = _PENDING_GEMM is not None and _cdiv(M, 160) * _cdiv(Kp, 128) <= 512
+                    sk_ = splitk_for(n, Kp, M, SPLITK_TARGET_MERGED if merged else 0)
                     if ks is not None:       # gradient of the column slice, in place inside the full matrix
                         g_ = g_.view(n, kf)[:, ks[0]:ks[1]]
                     if sk_ > 1 and USE_SLABS:
