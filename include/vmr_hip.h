@@ -102,6 +102,11 @@ int vmr_gemm(const vmr_gemm_t* g, void* stream);
  * split-K slabs (the weight gradient dW = dY^T.x) -- so that one problem's fill overlaps the other's store drain;
  * otherwise exactly vmr_gemm(g1) followed by vmr_gemm(g2). */
 int vmr_gemm2(const vmr_gemm_t* g1, const vmr_gemm_t* g2, void* stream);
+/* ... plus, optionally (slab != NULL), the vmr_splitk_reduce of an EARLIER product's slabs as extra workgroups of the
+ * same grid (dst += sum_k slab[k], arguments as vmr_splitk_reduce): the previous layer's weight-gradient reduction
+ * runs under this layer's products instead of being a launch of its own. */
+int vmr_gemm2_reduce(const vmr_gemm_t* g1, const vmr_gemm_t* g2, const float* slab, float* dst, int nsplit, int64_t n,
+                     int cols, int64_t ld_dst, void* stream);
 
 /* ------------------------------------------------------------- LayerNorm
  * y = (x-mean)/sqrt(var+eps)*gamma+beta over the last dim D, optional

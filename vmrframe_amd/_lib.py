@@ -62,6 +62,7 @@ _P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 SIGNATURES = {
     "vmr_gemm": [C.POINTER(GemmDesc), _P],
     "vmr_gemm2": [_P, _P, _P],
+    "vmr_gemm2_reduce": [_P, _P, _P, _P, _I, _L, _I, _L, _P],
     "vmr_layernorm_fwd": [_P, _P, _P, _F, _P, _I, _P, _P, _P, _L, _I, _I, _F, _U, _P, _P],
     "vmr_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _U, _P, _P],
     "vmr_ln_dwconv_fwd": [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -732,14 +732,37 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_bf16_dma_ker
 // dW = dz^T.x writing slabs), the rest problem 1 (an x.W^T-layout product: the input gradient dX = dz.Wt^T).  Single-round
 // grids run every workgroup in phase (fill, K loop, epilogue burst); back to back in one grid, the second problem's
 // workgroups start their DMA under the first's store drain and one launch gap disappears.
+struct ReduceJob {   // dst[i] += sum_k slab[k][i] in 16-byte quads (the split-K second stage of an EARLIER product)
+  const float* slab;
+  float* dst;
+  int nsplit, cols4, nblocks;
+  int64_t n4, ld4;
+};
+
 template <int MT1>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_dma2_kernel(vmr_gemm_t g1, int tm1, int tn1, vmr_gemm_t g2, int tm2, int tn2,
-                                                                int nblk2) {
+                                                                int nblk2, int nblk12, ReduceJob rj) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // the split-K weight-gradient workgroups go first (measured: 9.32 vs 9.37 ms/step the other way round; alternating
   // the two problems in groups of 8 workgroups was worse than either, 9.53)
-  if ((int)blockIdx.x < nblk2) gemm_dma_body<true, true, 64, 2, 4, 2>(g2, tm2, tn2, smem, blockIdx.x, 0, 1);
-  else gemm_dma_body<false, false, 64, 2, MT1, 2>(g1, tm1, tn1, smem, blockIdx.x - nblk2, 0, 1);
+  // the slab reduction of the PREVIOUS layer's weight gradient takes the first workgroup ids (measured: first 9.08-9.10,
+  // last 9.21 ms/step; 256-384 reduction workgroups, 128 or 512+ are slower)
+  const int bid = (int)blockIdx.x < rj.nblocks ? nblk12 + (int)blockIdx.x : (int)blockIdx.x - rj.nblocks;
+  if (bid < nblk2) gemm_dma_body<true, true, 64, 2, 4, 2>(g2, tm2, tn2, smem, bid, 0, 1);
+  else if (bid < nblk12) gemm_dma_body<false, false, 64, 2, MT1, 2>(g1, tm1, tn1, smem, bid - nblk2, 0, 1);
+  else {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(rj.slab);
+    f32x4* d4 = reinterpret_cast<f32x4*>(rj.dst);
+    for (int64_t i = (int64_t)(bid - nblk12) * 256 + threadIdx.x; i < rj.n4; i += (int64_t)rj.nblocks * 256) {
+      const int64_t o = rj.cols4 ? (i / rj.cols4) * rj.ld4 + (i % rj.cols4) : i;
+      f32x4 acc = d4[o];
+      for (int k = 0; k < rj.nsplit; ++k) {
+        const f32x4 v = s4[k * rj.n4 + i];
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+      }
+      d4[o] = acc;
+    }
+  }
 }
 
 // ----------------------------------------------------------------- f32 kernel
@@ -1069,8 +1092,11 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
 // Two independent bf16 products in one launch where both take the single-round LDS-DMA tiles (see
 // gemm_bf16_dma2_kernel): g1 = an x.W^T-layout product without split-K (the input gradient on the K-major weight copy),
 // g2 = a transposed-operand split-K slab product (the weight gradient).  Anything else falls back to two vmr_gemm calls.
-extern "C" int vmr_gemm2(const vmr_gemm_t* p1, const vmr_gemm_t* p2, void* stream) {
+extern "C" int vmr_gemm2_reduce(const vmr_gemm_t* p1, const vmr_gemm_t* p2, const float* slab, float* dst, int nsplit, int64_t n,
+                                int cols, int64_t ld_dst, void* stream) {
   VMR_CHECK(p1 && p2, "vmr_gemm2: null descriptor");
+  VMR_CHECK(!slab || (dst && nsplit > 0 && n % 4 == 0 && (cols == 0 || (cols % 4 == 0 && ld_dst % 4 == 0 && ld_dst >= cols && n % cols == 0))),
+            "vmr_gemm2_reduce: bad reduction job");
   static int g_merge = -1;
   if (g_merge < 0) {
     const char* e = getenv("VMR_GEMM_MERGE");
@@ -1110,20 +1136,32 @@ extern "C" int vmr_gemm2(const vmr_gemm_t* p1, const vmr_gemm_t* p2, void* strea
   ok = ok && g2.transA && g2.transB && g2.splitk > 1 && (g2.flags & VMR_EPI_SLAB) && g2.M % BM == 0 &&
        g2.K >= 128 * g2.splitk && (int64_t)tm2 * tn2 * g2.splitk <= 1024 && (!g2.a_colsum || true);
   if (!ok) {
+    if (slab)
+      if (int rc = vmr_splitk_reduce(slab, dst, nsplit, n, cols, ld_dst, stream)) return rc;
     if (int rc = vmr_gemm(p1, stream)) return rc;
     return vmr_gemm(p2, stream);
   }
   const int nblk1 = tm1 * tn1, nblk2 = tm2 * tn2 * g2.splitk;
+  ReduceJob rj;
+  memset(&rj, 0, sizeof(rj));
+  if (slab && n > 0) {
+    rj.slab = slab; rj.dst = dst; rj.nsplit = nsplit; rj.n4 = n / 4; rj.cols4 = cols / 4; rj.ld4 = ld_dst / 4;
+    rj.nblocks = (int)min((int64_t)384, (n / 4 + 255) / 256);
+  }
   const int smem = TALL_SMEM;   // >= both variants' two-stage rings (direct epilogues: no staging tile)
   if (mt1 == 5) {
     if (int rc = set_smem_once((gemm_fn)(void*)gemm_bf16_dma2_kernel<5>, smem)) return rc;
-    hipLaunchKernelGGL(gemm_bf16_dma2_kernel<5>, dim3(nblk1 + nblk2), dim3(256), smem, (hipStream_t)stream, g1, tm1, tn1, g2, tm2,
-                       tn2, nblk2);
+    hipLaunchKernelGGL(gemm_bf16_dma2_kernel<5>, dim3(nblk1 + nblk2 + rj.nblocks), dim3(256), smem, (hipStream_t)stream, g1, tm1,
+                       tn1, g2, tm2, tn2, nblk2, nblk1 + nblk2, rj);
   } else {
     if (int rc = set_smem_once((gemm_fn)(void*)gemm_bf16_dma2_kernel<4>, smem)) return rc;
-    hipLaunchKernelGGL(gemm_bf16_dma2_kernel<4>, dim3(nblk1 + nblk2), dim3(256), smem, (hipStream_t)stream, g1, tm1, tn1, g2, tm2,
-                       tn2, nblk2);
+    hipLaunchKernelGGL(gemm_bf16_dma2_kernel<4>, dim3(nblk1 + nblk2 + rj.nblocks), dim3(256), smem, (hipStream_t)stream, g1, tm1,
+                       tn1, g2, tm2, tn2, nblk2, nblk1 + nblk2, rj);
   }
   VMR_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int vmr_gemm2(const vmr_gemm_t* p1, const vmr_gemm_t* p2, void* stream) {
+  return vmr_gemm2_reduce(p1, p2, nullptr, nullptr, 0, 0, 0, 0, stream);
 }

@@ -104,7 +104,13 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
         pd, keep = _PENDING_GEMM
         _PENDING_GEMM = None
         if ta and tb and splitk > 1 and (flags & L.EPI_SLAB) and Z1 * Z2 == 1:
-            L.check(L.lib().vmr_gemm2(C.byref(pd), C.byref(d), L.stream_ptr()), "vmr_gemm2")
+            rj = _take_pending_reduce()
+            if rj is None:
+                L.check(L.lib().vmr_gemm2(C.byref(pd), C.byref(d), L.stream_ptr()), "vmr_gemm2")
+            else:   # the previous layer's slab reduction rides at the end of this launch
+                ws_, dst_, sk_, n_, cols_, ld_ = rj
+                L.check(L.lib().vmr_gemm2_reduce(C.byref(pd), C.byref(d), ws_.data_ptr(), dst_.data_ptr(), sk_, n_, cols_, ld_,
+                                                 L.stream_ptr()), "vmr_gemm2_reduce")
             return
         L.check(L.lib().vmr_gemm(C.byref(pd), L.stream_ptr()), "vmr_gemm")
     L.check(L.lib().vmr_gemm(C.byref(d), L.stream_ptr()), "vmr_gemm")
@@ -113,6 +119,54 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
 MERGE_DX_DW = os.environ.get("VMR_MERGE_DX_DW", "1") != "0"
 GROUP_DW = os.environ.get("VMR_GROUP_DW", "1") != "0"      # one weight-gradient product per grouped projection
 _PENDING_GEMM = None     # (descriptor, tensors kept alive) of a deferred dX product
+
+
+_PENDING_REDUCE = None   # (slabs kept alive, dst, nsplit, n, cols, ld_dst) of a split-K second stage not launched yet
+DEFER_SPLITK_REDUCE = os.environ.get("VMR_DEFER_SPLITK_REDUCE", "1") != "0"
+
+
+def _take_pending_reduce():
+    global _PENDING_REDUCE
+    rj, _PENDING_REDUCE = _PENDING_REDUCE, None
+    return rj
+
+
+def flush_pending_reduce():
+    rj = _take_pending_reduce()
+    if rj is not None:
+        ws_, dst_, sk_, n_, cols_, ld_ = rj
+        L.check(L.lib().vmr_splitk_reduce(ws_.data_ptr(), dst_.data_ptr(), sk_, n_, cols_, ld_, L.stream_ptr()),
+                "vmr_splitk_reduce")
+
+
+_REDUCE_CB_ARMED = False
+
+
+def _reduce_cb():
+    global _REDUCE_CB_ARMED
+    _REDUCE_CB_ARMED = False
+    flush_pending_reduce()
+
+
+def splitk_reduce_later(ws, dst, sk, n, cols, ld):
+    """Second stage of a split-K weight gradient: held back so that the NEXT merged dX + dW launch (the next layer of
+    the backward pass) carries it as tail workgroups; whatever is still pending when the autograd engine finishes
+    the pass is launched then (queue_callback), i.e. before anything can read the gradient arena."""
+    global _PENDING_REDUCE
+    if not DEFER_SPLITK_REDUCE or GEMM_HOOK is not None or DW_SIDE_STREAM is not None or not MERGE_DX_DW:
+        L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, n, cols, ld, L.stream_ptr()), "vmr_splitk_reduce")
+        return
+    global _REDUCE_CB_ARMED
+    flush_pending_reduce()
+    if not _REDUCE_CB_ARMED:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_reduce_cb)
+            _REDUCE_CB_ARMED = True
+        except RuntimeError:      # not inside a backward pass
+            L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, n, cols, ld, L.stream_ptr()),
+                    "vmr_splitk_reduce")
+            return
+    _PENDING_REDUCE = (ws, dst, sk, n, cols, ld)
 
 
 def flush_pending_gemm():
@@ -528,8 +582,7 @@ class _Linear(torch.autograd.Function):
                         ws = torch.empty(sk_, n, Kp, device=dy.device, dtype=torch.float32)
                         gemm(a, x, ws, n, Kp, M, 1, 1, a.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_SLAB,
                              splitk=sk_, a_colsum=db[r:r + n] if colsum_in_gemm else None)
-                        L.check(lib.vmr_splitk_reduce(ws.data_ptr(), g_.data_ptr(), sk_, n * Kp, Kp, kf,
-                                                      L.stream_ptr()), "vmr_splitk_reduce")
+                        splitk_reduce_later(ws, g_, sk_, n * Kp, Kp, kf)
                     else:
                         gemm(a, x, g_, n, Kp, M, 1, 1, a.stride(0), x.stride(0), kf, dtype=dt, flags=L.EPI_ACCUM,
                              splitk=sk_, a_colsum=db[r:r + n] if colsum_in_gemm else None)
