@@ -73,6 +73,30 @@ class GemmTimer:
                 "bytes_per_launch": sum(r[3] for r in self.records) / len(self.records)}
 
 
+class Gemm2Timer:
+    """HIP events around the merged launches (gemm_bf16_dma2_kernel: a layer's dW + dX products and the previous
+    layer's slab reduction in one grid)."""
+
+    def __init__(self):
+        self.records = []
+
+    def __call__(self, launch, flops, nbytes):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        launch()
+        e.record()
+        self.records.append((s, e, flops, nbytes))
+
+    def summary(self):
+        if not self.records:
+            return None
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        fl = sum(r[2] for r in self.records)
+        return {"launches": len(self.records), "ms_total": ms, "tflops": fl / (ms * 1e-3) / 1e12,
+                "avg_us": ms * 1e3 / len(self.records), "flops_per_launch": fl / len(self.records),
+                "bytes_per_launch": sum(r[3] for r in self.records) / len(self.records)}
+
+
 def cpu_baseline(a):
     """The oracle (CPU fp32 restatement of the reference, kind 'port') timed on the host cores
     on a bounded sample: cfg2 shapes at B=8 clips, one warm-up + two timed fwd+bwd+AdamW steps."""
@@ -218,6 +242,8 @@ def main():
     # GEMM of two more (eager) steps of the same workload -- events cannot be recorded inside a graph replay
     timer = GemmTimer() if rank == 0 else None
     ops.GEMM_HOOK = timer
+    timer2 = Gemm2Timer() if rank == 0 else None
+    ops.GEMM2_HOOK = timer2
     cq_rec = []
 
     def cq_hook(launch, B_, Ll, Ls, D_):
@@ -229,6 +255,7 @@ def main():
         eager_step()
     torch.cuda.synchronize()
     ops.GEMM_HOOK = None
+    ops.GEMM2_HOOK = None
     ops.CQ_HOOK = None
     timed_steps_for_hook = 2
     if world > 1:
@@ -242,13 +269,15 @@ def main():
         clips = a["B"] * world * args.steps
         value = clips / dt
         gs = timer.summary()
-        traffic = None
+        traffic = traffic2 = None
         tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
         if os.path.exists(tpath) and args.workload == "seqpan":   # the PMC passes were taken on the headline workload
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic2 = (tj.get("merged") or {}).get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic = traffic2 = None
         roofline = None
         if gs:
             roofline = {"kernel": "gemm_bf16_dma_kernel<false,false,64,2,{4|5}> (NT: x.W^T pointwise-conv / projection GEMM)",
@@ -269,6 +298,18 @@ def main():
               "banmap": ("BAN 2-D proposal-map stage (configs[4], next-row N2 first slice; models/BAN.py:87-99 + loss_bce): "
                          "B=64 clips/GPU, N=128, fuse_dim 512, contrast 128, pooling_counts [31,16,16], bf16, dropout 0.1, "
                          "dense tmap / map2d_proj outputs; fwd+loss+bwd+clip+AdamW")}[args.workload]
+        g2 = timer2.summary()
+        roofline2 = None
+        if g2:
+            roofline2 = {"kernel": "gemm_bf16_dma2_kernel<{4|5}> (one launch = a layer's dW = dz^T.x split-K slabs + its dX = dz.Wt^T "
+                                   "+ the previous layer's slab reduction)",
+                         "bound": "mfma", "achieved": round(g2["tflops"], 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(g2["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic2,
+                         "launches_per_step": g2["launches"] / timed_steps_for_hook, "avg_launch_us": round(g2["avg_us"], 2),
+                         "flops_per_launch": g2["flops_per_launch"], "algorithmic_bytes_per_launch": g2["bytes_per_launch"]}
+            # `roofline` = the kernel with the larger share of the step; the other one is reported beside it
+            if roofline is None or g2["ms_total"] > gs["ms_total"]:
+                roofline, roofline2 = roofline2, roofline
         out = {"metric": metric, "value": round(value, 2),
                "unit": "clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -277,7 +318,7 @@ def main():
                           "global_batch": a["B"] * world, "parallelism": f"dp{world}"},
                "step_mfma_frac": round(value * TRAIN_GFLOP_PER_CLIP * 1e9 / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
                "final_loss": round(final_loss, 4), "hipgraph": not args.no_graph,
-               "roofline": roofline}
+               "roofline": roofline, "roofline_second": roofline2}
         if cq_rec:
             # the CQAttention score kernel (north-star "attention score/softmax/context-gather"): algorithmic
             # bytes = read long + short operand, write both probability matrices (bf16); flops = the QK^T contraction

@@ -26,6 +26,12 @@ traffic = {"kernel": "gemm_bf16_dma_kernel<false,false,64,2,{4|5}> (NT), all lau
            "launches": nf, "FETCH_SIZE_KB": round(f, 2), "WRITE_SIZE_KB": round(w, 2),
            "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
            "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+m2 = r"gemm_bf16_dma2_kernel"
+nf2, f2 = pmc("FETCH_SIZE", m2); nw2, w2 = pmc("WRITE_SIZE", m2)
+if nf2:
+    traffic["merged"] = {"kernel": "gemm_bf16_dma2_kernel<{4|5}> (dW slabs + dX + previous layer's slab reduction), all launches of one train step",
+                         "launches": nf2, "FETCH_SIZE_KB": round(f2, 2), "WRITE_SIZE_KB": round(w2, 2),
+                         "hbm_bytes_per_launch": int((2 * f2 + w2) * 1024)}
 json.dump(traffic, open(os.path.join(P, "gemm_traffic.json"), "w"), indent=1)
 with open(os.path.join(P, f"{tag}_summary.md"), "w") as o:
     o.write(f"# Round 1, {tag} -- rocprofv3 --kernel-trace --stats of the default bench (hipGraph replay)\n\n")

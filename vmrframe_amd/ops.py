@@ -21,6 +21,7 @@ from . import _lib as L
 
 NO_DROP = (0.0, 0, None)
 GEMM_HOOK = None   # bench.py: callable(launch, M, N, K, ta, tb, Z, dtype) timing the launch with HIP events
+GEMM2_HOOK = None  # bench.py: callable(launch, flops) around the merged dX + dW (+ slab reduction) launches
 CQ_HOOK = None     # bench.py: callable(launch, B, Ll, Ls, D) around the CQAttention score kernel
 # Optional side stream for the weight-gradient GEMMs (dW = dY^T.X).  They are off the backward's
 # critical path (only the optimizer needs them), so the trainer lets them run beside the dX chain:
@@ -90,30 +91,40 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
     d.drop_step = _ptr(drop[2])
     d.bias2, d.bias_scale, d.res_div = _ptr(bias2), bias_scale, res_div
     d.a_colsum = _ptr(a_colsum)
-    if GEMM_HOOK is not None:
-        flush_pending_gemm()
-        GEMM_HOOK(lambda: L.check(L.lib().vmr_gemm(C.byref(d), L.stream_ptr()), "vmr_gemm"), M, N, K, ta, tb,
-                  Z1 * Z2, dtype)
-        return
+    def single(desc=d):
+        L.check(L.lib().vmr_gemm(C.byref(desc), L.stream_ptr()), "vmr_gemm")
+
     if defer and MERGE_DX_DW:
         # held back: the next split-K slab product (the layer's weight gradient) takes it along in ONE launch
         flush_pending_gemm()
-        _PENDING_GEMM = (d, (A, B, Cmat, bias, residual, aux, rowscale, bias2, a_colsum, drop))
+        _PENDING_GEMM = (d, (A, B, Cmat, bias, residual, aux, rowscale, bias2, a_colsum, drop),
+                         (2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)))
         return
     if _PENDING_GEMM is not None:
-        pd, keep = _PENDING_GEMM
+        pd, keep, (pflops, pbytes) = _PENDING_GEMM
         _PENDING_GEMM = None
         if ta and tb and splitk > 1 and (flags & L.EPI_SLAB) and Z1 * Z2 == 1:
             rj = _take_pending_reduce()
-            if rj is None:
-                L.check(L.lib().vmr_gemm2(C.byref(pd), C.byref(d), L.stream_ptr()), "vmr_gemm2")
-            else:   # the previous layer's slab reduction rides at the end of this launch
-                ws_, dst_, sk_, n_, cols_, ld_ = rj
-                L.check(L.lib().vmr_gemm2_reduce(C.byref(pd), C.byref(d), ws_.data_ptr(), dst_.data_ptr(), sk_, n_, cols_, ld_,
-                                                 L.stream_ptr()), "vmr_gemm2_reduce")
+
+            def merged():
+                if rj is None:
+                    L.check(L.lib().vmr_gemm2(C.byref(pd), C.byref(d), L.stream_ptr()), "vmr_gemm2")
+                else:   # the previous layer's slab reduction rides in this launch
+                    ws_, dst_, sk_, n_, cols_, ld_ = rj
+                    L.check(L.lib().vmr_gemm2_reduce(C.byref(pd), C.byref(d), ws_.data_ptr(), dst_.data_ptr(), sk_, n_, cols_,
+                                                     ld_, L.stream_ptr()), "vmr_gemm2_reduce")
+            if GEMM2_HOOK is not None:
+                # algorithmic bytes: dX operands + result, dW operands + fp32 slabs, the ridden reduction's slabs + RMW
+                by = pbytes + 2.0 * (M * K + N * K) + 4.0 * M * N * splitk + (0.0 if rj is None else 4.0 * rj[3] * (rj[2] + 2))
+                GEMM2_HOOK(merged, pflops + 2.0 * M * N * K, by)
+            else:
+                merged()
             return
-        L.check(L.lib().vmr_gemm(C.byref(pd), L.stream_ptr()), "vmr_gemm")
-    L.check(L.lib().vmr_gemm(C.byref(d), L.stream_ptr()), "vmr_gemm")
+        single(pd)
+    if GEMM_HOOK is not None:
+        GEMM_HOOK(single, M, N, K, ta, tb, Z1 * Z2, dtype)
+        return
+    single()
 
 
 MERGE_DX_DW = os.environ.get("VMR_MERGE_DX_DW", "1") != "0"
@@ -153,7 +164,7 @@ def splitk_reduce_later(ws, dst, sk, n, cols, ld):
     the backward pass) carries it as tail workgroups; whatever is still pending when the autograd engine finishes
     the pass is launched then (queue_callback), i.e. before anything can read the gradient arena."""
     global _PENDING_REDUCE
-    if not DEFER_SPLITK_REDUCE or GEMM_HOOK is not None or DW_SIDE_STREAM is not None or not MERGE_DX_DW:
+    if not DEFER_SPLITK_REDUCE or DW_SIDE_STREAM is not None or not MERGE_DX_DW:
         L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, n, cols, ld, L.stream_ptr()), "vmr_splitk_reduce")
         return
     global _REDUCE_CB_ARMED
@@ -173,7 +184,7 @@ def flush_pending_gemm():
     """Launch a held-back product on its own (nothing came along to share its launch)."""
     global _PENDING_GEMM
     if _PENDING_GEMM is not None:
-        pd, keep = _PENDING_GEMM
+        pd, keep, _fl = _PENDING_GEMM
         _PENDING_GEMM = None
         L.check(L.lib().vmr_gemm(C.byref(pd), L.stream_ptr()), "vmr_gemm")
 
