@@ -150,15 +150,6 @@ def flush_pending_reduce():
                 "vmr_splitk_reduce")
 
 
-_REDUCE_CB_ARMED = False
-
-
-def _reduce_cb():
-    global _REDUCE_CB_ARMED
-    _REDUCE_CB_ARMED = False
-    flush_pending_reduce()
-
-
 def splitk_reduce_later(ws, dst, sk, n, cols, ld):
     """Second stage of a split-K weight gradient: held back so that the NEXT merged dX + dW launch (the next layer of
     the backward pass) carries it as tail workgroups; whatever is still pending when the autograd engine finishes
@@ -167,16 +158,13 @@ def splitk_reduce_later(ws, dst, sk, n, cols, ld):
     if not DEFER_SPLITK_REDUCE or DW_SIDE_STREAM is not None or not MERGE_DX_DW:
         L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, n, cols, ld, L.stream_ptr()), "vmr_splitk_reduce")
         return
-    global _REDUCE_CB_ARMED
     flush_pending_reduce()
-    if not _REDUCE_CB_ARMED:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_reduce_cb)
-            _REDUCE_CB_ARMED = True
-        except RuntimeError:      # not inside a backward pass
-            L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, n, cols, ld, L.stream_ptr()),
-                    "vmr_splitk_reduce")
-            return
+    try:   # (every time, see _defer_colreduce; the callback is idempotent)
+        torch.autograd.Variable._execution_engine.queue_callback(flush_pending_reduce)
+    except RuntimeError:      # not inside a backward pass
+        L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, n, cols, ld, L.stream_ptr()),
+                "vmr_splitk_reduce")
+        return
     _PENDING_REDUCE = (ws, dst, sk, n, cols, ld)
 
 
@@ -273,8 +261,9 @@ _deferred: List[tuple] = []      # (partials tensor kept alive, out0, out1, nblo
 def _defer_colreduce(part, out0, out1, nblocks, n0, n1, slots):
     """Queue the second stage of a parameter-gradient reduction; all queued items of one backward pass run as ONE
     launch when the autograd engine finishes the pass (queue_callback), i.e. before anything can read the arena."""
-    if not _deferred:
-        torch.autograd.Variable._execution_engine.queue_callback(flush_colreduce)
+    # (queued on every call, not only the first of a pass: a pass that died half-way must not leave a state in which the
+    #  next one never flushes; the flush is idempotent)
+    torch.autograd.Variable._execution_engine.queue_callback(flush_colreduce)
     _deferred.append((part, out0, out1, int(nblocks), int(n0), int(n1), int(slots)))
 
 
