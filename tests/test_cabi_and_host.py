@@ -106,3 +106,22 @@ def test_linear_warmup_schedule_matches_transformers():
     for step in range(50):
         assert abs(opt.param_groups[0]["lr"] - f(step)) < 1e-12
         opt.step(); sch.step()
+
+
+def test_ban_map_cell_layout_matches_the_reference_masks():
+    """Row N2 host logic (no GPU): the compact cell order of ops.Map2dLayout and the C-side cell count agree with
+    the oracle's restatement of the reference's mask2d / maskij construction (sparse and dense layouts)."""
+    import numpy as np
+    from oracle import ban_map_ref as BR
+    from vmrframe_amd import _lib, ops
+    for N, pc in ((16, [3, 2, 2]), (64, [15, 8, 8]), (128, [31, 16, 16]), (128, None), (33, [4, 3]), (8, [])):
+        lay = ops.Map2dLayout(N, pc)
+        mask = BR.mask2d(pc, N).numpy()
+        assert np.array_equal(lay.mask2d_host, mask)
+        assert lay.C == int(mask.sum())
+        offs = [0] + BR.offsets(pc, N)
+        ii = np.concatenate([np.arange(0, N - o) for o in offs])
+        jj = np.concatenate([np.arange(o, N) for o in offs])
+        assert np.array_equal(lay.ii, ii) and np.array_equal(lay.jj, jj)          # the reference's maskij order
+        g = lay.grow_host
+        assert _lib.lib().vmr_map2d_cells(g.ctypes.data if g.size else None, int(g.size), N) == lay.C

@@ -325,7 +325,7 @@ int64_t count_cells(const int* grow_host, int ndiag, int N) {
 }  // namespace
 
 extern "C" int vmr_map2d_cells(const int32_t* grow_host, int ndiag, int N) {
-  if (!grow_host || ndiag < 0 || N <= 0) return -1;
+  if ((!grow_host && ndiag > 0) || ndiag < 0 || N <= 0) return -1;
   return (int)count_cells(grow_host, ndiag, N);
 }
 
