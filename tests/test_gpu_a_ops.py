@@ -106,6 +106,46 @@ def test_gemm_splitk_slabs_colsum(dev, shape):
     assert torch.equal(cs - 1, A.float().sum(0))
 
 
+@pytest.mark.parametrize("shape", [(512, 256, 256, 256, 256, 1024, 4), (9472, 1024, 128, 1024, 1024, 1024, 4),
+                                   (8192, 1024, 192, 1024, 1024, 2048, 8), (200, 256, 256, 256, 256, 1024, 4)])
+def test_gemm2_reduce_exact(dev, shape):
+    """vmr_gemm2_reduce: an x.W^T product (with bias + residual epilogue), a transposed-operand split-K slab product
+    (with the bias-gradient column sums) and the slab reduction of an EARLIER product in ONE launch -- all three
+    bit-exact on small-integer operands, for both tile heights; the last shape (M not a multiple of 8 x 16) takes the
+    library's fallback of separate launches and must give the same results."""
+    import ctypes as C
+    from vmrframe_amd import _lib as L
+    M1, N1, K1, M2, N2, K2, sk = shape
+    torch.manual_seed(M1 + K2)
+    dt = torch.bfloat16
+    A1, B1 = _ints(M1, K1, dt, dev), _ints(N1, K1, dt, dev)
+    bias = torch.randint(-2, 3, (N1,), device=dev).float()
+    res = _ints(M1, N1, dt, dev)
+    C1 = torch.empty(M1, N1, device=dev, dtype=dt)
+    A2, B2 = _ints(K2, M2, dt, dev), _ints(K2, N2, dt, dev)
+    slabs = torch.empty(sk, M2, N2, device=dev)
+    cs = torch.zeros(M2, device=dev)
+    old = torch.randint(-4, 5, (3, 96, 64), device=dev).float()          # slabs of an earlier product
+    dst = torch.ones(96, 128, device=dev)                                  # their target: a [96, 64] block inside [96, 128]
+    d1 = L.GemmDesc(); d2 = L.GemmDesc()
+    d1.A, d1.B, d1.C, d1.bias, d1.residual = A1.data_ptr(), B1.data_ptr(), C1.data_ptr(), bias.data_ptr(), res.data_ptr()
+    d1.lda, d1.ldb, d1.ldc, d1.ldr = K1, K1, N1, N1
+    d1.M, d1.N, d1.K, d1.transA, d1.transB, d1.dtype = M1, N1, K1, 0, 0, L.BF16
+    d1.flags, d1.alpha, d1.Z1, d1.Z2, d1.splitk = L.EPI_BIAS | L.EPI_RESIDUAL, 1.0, 1, 1, 1
+    d2.A, d2.B, d2.C = A2.data_ptr(), B2.data_ptr(), slabs.data_ptr()
+    d2.lda, d2.ldb, d2.ldc = M2, N2, N2
+    d2.M, d2.N, d2.K, d2.transA, d2.transB, d2.dtype = M2, N2, K2, 1, 1, L.BF16
+    d2.flags, d2.alpha, d2.Z1, d2.Z2, d2.splitk, d2.a_colsum = L.EPI_SLAB, 1.0, 1, 1, sk, cs.data_ptr()
+    L.check(L.lib().vmr_gemm2_reduce(C.byref(d1), C.byref(d2), old.data_ptr(), dst.data_ptr(), 3, 96 * 64, 64, 128,
+                                      L.stream_ptr()), "vmr_gemm2_reduce")
+    assert torch.equal(C1.float(), (A1.float() @ B1.float().t() + bias + res.float()).to(dt).float())
+    assert torch.equal(slabs.sum(0), A2.float().t() @ B2.float())
+    assert torch.equal(cs, A2.float().sum(0))
+    ref = torch.ones(96, 128, device=dev)
+    ref[:, :64] += old.sum(0)
+    assert torch.equal(dst, ref)
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_gemm_epilogue_splitk_dropout(dev, dt):
     ops = _ops()
