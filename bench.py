@@ -33,16 +33,16 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def make_cfg(a, dtype):
-    from oracle import seqpan_ref as R   # only for the attribute-dict helper + synthetic batch recipe
-    cfg = R.make_cfg(dim=a["D"], vlen=a["T"], vdim=a["V"], num_words=a["num_words"], num_chars=a["num_chars"],
+    from vmrframe_amd import synth as S    # config object + synthetic batch recipe (no oracle on the product path)
+    cfg = S.make_cfg(dim=a["D"], vlen=a["T"], vdim=a["V"], num_words=a["num_words"], num_chars=a["num_chars"],
                      droprate=a["droprate"])
     cfg.model.compute_dtype = dtype
     return cfg
 
 
 def synth(a, seed):
-    from oracle import seqpan_ref as R
-    return R.synth_batch(a["B"], a["T"], a["L"], a["V"], a["num_words"], a["num_chars"], C=a["C"], seed=seed)
+    from vmrframe_amd import synth as S
+    return S.synth_batch(a["B"], a["T"], a["L"], a["V"], a["num_words"], a["num_chars"], C=a["C"], seed=seed)
 
 
 class GemmTimer:
@@ -169,11 +169,11 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     if args.workload == "banmap":
-        from oracle import seqpan_ref as R   # (attribute-dict helper only)
+        from vmrframe_amd.synth import Cfg
         a = CFG5
         engine = V.train_engine_ProposalMap2D
         torch.manual_seed(1234)
-        cfg = R.Cfg(device=dev, dense_outputs=True, loss=R.Cfg(min_iou=a["min_iou"], max_iou=a["max_iou"]))
+        cfg = Cfg(device=dev, dense_outputs=True, loss=Cfg(min_iou=a["min_iou"], max_iou=a["max_iou"]))
         model = V.ProposalMap2D(a["F"], a["Cd"], a["N"], a["pooling"]).to(dev)
         model.base_seed = 1234 + rank
         torch.manual_seed(1234 + rank)

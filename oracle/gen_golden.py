@@ -130,7 +130,7 @@ def maxdiff(a, b):
 
 
 def case(mods, name, B, T, L, D, V, num_words, num_chars, C, seed, store_weights, hooks, mutate=None,
-         variant="SeqPAN"):
+         variant="SeqPAN", gtol=2e-3):
     cfg = R.make_cfg(dim=D, vlen=T, vdim=V, num_words=num_words, num_chars=num_chars, name=variant)
     weights = R.make_weights(cfg, seed, enc_layers=2 if variant == "BaseFast" else 4)
     batch = R.synth_batch(B, T, L, V, num_words, num_chars, C=C, seed=seed)
@@ -149,7 +149,7 @@ def case(mods, name, B, T, L, D, V, num_words, num_chars, C, seed, store_weights
              (1e-4 * gmax * np.sqrt(grads[k].size) + float(np.linalg.norm(grads[k]))) for k in grads)
     assert set(grads) == set(grads_o), set(grads) ^ set(grads_o)
     print(f"[{name}] oracle-vs-reference max abs diff {d}  worst rel grad diff {gd:.2e}")
-    assert max(d.values()) < 2e-4 and gd < 2e-3, "oracle restatement disagrees with the reference"
+    assert max(d.values()) < 2e-4 and gd < gtol, "oracle restatement disagrees with the reference"
     save = {"meta": np.array([B, T, L, D, V, num_words, num_chars, C, seed], np.int64)}
     for k, v in batch.items():
         save["in." + k] = v.numpy()
@@ -346,17 +346,70 @@ def ban_map_case():
     print("wrote g_ban_map.npz", {k: np.asarray(v).shape for k, v in out.items() if k in ("tmap", "map2d", "map2d_proj")})
 
 
+def cfg4_case(mods):
+    """BASELINE configs[3] at its real width: BaseFast, T=256, D=1024 (hd = 256 attention tiles, multi-round
+    GEMMs), B=2.  Gradient bound 4e-3 instead of 2e-3: at this width two fp32 summation orders differ by that much
+    -- the reference against ITSELF at 8 vs 1 OpenMP threads differs by 1.8e-3 relative L2 on the worst tensor
+    (predictor conv block layer 2 pointwise weight), the oracle against the reference by 2.3e-3; logits agree to 5e-6."""
+    case(mods, "g_basefast_cfg4", B=2, T=256, L=12, D=1024, V=1024, num_words=300, num_chars=40, C=8, seed=18,
+         store_weights=False, hooks=False, variant="BaseFast", gtol=4e-3)
+
+
+def labels_case():
+    """Row a27: the reference's OWN label producers -- BaseDataset.get_dist_idx / get_NER_label
+    (utils/BaseDataset.py:73-93,115-132) bound to a stub `self` carrying max_vlen, and convert_length_to_mask
+    (utils/utils.py:125-130) -- on every (s, e, clip length) of a small T plus the edge cases at a larger one
+    (s = e, span at the clip end, one-frame clips, widened start meeting widened end) -> tests/golden/g_labels.npz."""
+    import_reference()
+    bd = importlib.import_module("utils.BaseDataset")
+    uu = importlib.import_module("utils.utils")
+    cls = bd.BaseDataset
+    out = {}
+    for tag, T, triples in (
+            ("all12", 12, [(s, e, n) for n in range(1, 13) for s in range(n) for e in range(s, n)]),
+            ("edge128", 128, [(0, 0, 1), (0, 0, 128), (127, 127, 128), (0, 127, 128), (63, 64, 128), (63, 65, 128),
+                              (62, 65, 70), (5, 5, 6), (5, 6, 7), (0, 1, 2), (0, 2, 3), (100, 127, 128), (69, 69, 70),
+                              (1, 3, 64), (10, 90, 91), (30, 31, 64), (30, 32, 64), (30, 33, 64)])):
+        stub = types.SimpleNamespace(max_vlen=T)
+        tri = np.asarray(triples, np.int64)
+        dist = np.stack([cls.get_dist_idx(stub, int(s), int(e)).numpy() for s, e, _ in triples])
+        ner = np.stack([cls.get_NER_label(stub, int(s), int(e), np.zeros((int(n), 1), np.float32)).numpy()
+                        for s, e, n in triples])
+        mask = uu.convert_length_to_mask(torch.from_numpy(tri[:, 2]), max_len=T).numpy()
+        out[f"{tag}.T"] = np.int64(T)
+        out[f"{tag}.sen"] = tri
+        out[f"{tag}.label1d"] = dist
+        out[f"{tag}.ner"] = ner
+        out[f"{tag}.mask"] = mask
+        # the oracle restatement must agree before the fixture is trusted
+        for k, (s, e, n) in enumerate(triples):
+            assert np.array_equal(R.soft_boundary_labels(s, e, T), dist[k]), ("oracle soft labels != reference", s, e)
+            assert np.array_equal(R.ner_labels(s, e, n, T), ner[k]), ("oracle NER labels != reference", s, e, n)
+    np.savez_compressed(os.path.join(GOLD, "g_labels.npz"), **out)
+    print("g_labels: ok", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true")
     ap.add_argument("--only-metrics", action="store_true")
     ap.add_argument("--only-ban", action="store_true")
+    ap.add_argument("--only-labels", action="store_true")
+    ap.add_argument("--only-cfg4", action="store_true")
     args = ap.parse_args()
     torch.manual_seed(0)
     if args.only_ban:
         ban_map_case()
         return
+    if args.only_labels:
+        labels_case()
+        return
     mods = import_reference()
+    if args.only_cfg4:
+        # BASELINE configs[3] at its real width: BaseFast, T=256, D=1024 (hd = 256 attention tiles, multi-round GEMMs)
+        cfg4_case(mods)
+        return
+    labels_case()
     metrics_case(mods)
     staging_case()
     ban_map_case()
@@ -382,6 +435,7 @@ def main():
          store_weights=True, hooks=False, variant="BaseFast")
     case(mods, "g_basefast", B=4, T=256, L=12, D=256, V=1024, num_words=300, num_chars=40, C=8, seed=17,
          store_weights=False, hooks=False, variant="BaseFast")
+    cfg4_case(mods)
     if args.time:
         time_both(mods)
 

@@ -21,7 +21,7 @@ seen = collections.Counter()
 orig = ops.gemm
 def spy(A, B, Cm, M, N, K, ta, tb, *args, **kw):
     if ta and tb:
-        merged = ops._PENDING_GEMM is not None and kw.get("splitk", 1) > 1 and (kw.get("flags", 0) & ops.L.EPI_SLAB)
+        merged = kw.get("held") is not None and kw.get("splitk", 1) > 1 and (kw.get("flags", 0) & ops.L.EPI_SLAB)
         seen[("merged" if merged else "alone", M, N, K, kw.get("splitk", 1), bool(kw.get("flags", 0) & ops.L.EPI_SLAB))] += 1
     elif kw.get("defer"):
         seen[("dX held", M, N, K, 1, False)] += 1

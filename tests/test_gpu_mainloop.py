@@ -1,0 +1,107 @@
+"""GPU: the drop-in boundary driven the way the reference's main.py drives it.
+
+A loop shaped like main.py:20-32,75-136 -- everything resolved BY NAME with eval() after a star import, the
+optimizer built from named_parameters() exactly as utils/utils.py:87-97 does (torch.optim.AdamW, two decay groups,
+transformers' linear warm-up), loss.item() / zero_grad / backward / clip_grad_norm_ / step / scheduler.step,
+infer_<Name> -> append_ious -> get_i345_mi, output["consume_time"] summed, a test pass in eval mode,
+save_best_model's torch.save(state_dict) and build_load_model's load_state_dict -- runs against the package
+unchanged.  Nothing here uses the package's own optimizer or trainer: this is the reference's control flow."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from vmrframe_amd import *            # noqa: F401,F403   (reference main.py:16 `from models import *`)
+from vmrframe_amd import synth as S
+
+pytestmark = pytest.mark.gpu
+
+
+def build_optimizer_and_scheduler(model, configs):
+    """Same construction as reference utils/utils.py:87-97."""
+    from transformers import get_linear_schedule_with_warmup
+    no_decay = ["bias", "layer_norm", "LayerNorm"]
+    groups = [{"params": [p for n, p in model.named_parameters() if not any(nd in n for nd in no_decay)],
+               "weight_decay": 0.01},
+              {"params": [p for n, p in model.named_parameters() if any(nd in n for nd in no_decay)],
+               "weight_decay": 0.0}]
+    optimizer = torch.optim.AdamW(groups, lr=configs.train.lr)
+    scheduler = get_linear_schedule_with_warmup(optimizer, configs.train.num_train_steps * configs.train.warmup_proportion,
+                                                configs.train.num_train_steps)
+    return optimizer, scheduler
+
+
+@pytest.mark.parametrize("name,dtype", [("SeqPAN", "fp32"), ("SeqPAN", "bf16"), ("BaseFast", "bf16")])
+def test_main_py_shaped_loop(tmp_path, name, dtype):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    B, T, L, D, Vd, nw, nc = 6, 32, 8, 64, 40, 50, 20
+    torch.manual_seed(1234)                                               # main.py:41,48 set_seed_config
+    configs = S.make_cfg(dim=D, vlen=T, vdim=Vd, num_words=nw, num_chars=nc, droprate=0.2, name=name, lr=1e-3,
+                         clip_norm=1.0, warmup_proportion=0.1, epochs=2, batch_size=B)
+    configs.model.compute_dtype = dtype
+    configs.device = torch.device("cuda")                                 # main.py:50
+    word_vector = np.random.default_rng(0).standard_normal((nw - 2, 300)).astype(np.float32)
+    train_loader = [(S.synth_batch(B, T, L, Vd, nw, nc, C=6, seed=100 + i), None) for i in range(4)]
+    test_loader = [(S.synth_batch(B, T, L, Vd, nw, nc, C=6, seed=200 + i), None) for i in range(2)]
+    configs.train.num_train_steps = len(train_loader) * configs.train.epochs     # main.py:66
+
+    model = eval(configs.model.name)(configs, word_vector)                # main.py:21
+    model = model.to(configs.device)
+    optimizer, scheduler = build_optimizer_and_scheduler(model, configs)  # main.py:78
+    no_grad_names = None
+    epoch_losses, mious = [], []
+    ckpt = os.path.join(tmp_path, "best_{}.pkl".format(configs.model.name))
+    for epoch in range(configs.train.epochs):
+        totle_time, ious, losses = 0, [], []
+        model.train()
+        for inputbatch, records in train_loader:
+            train_engine = eval("train_engine_" + configs.model.name)    # main.py:87
+            loss, output = train_engine(model, inputbatch, configs, "train")
+            losses.append(loss.item())
+            optimizer.zero_grad()
+            loss.backward()
+            nn.utils.clip_grad_norm_(model.parameters(), configs.train.clip_norm)
+            optimizer.step()
+            scheduler.step()
+            infer_fun = eval("infer_" + configs.model.name)               # main.py:99
+            props_frac = infer_fun(output, configs)
+            assert isinstance(props_frac, np.ndarray) and props_frac.shape == (B, 2)
+            ious = append_ious(ious, inputbatch["se_fracs"], props_frac)  # noqa: F405
+            totle_time += output["consume_time"]
+            if no_grad_names is None:
+                no_grad_names = sorted(n for n, p in model.named_parameters() if p.requires_grad and p.grad is None)
+        r1i3, r1i5, r1i5, r1i7, mi = get_i345_mi(ious)                    # noqa: F405
+        assert all(np.isfinite(losses)) and totle_time > 0 and 0.0 <= mi <= 100.0
+        epoch_losses.append(float(np.mean(losses)))
+        model.eval()
+        ious = []
+        for inputbatch, records in test_loader:
+            loss, output = eval("train_engine_" + configs.model.name)(model, inputbatch, configs, "test")
+            assert np.isfinite(loss.item())
+            ious = append_ious(ious, inputbatch["se_fracs"], eval("infer_" + configs.model.name)(output, configs))  # noqa: F405
+        mious.append(get_i345_mi(ious)[-1])                               # noqa: F405
+        torch.save(model.state_dict(), ckpt)                              # utils/utils.py:208-215
+    assert epoch_losses[1] < epoch_losses[0], epoch_losses                # it trains under the reference's optimizer
+    # the reference's unused parameters never receive a gradient (AdamW skips them): 20 for SeqPAN
+    if name == "SeqPAN":
+        assert len(no_grad_names) == 20, no_grad_names
+    else:
+        assert any(n.startswith("dual_attention_block_1") for n in no_grad_names)
+    # --eval: build_load_model(..., checkpoint) (main.py:26-28) on a fresh instance reproduces the trained model
+    sd = torch.load(ckpt)
+    assert len(sd) == 192 and all(isinstance(v, torch.Tensor) for v in sd.values())
+    model2 = eval(configs.model.name)(configs, np.zeros_like(word_vector)).to(configs.device)
+    model2.load_state_dict(sd)
+    model.eval(); model2.eval()
+    inputbatch = test_loader[0][0]
+    gum = S.gumbel_noise(B, T, 9).to(configs.device)     # (the match head samples Gumbel noise even in eval mode)
+    model.gumbel_override = model2.gumbel_override = gum
+    with torch.no_grad():
+        l1, o1 = eval("train_engine_" + configs.model.name)(model, inputbatch, configs, "test")
+        l2, o2 = eval("train_engine_" + configs.model.name)(model2, inputbatch, configs, "test")
+    for k in ("slogits", "elogits", "match_score"):
+        assert torch.allclose(o1[k].float(), o2[k].float(), atol=1e-5, rtol=1e-5), k
+    assert np.array_equal(eval("infer_" + configs.model.name)(o1, configs), eval("infer_" + configs.model.name)(o2, configs))

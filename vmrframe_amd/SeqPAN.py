@@ -266,7 +266,8 @@ class SeqPAN(nn.Module):
         for l in range(nlayers):
             u, x = ops.ln_dwconv(x, self.P(f"{prefix}.layer_norms.{l}.weight"),
                                  self.P(f"{prefix}.layer_norms.{l}.bias"),
-                                 self.P(f"{prefix}.depthwise_separable_conv.{l}.0.weight"), 1e-6, segs, tee=True)
+                                 self.P(f"{prefix}.depthwise_separable_conv.{l}.0.weight"), 1e-6, segs, tee=True,
+                                 cache=self._cache)
             x = ops.linear(u, self.P(f"{prefix}.depthwise_separable_conv.{l}.1.weight"),
                            self.P(f"{prefix}.depthwise_separable_conv.{l}.1.bias"), self._cache,
                            relu=True, drop=dc.next(f"{prefix}.{l}"), residual=x)
@@ -389,9 +390,13 @@ class SeqPAN(nn.Module):
     # -- forward --------------------------------------------------------------
     def forward(self, word_ids, char_ids, vfeat_in, vmask, tmask):
         L.require_gpu(word_ids, char_ids, vfeat_in, vmask, tmask)
-        if self.sync_timing:
-            torch.cuda.synchronize()      # reference models/SeqPAN.py:51-52 self-timing
+        # the reference's synchronised self-timing (models/SeqPAN.py:51-52,85-87); a device-wide sync is illegal while
+        # a stream is being captured into a hipGraph, so it is skipped there (consume_time is then host enqueue time)
+        sync = self.sync_timing and not torch.cuda.is_current_stream_capturing()
+        if sync:
+            torch.cuda.synchronize()
         start = time.time()
+        self._cache.state.reset()         # partials a dead backward pass left behind must not reach this one
         cdt, D = self.compute_dtype, self.dim
         B, T = vmask.shape
         Lq = tmask.shape[1]
@@ -453,7 +458,7 @@ class SeqPAN(nn.Module):
         elogits = self._head(eh, "predictor.end_dense").reshape(B, T)
         self.last_drop_sites = dc.sites
 
-        if self.sync_timing:
+        if sync:
             torch.cuda.synchronize()
         consume_time = time.time() - start
         return {"slogits": slogits, "elogits": elogits, "vmask": vmask, "match_score": match_score,

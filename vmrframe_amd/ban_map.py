@@ -81,6 +81,7 @@ class ProposalMap2D(nn.Module):
         self._seed_calls += 1
         dc = ops.DropCtx(self.droprate, self.training, self.base_seed + 7919 * self._seed_calls, self.drop_step)
         c = self._cache
+        c.state.reset()                  # partials of a dead backward pass must not reach this one
         Wm, bm = self.map2d_proj[0].weight, self.map2d_proj[0].bias
         hb = ops.to_dtype(hidden_b.reshape(B * N, F), cdt)
         x = ops.to_dtype(fuse_feature.reshape(B * N, F), cdt).view(B, N, F)

@@ -1120,6 +1120,8 @@ extern "C" int vmr_gemm2_reduce(const vmr_gemm_t* p1, const vmr_gemm_t* p2, cons
            (!(g.flags & VMR_EPI_ROWSCALE) || g.rowscale);
   };
   bool ok = g_merge && basic(g1) && basic(g2);
+  // the ridden reduction moves float4s: a misaligned job takes the fallback, where vmr_splitk_reduce reports it
+  ok = ok && (!slab || (aligned16(slab) && aligned16(dst)));
   // problem 1: row-major operands, no split; 128- or 160-row tiles exactly as vmr_gemm would pick, single round
   int mt1 = 4, tm1 = 0;
   const int tn1 = g1.N / BN;

@@ -38,11 +38,30 @@ def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[s
     return {k: v[rank::world] for k, v in batch.items()}
 
 
-def broadcast_parameters(model: torch.nn.Module, src: int = 0):
+def broadcast_parameters(model: torch.nn.Module, src: int = 0, optimizer=None):
+    """Every rank starts from rank `src`'s weights.  With a flat arena (optimizer given and built) that is ONE
+    broadcast of the fp32 arena plus the few parameters outside it, followed by a refresh of the compute-dtype
+    mirrors; before the arena exists, parameters are coalesced into one flat buffer per dtype."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    for p in model.parameters():
-        dist.broadcast(p.data, src)
+    arena = getattr(optimizer, "arena", None)
+    inside = set()
+    if arena is not None:
+        dist.broadcast(arena.flat_p, src)
+        inside = {id(p) for p in arena.params}
+    rest = [p for p in model.parameters() if id(p) not in inside]
+    by_dtype = {}
+    for p in rest:
+        by_dtype.setdefault(p.dtype, []).append(p)
+    for ps in by_dtype.values():
+        flat = torch.cat([p.data.reshape(-1) for p in ps])
+        dist.broadcast(flat, src)
+        o = 0
+        for p in ps:
+            p.data.copy_(flat[o:o + p.numel()].view_as(p.data))
+            o += p.numel()
+    if optimizer is not None and hasattr(optimizer, "sync_mirrors"):
+        optimizer.sync_mirrors()
 
 
 class GradReducer:

@@ -72,10 +72,91 @@ class DropCtx:
 # ---------------------------------------------------------------------------
 # raw GEMM launch
 # ---------------------------------------------------------------------------
+class HeldGemm:
+    """A product whose launch is held back by its caller so that a following split-K slab product (the same layer's
+    weight gradient) can take it along in ONE launch (vmr_gemm2).  Purely local to one `_Linear.backward` call."""
+    __slots__ = ("desc", "keep", "flops", "nbytes")
+
+    def __init__(self, desc, keep, flops, nbytes):
+        self.desc, self.keep, self.flops, self.nbytes = desc, keep, flops, nbytes
+
+    def launch(self):
+        L.check(L.lib().vmr_gemm(C.byref(self.desc), L.stream_ptr()), "vmr_gemm")
+
+
+class PassState:
+    """Launches that ONE model's backward pass has held back: the split-K second stage that rides in the next layer's
+    merged launch, and the parameter-gradient column reductions that run as one batched launch when the autograd
+    engine finishes the pass.  One instance per model (it hangs off the model's WeightCache), so two models -- or a
+    model whose previous backward died half-way -- never see each other's partials."""
+
+    def __init__(self):
+        self.pending_reduce = None   # (slabs kept alive, dst, nsplit, n, cols, ld_dst)
+        self.deferred: List[tuple] = []   # (partials kept alive, out0, out1, nblocks, n0, n1, slots)
+
+    def reset(self):
+        """Drop (never launch) whatever a dead backward pass left behind: stale partials must not be added into the
+        freshly zeroed gradient arena.  Called at every forward and from FlatAdamW.zero_grad()."""
+        self.pending_reduce = None
+        self.deferred.clear()
+
+    # -- split-K second stage ---------------------------------------------------
+    def take_reduce(self):
+        rj, self.pending_reduce = self.pending_reduce, None
+        return rj
+
+    def flush_reduce(self):
+        rj = self.take_reduce()
+        if rj is not None:
+            ws_, dst_, sk_, n_, cols_, ld_ = rj
+            L.check(L.lib().vmr_splitk_reduce(ws_.data_ptr(), dst_.data_ptr(), sk_, n_, cols_, ld_, L.stream_ptr()),
+                    "vmr_splitk_reduce")
+
+    def reduce_later(self, ws, dst, sk, n, cols, ld):
+        """Second stage of a split-K weight gradient: held back so that the NEXT merged dX + dW launch (the next layer
+        of the backward pass) carries it as extra workgroups; whatever is still pending when the autograd engine
+        finishes the pass is launched then (queue_callback), i.e. before anything can read the gradient arena."""
+        if not DEFER_SPLITK_REDUCE or DW_SIDE_STREAM is not None or not MERGE_DX_DW:
+            L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, n, cols, ld, L.stream_ptr()), "vmr_splitk_reduce")
+            return
+        self.flush_reduce()
+        try:   # (every time, see defer_colreduce; the callback is idempotent)
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush_reduce)
+        except RuntimeError:      # not inside a backward pass
+            L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, n, cols, ld, L.stream_ptr()),
+                    "vmr_splitk_reduce")
+            return
+        self.pending_reduce = (ws, dst, sk, n, cols, ld)
+
+    # -- parameter-gradient column reductions -------------------------------------
+    def defer_colreduce(self, part, out0, out1, nblocks, n0, n1, slots):
+        """Queue the second stage of a parameter-gradient reduction; all queued items of one backward pass run as ONE
+        launch when the autograd engine finishes the pass (queue_callback), before anything can read the arena."""
+        # (queued on every call, not only the first of a pass: the flush is idempotent)
+        torch.autograd.Variable._execution_engine.queue_callback(self.flush_colreduce)
+        self.deferred.append((part, out0, out1, int(nblocks), int(n0), int(n1), int(slots)))
+
+    def flush_colreduce(self):
+        if not self.deferred:
+            return
+        items = (L.ColReduceItem * len(self.deferred))()
+        for it, (part, o0, o1, nb, n0, n1, sl) in zip(items, self.deferred):
+            it.part, it.out0, it.out1 = part.data_ptr(), o0.data_ptr(), o1.data_ptr()
+            it.nblocks, it.n0, it.n1, it.slots = nb, n0, n1, sl
+        n = len(self.deferred)
+        try:
+            L.check(L.lib().vmr_colreduce_batched(items, n, L.stream_ptr()), "vmr_colreduce_batched")
+        finally:
+            self.deferred.clear()
+
+
 def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=None, residual=None, aux=None,
          ldr=0, rowscale=None, alpha=1.0, Z1=1, Z2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1, drop=NO_DROP,
-         bias2=None, bias_scale=1.0, res_div=1, a_colsum=None, defer=False):
-    global _PENDING_GEMM
+         bias2=None, bias_scale=1.0, res_div=1, a_colsum=None, hold=False, held: Optional[HeldGemm] = None,
+         state: Optional[PassState] = None):
+    """One vmr_gemm launch.  hold=True: do not launch, return a HeldGemm.  held=<HeldGemm>: launch the held product
+    too -- in ONE launch with this one when this is a split-K slab product (vmr_gemm2; `state`'s pending slab
+    reduction then rides along as well), otherwise on its own just before this one."""
     d = L.GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cmat.data_ptr()
     d.bias, d.residual, d.aux, d.rowscale = _ptr(bias), _ptr(residual), _ptr(aux), _ptr(rowscale)
@@ -91,90 +172,45 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
     d.drop_step = _ptr(drop[2])
     d.bias2, d.bias_scale, d.res_div = _ptr(bias2), bias_scale, res_div
     d.a_colsum = _ptr(a_colsum)
+
     def single(desc=d):
         L.check(L.lib().vmr_gemm(C.byref(desc), L.stream_ptr()), "vmr_gemm")
 
-    if defer and MERGE_DX_DW:
-        # held back: the next split-K slab product (the layer's weight gradient) takes it along in ONE launch
-        flush_pending_gemm()
-        _PENDING_GEMM = (d, (A, B, Cmat, bias, residual, aux, rowscale, bias2, a_colsum, drop),
-                         (2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)))
-        return
-    if _PENDING_GEMM is not None:
-        pd, keep, (pflops, pbytes) = _PENDING_GEMM
-        _PENDING_GEMM = None
-        if ta and tb and splitk > 1 and (flags & L.EPI_SLAB) and Z1 * Z2 == 1:
-            rj = _take_pending_reduce()
+    if hold:
+        return HeldGemm(d, (A, B, Cmat, bias, residual, aux, rowscale, bias2, a_colsum, drop),
+                        2.0 * M * N * K, 2.0 * (M * K + N * K + M * N))
+    if held is not None and not (ta and tb and splitk > 1 and (flags & L.EPI_SLAB) and Z1 * Z2 == 1):
+        held.launch()           # not a slab product: nothing to share, the held product goes first on its own
+        held = None
+    if held is not None:
+        pd = held.desc
+        rj = state.take_reduce() if state is not None else None
 
-            def merged():
-                if rj is None:
-                    L.check(L.lib().vmr_gemm2(C.byref(pd), C.byref(d), L.stream_ptr()), "vmr_gemm2")
-                else:   # the previous layer's slab reduction rides in this launch
-                    ws_, dst_, sk_, n_, cols_, ld_ = rj
-                    L.check(L.lib().vmr_gemm2_reduce(C.byref(pd), C.byref(d), ws_.data_ptr(), dst_.data_ptr(), sk_, n_, cols_,
-                                                     ld_, L.stream_ptr()), "vmr_gemm2_reduce")
-            if GEMM2_HOOK is not None:
-                # algorithmic bytes: dX operands + result, dW operands + fp32 slabs, the ridden reduction's slabs + RMW
-                by = pbytes + 2.0 * (M * K + N * K) + 4.0 * M * N * splitk + (0.0 if rj is None else 4.0 * rj[3] * (rj[2] + 2))
-                GEMM2_HOOK(merged, pflops + 2.0 * M * N * K, by)
-            else:
-                merged()
-            return
-        single(pd)
+        def merged():
+            if rj is None:
+                L.check(L.lib().vmr_gemm2(C.byref(pd), C.byref(d), L.stream_ptr()), "vmr_gemm2")
+            else:   # the previous layer's slab reduction rides in this launch
+                ws_, dst_, sk_, n_, cols_, ld_ = rj
+                L.check(L.lib().vmr_gemm2_reduce(C.byref(pd), C.byref(d), ws_.data_ptr(), dst_.data_ptr(), sk_, n_, cols_,
+                                                 ld_, L.stream_ptr()), "vmr_gemm2_reduce")
+        if GEMM2_HOOK is not None:
+            # algorithmic bytes (the minimum any schedule must move): dX operands + result, dW operands + ONE fp32
+            # [M, N] result.  The split-K slabs and the ridden reduction's read-modify-write are this
+            # implementation's overhead and show up in `traffic`, not here.
+            GEMM2_HOOK(merged, held.flops + 2.0 * M * N * K, held.nbytes + 2.0 * (M * K + N * K) + 4.0 * M * N)
+        else:
+            merged()
+        return None
     if GEMM_HOOK is not None:
         GEMM_HOOK(single, M, N, K, ta, tb, Z1 * Z2, dtype)
-        return
+        return None
     single()
+    return None
 
 
 MERGE_DX_DW = os.environ.get("VMR_MERGE_DX_DW", "1") != "0"
 GROUP_DW = os.environ.get("VMR_GROUP_DW", "1") != "0"      # one weight-gradient product per grouped projection
-_PENDING_GEMM = None     # (descriptor, tensors kept alive) of a deferred dX product
-
-
-_PENDING_REDUCE = None   # (slabs kept alive, dst, nsplit, n, cols, ld_dst) of a split-K second stage not launched yet
 DEFER_SPLITK_REDUCE = os.environ.get("VMR_DEFER_SPLITK_REDUCE", "1") != "0"
-
-
-def _take_pending_reduce():
-    global _PENDING_REDUCE
-    rj, _PENDING_REDUCE = _PENDING_REDUCE, None
-    return rj
-
-
-def flush_pending_reduce():
-    rj = _take_pending_reduce()
-    if rj is not None:
-        ws_, dst_, sk_, n_, cols_, ld_ = rj
-        L.check(L.lib().vmr_splitk_reduce(ws_.data_ptr(), dst_.data_ptr(), sk_, n_, cols_, ld_, L.stream_ptr()),
-                "vmr_splitk_reduce")
-
-
-def splitk_reduce_later(ws, dst, sk, n, cols, ld):
-    """Second stage of a split-K weight gradient: held back so that the NEXT merged dX + dW launch (the next layer of
-    the backward pass) carries it as tail workgroups; whatever is still pending when the autograd engine finishes
-    the pass is launched then (queue_callback), i.e. before anything can read the gradient arena."""
-    global _PENDING_REDUCE
-    if not DEFER_SPLITK_REDUCE or DW_SIDE_STREAM is not None or not MERGE_DX_DW:
-        L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, n, cols, ld, L.stream_ptr()), "vmr_splitk_reduce")
-        return
-    flush_pending_reduce()
-    try:   # (every time, see _defer_colreduce; the callback is idempotent)
-        torch.autograd.Variable._execution_engine.queue_callback(flush_pending_reduce)
-    except RuntimeError:      # not inside a backward pass
-        L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, n, cols, ld, L.stream_ptr()),
-                "vmr_splitk_reduce")
-        return
-    _PENDING_REDUCE = (ws, dst, sk, n, cols, ld)
-
-
-def flush_pending_gemm():
-    """Launch a held-back product on its own (nothing came along to share its launch)."""
-    global _PENDING_GEMM
-    if _PENDING_GEMM is not None:
-        pd, keep, _fl = _PENDING_GEMM
-        _PENDING_GEMM = None
-        L.check(L.lib().vmr_gemm(C.byref(pd), L.stream_ptr()), "vmr_gemm")
 
 
 def mm(a: torch.Tensor, b: torch.Tensor, ta: int, tb: int, *, out=None, out_f32=False, **kw) -> torch.Tensor:
@@ -187,8 +223,8 @@ def mm(a: torch.Tensor, b: torch.Tensor, ta: int, tb: int, *, out=None, out_f32=
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
     flags = kw.pop("flags", 0) | (L.EPI_OUT_F32 if (out_f32 and dt != L.F32) else 0)
-    gemm(a, b, out, M, N, K, ta, tb, a.stride(0), b.stride(0), out.stride(0), dtype=dt, flags=flags, **kw)
-    return out
+    h = gemm(a, b, out, M, N, K, ta, tb, a.stride(0), b.stride(0), out.stride(0), dtype=dt, flags=flags, **kw)
+    return (out, h) if kw.get("hold") else out
 
 
 def mm_few_tiles(a: torch.Tensor, b: torch.Tensor, ta: int, tb: int) -> Optional[torch.Tensor]:
@@ -255,30 +291,6 @@ def main_grad(p):
 # ---------------------------------------------------------------------------
 DEFER_COLREDUCE = os.environ.get("VMR_DEFER_COLREDUCE", "1") != "0"
 USE_WT = os.environ.get("VMR_USE_WT", "1") != "0"     # dX products on the K-major weight copies
-_deferred: List[tuple] = []      # (partials tensor kept alive, out0, out1, nblocks, n0, n1, slots)
-
-
-def _defer_colreduce(part, out0, out1, nblocks, n0, n1, slots):
-    """Queue the second stage of a parameter-gradient reduction; all queued items of one backward pass run as ONE
-    launch when the autograd engine finishes the pass (queue_callback), i.e. before anything can read the arena."""
-    # (queued on every call, not only the first of a pass: a pass that died half-way must not leave a state in which the
-    #  next one never flushes; the flush is idempotent)
-    torch.autograd.Variable._execution_engine.queue_callback(flush_colreduce)
-    _deferred.append((part, out0, out1, int(nblocks), int(n0), int(n1), int(slots)))
-
-
-def flush_colreduce():
-    if not _deferred:
-        return
-    items = (L.ColReduceItem * len(_deferred))()
-    for it, (part, o0, o1, nb, n0, n1, sl) in zip(items, _deferred):
-        it.part, it.out0, it.out1 = part.data_ptr(), o0.data_ptr(), o1.data_ptr()
-        it.nblocks, it.n0, it.n1, it.slots = nb, n0, n1, sl
-    n = len(_deferred)
-    try:
-        L.check(L.lib().vmr_colreduce_batched(items, n, L.stream_ptr()), "vmr_colreduce_batched")
-    finally:
-        _deferred.clear()
 
 
 # ---------------------------------------------------------------------------
@@ -292,6 +304,7 @@ class WeightCache:
 
     def __init__(self):
         self.store = {}
+        self.state = PassState()     # the owning model's held-back backward launches
 
     def clear(self):
         """Forget the cast copies (the masters changed); mirror-backed entries stay valid because
@@ -319,6 +332,10 @@ class WeightCache:
             # (optim.FlatArena): a group laid out back to back is used in place, no cast launch
             mirrors = [getattr(p, "_vmr_w16", None) for p in params]
             if all(m is not None for m in mirrors):
+                if any(p._version != getattr(p, "_vmr_synced_version", p._version) for p in params):
+                    # a master was edited in place behind the optimizer's back (load_state_dict, p.copy_()): the
+                    # mirror the AdamW kernel maintains -- and the K-major copies -- have not seen it yet
+                    params[0]._vmr_arena.sync_mirrors()
                 K = mirrors[0].numel() // mirrors[0].shape[0]
                 ok = K % 8 == 0 and kpad in (0, K)
                 for a_, b_ in zip(mirrors[:-1], mirrors[1:]):
@@ -458,6 +475,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x, W, aux if aux is not None else (ybuf if relu else None), rowscale)
         ctx.meta = (relu, drop, bias is not None, residual is not None, [tuple(w.shape) for w in weights])
         ctx.weights = weights
+        ctx.state = cache.state
         ctx.bias_param = bias
         ctx.bias2_param, ctx.bias_scale = bias2, bias_scale
         ctx.kslice, ctx.res_div, ctx.res_pre = kslice, res_div, res_pre
@@ -523,6 +541,8 @@ class _Linear(torch.autograd.Function):
             if ctx.res_div > 1:
                 dres = dzb.view(M // ctx.res_div, ctx.res_div, Np).sum(1, dtype=torch.float32).to(dzb.dtype)
         dx = None
+        held = None       # the dX product, held back until the first weight-gradient slab product takes it along
+        state = ctx.state
         if ctx.needs_input_grad[0]:
             few = mm_few_tiles(dz, W, 0, 1)
             if few is not None:
@@ -536,13 +556,15 @@ class _Linear(torch.autograd.Function):
                     Wt = None                # (K-padded inputs use a padded cast copy of W, not the arena mirror)
                 Bm, tb = (Wt, 0) if Wt is not None else (W, 1)
                 # (held back: launched together with the first weight-gradient slab product below, vmr_gemm2)
-                hold = Wt is not None and DW_SIDE_STREAM is None
+                hold = Wt is not None and DW_SIDE_STREAM is None and MERGE_DX_DW
                 if dxtra is not None:        # tee: dX = dz.W + (gradient of x's other consumer), one epilogue
                     dxtra = dxtra.contiguous()
                     assert dxtra.shape == x.shape and dxtra.dtype == dz.dtype
-                    dx = mm(dz, Bm, 0, tb, flags=L.EPI_RESIDUAL, residual=dxtra, ldr=dxtra.stride(0), defer=hold)
+                    dx = mm(dz, Bm, 0, tb, flags=L.EPI_RESIDUAL, residual=dxtra, ldr=dxtra.stride(0), hold=hold)
                 else:
-                    dx = mm(dz, Bm, 0, tb, defer=hold)                                          # [M,N] . [N,Kp]
+                    dx = mm(dz, Bm, 0, tb, hold=hold)                                          # [M,N] . [N,Kp]
+                if hold:
+                    dx, held = dx
         elif dxtra is not None:
             dx = dxtra
         # dW = dz^T . x  -> fp32 [N,Kp], split-K over the M (token) dimension
@@ -572,7 +594,7 @@ class _Linear(torch.autograd.Function):
                     n = shp[0]
                     a = dz[:, r:r + n]
                     # (a held-back single-round dX product will share this launch: fewer, longer splits)
-                    merged = _PENDING_GEMM is not None and _cdiv(M, 160) * _cdiv(Kp, 128) <= 512
+                    merged = held is not None and _cdiv(M, 160) * _cdiv(Kp, 128) <= 512
                     sk_ = splitk_for(n, Kp, M, SPLITK_TARGET_MERGED if merged else 0)
                     if ks is not None:       # gradient of the column slice, in place inside the full matrix
                         g_ = g_.view(n, kf)[:, ks[0]:ks[1]]
@@ -581,18 +603,19 @@ class _Linear(torch.autograd.Function):
                         # every workgroup of a single-round grid land together and run far below HBM speed
                         ws = torch.empty(sk_, n, Kp, device=dy.device, dtype=torch.float32)
                         gemm(a, x, ws, n, Kp, M, 1, 1, a.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_SLAB,
-                             splitk=sk_, a_colsum=db[r:r + n] if colsum_in_gemm else None)
-                        splitk_reduce_later(ws, g_, sk_, n * Kp, Kp, kf)
+                             splitk=sk_, a_colsum=db[r:r + n] if colsum_in_gemm else None, held=held, state=state)
+                        state.reduce_later(ws, g_, sk_, n * Kp, Kp, kf)
                     else:
                         gemm(a, x, g_, n, Kp, M, 1, 1, a.stride(0), x.stride(0), kf, dtype=dt, flags=L.EPI_ACCUM,
-                             splitk=sk_, a_colsum=db[r:r + n] if colsum_in_gemm else None)
+                             splitk=sk_, a_colsum=db[r:r + n] if colsum_in_gemm else None, held=held)
+                    held = None
                     r += n
             if db is not None and Np != N:
                 db = db[:N]
-            flush_pending_gemm()
             return (dx, *_bias_grads(db, bgrad, has_b2, ctx.bias_scale), None, dres, None, None, None, None, None, None,
                     None, None, *([None] * len(wshapes)))
-        flush_pending_gemm()
+        if held is not None:
+            held.launch()
         if sk > 1:
             dW = torch.zeros(N, Kp, device=dy.device, dtype=torch.float32)
             gemm(dz, x, dW, N, Kp, M, 1, 1, dz.stride(0), x.stride(0), Kp, dtype=dt, flags=L.EPI_ACCUM, splitk=sk)
@@ -943,6 +966,7 @@ class _LayerNorm(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.meta = (drop, S, None if pos is None else tuple(pos.shape))
         ctx.params = (gamma, beta)
+        ctx.state = cache.state
         if tee:
             return y, x.view_as(x)
         return y
@@ -969,7 +993,7 @@ class _LayerNorm(torch.autograd.Function):
                                                        rstd.data_ptr(), _ptr(dres), dx.data_ptr(), _ptr(dpos), ws.data_ptr(),
                                                        S, rows, D, L.dtype_code(x), drop[0], drop[1], _ptr(drop[2]),
                                                        C.byref(nb), L.stream_ptr()), "vmr_layernorm_bwd_deferred")
-            _defer_colreduce(ws, dg, db, nb.value, D, D, 512 if D <= 512 else (1024 if D <= 1024 else 2048))
+            ctx.state.defer_colreduce(ws, dg, db, nb.value, D, D, 512 if D <= 512 else (1024 if D <= 1024 else 2048))
             return dx, None, None, None, dpos, None, None, None, None
         L.check(L.lib().vmr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                           rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
@@ -992,11 +1016,12 @@ class _LnDwConv(torch.autograd.Function):
     sequence groups stored back to back (video clips, then query sentences)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, w, eps, segs, tee=False):
+    def forward(ctx, x, gamma, beta, w, eps, segs, tee=False, cache=None):
         L.require_gpu(x)
         x = x.contiguous()
         rows, D = x.shape
         assert rows == sum(b * s for b, s in segs)
+        ctx.state = None if cache is None else cache.state
         u = torch.empty_like(x)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
@@ -1028,7 +1053,7 @@ class _LnDwConv(torch.autograd.Function):
         direct = mg is not None and mb is not None and mw is not None
         dw = mw if direct else torch.zeros(D, 7, device=x.device, dtype=torch.float32)
         r = 0
-        defer = direct and DEFER_COLREDUCE
+        defer = direct and DEFER_COLREDUCE and ctx.state is not None
         dx = torch.empty_like(x)
         dg = mg if direct else torch.zeros(D, device=x.device, dtype=torch.float32)
         db = mb if direct else torch.zeros_like(dg)
@@ -1043,14 +1068,14 @@ class _LnDwConv(torch.autograd.Function):
                                                      mean[r:].data_ptr(), rstd[r:].data_ptr(), w2.data_ptr(),
                                                      dn[r:].data_ptr(), wsc.data_ptr(), B1, S1, B2, S2, D, dt, C.byref(nb), st),
                         "vmr_dwconv_bwd2_deferred")
-                _defer_colreduce(wsc, dw, dw, nb.value, 7 * D, 0, 0)
+                ctx.state.defer_colreduce(wsc, dw, dw, nb.value, 7 * D, 0, 0)
                 r += B1 * S1 + B2 * S2
             wsl = torch.empty(L.ln_bwd_ws_floats(rows, D), device=x.device, dtype=torch.float32)
             L.check(lib.vmr_layernorm_bwd_deferred(dn.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                                    rstd.data_ptr(), _ptr(dres), dx.data_ptr(), None, wsl.data_ptr(), 0, rows, D,
                                                    dt, 0.0, 0, None, C.byref(nb), st), "vmr_layernorm_bwd_deferred")
-            _defer_colreduce(wsl, dg, db, nb.value, D, D, 512 if D <= 512 else (1024 if D <= 1024 else 2048))
-            return dx, None, None, None, None, None, None
+            ctx.state.defer_colreduce(wsl, dg, db, nb.value, D, D, 512 if D <= 512 else (1024 if D <= 1024 else 2048))
+            return dx, None, None, None, None, None, None, None
         ws = torch.empty(max(sum(b * ((sq + 63) // 64) for b, sq in segs) * D * 7, L.ln_bwd_ws_floats(rows, D)),
                          device=x.device,
                          dtype=torch.float32)
@@ -1064,12 +1089,14 @@ class _LnDwConv(torch.autograd.Function):
                                       _ptr(dres), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, ws.data_ptr(), 0,
                                       rows, D, dt, 0.0, 0, None, st), "vmr_layernorm_bwd")
         if direct:
-            return dx, None, None, None, None, None, None
-        return dx, dg, db, dw.reshape(wshape), None, None, None
+            return dx, None, None, None, None, None, None, None
+        return dx, dg, db, dw.reshape(wshape), None, None, None, None
 
 
-def ln_dwconv(x, gamma, beta, w, eps, segs, tee=False):
-    return _LnDwConv.apply(x, gamma, beta, w, eps, tuple(segs), tee)
+def ln_dwconv(x, gamma, beta, w, eps, segs, tee=False, cache=None):
+    """cache: the model's WeightCache -- its PassState batches the parameter-gradient reductions of a backward pass;
+    None = reduce right away."""
+    return _LnDwConv.apply(x, gamma, beta, w, eps, tuple(segs), tee, cache)
 
 
 # ---------------------------------------------------------------------------

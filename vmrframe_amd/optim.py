@@ -63,6 +63,7 @@ class FlatArena:
             if not any(nd in n for nd in NO_DECAY):
                 self.decay[o:o + k] = 1
         self.names: List[str] = [n for n, _ in named]
+        self.params = [p for _, p in named]
         self.offsets = offs
         self.flat_w = None
         self._t_count = 0
@@ -99,10 +100,30 @@ class FlatArena:
                 d[key] = view
                 ps[0]._vmr_wt_views = d
             self._t_count = len(items)
+        for p in self.params:
+            p._vmr_arena = self
+        self.mark_synced()
 
     def refresh_transposed(self):
         if getattr(self, "_t_count", 0):
             L.check(L.lib().vmr_transpose_batched(self._t_items, self._t_count, L.stream_ptr()), "vmr_transpose_batched")
+
+    def mark_synced(self):
+        """Remember every master's version counter: ops.WeightCache compares against it to notice in-place edits
+        (load_state_dict, `with no_grad(): p.copy_(...)`) that the bf16 mirrors have not seen yet."""
+        for p in self.params:
+            p._vmr_synced_version = p._version
+
+    def sync_mirrors(self):
+        """Re-derive the bf16 mirror and the K-major copies from the fp32 masters.  The AdamW kernel keeps them in
+        step on its own; this is for changes made to the masters BEHIND the optimizer's back (checkpoint load,
+        parameter broadcast, manual `p.data` edits)."""
+        if self.flat_w is not None:
+            n = self.flat_p.numel()
+            L.check(L.lib().vmr_cast(self.flat_p.data_ptr(), L.F32, self.flat_w.data_ptr(), L.BF16, n // 8, 8, 8, 8,
+                                     0.0, 0, None, L.stream_ptr()), "vmr_cast")
+            self.refresh_transposed()
+        self.mark_synced()
 
 
 class FlatAdamW:
@@ -127,6 +148,17 @@ class FlatAdamW:
         self.gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.step_t = torch.full((1,), self.t, device=dev, dtype=torch.int32)
         self.arena.refresh_transposed()
+        # a checkpoint loaded into the model from now on lands in the fp32 arena (in-place copies): bring the
+        # compute-dtype copies along (reference main.py:26-28 / utils/utils.py:208-215 resume-and-eval flow)
+        self.model.register_load_state_dict_post_hook(lambda _m, _keys: self.sync_mirrors())
+
+    def sync_mirrors(self):
+        """Call after changing parameter values behind the optimizer's back (dp.broadcast_parameters, manual
+        `p.data` edits); load_state_dict and in-place `p.copy_()` edits are noticed without it."""
+        if self.arena is not None:
+            self.arena.sync_mirrors()
+        if hasattr(self.model, "_cache"):
+            self.model._cache.clear()
 
     @property
     def grad_arena(self):
@@ -141,6 +173,9 @@ class FlatAdamW:
         return self.arena.offsets
 
     def zero_grad(self):
+        cache = getattr(self.model, "_cache", None)
+        if cache is not None and hasattr(cache, "state"):
+            cache.state.reset()             # a backward pass that died must not leak partials into this one
         if self.arena is None:
             for p in self.model.parameters():
                 p.grad = None
