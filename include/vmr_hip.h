@@ -34,6 +34,9 @@ extern "C" {
 int vmr_version(void);
 const char* vmr_last_error(void);
 int vmr_sizeof_gemm_desc(void); /* ABI guard for foreign-language bindings of vmr_gemm_t */
+/* Test utility (no reference counterpart): fills the whole LDS of every CU with `pattern`, so that a kernel reading
+ * LDS it never wrote yields the pattern instead of its predecessor's leftovers.  scratch_u32: 4 device bytes. */
+int vmr_debug_poison_lds(uint32_t pattern, void* scratch_u32, void* stream);
 
 /* ------------------------------------------------------------------ GEMM
  * C[z] = epilogue(alpha * opA(A[z]) . opB(B[z]))
@@ -363,8 +366,10 @@ int vmr_narrow_linear_bwd(const float* dy, const void* x, const float* W, void* 
  *   `padded` (nullable, dtype [R,ldo]) receives the same probabilities zero-padded to ldo columns (the
  *   operand of the label-embedding product, models/SeqPAN.py:80-82).  bwd: dlogits from dprobs and/or dpadded.
  * vmr_match_loss_fwd/bwd: lossfun_match (models/loss.py:24-41): sum_r -probs[r,label[r]]*vmask[r] /
- *   (sum_r vmask[r] + 1e-12) + || offdiag(E^T E) ||_F, E = label_embs fp32 [D,C].  aux: fp32 [C*C + 4]
- *   (Gram matrix, norm, denominator, 2 scratch) kept for the backward; dE is ACCUMULATED. */
+ *   (sum_r vmask[r] + 1e-12) + || offdiag(E^T E) ||_F, E = label_embs fp32 [D,C].  aux: fp32
+ *   [C*C + 2 + VMR_MATCH_LOSS_SCRATCH] (Gram matrix, norm, denominator, then per-workgroup partial sums --
+ *   no atomics, nothing for the caller to zero) kept for the backward; dE is ACCUMULATED. */
+#define VMR_MATCH_LOSS_SCRATCH 512
 int vmr_gumbel_softmax_fwd(const float* logits, const float* noise /*nullable*/, float tau, uint32_t seed,
                            const uint32_t* step, float* probs, void* padded, int64_t R, int C, int ldo,
                            int dtype, void* stream);

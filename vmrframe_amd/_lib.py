@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvmr_hip.so")
 
 F32, BF16 = 0, 1
 LN_BWD_MAX_BLOCKS = 8192   # == VMR_LN_BWD_MAX_BLOCKS
+MATCH_LOSS_SCRATCH = 512   # == VMR_MATCH_LOSS_SCRATCH
 
 
 def ln_bwd_ws_floats(rows: int, D: int) -> int:
@@ -113,6 +114,7 @@ SIGNATURES = {
     "vmr_map2d_pool_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "vmr_map2d_scatter": [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     "vmr_sumsq": [_P, _P, _L, _P],
+    "vmr_debug_poison_lds": [_U, _P, _P],
     "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P, _F, _F, _L, _P],
 }
 

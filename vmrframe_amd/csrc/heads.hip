@@ -68,7 +68,10 @@ __global__ __launch_bounds__(256) void gumbel_softmax_bwd_kernel(const float* __
   }
 }
 
-// stats = {numerator sum_r -p[r,label]*vmask[r], denominator sum_r vmask[r]} accumulated by atomics (caller zeroes)
+// stats[2*b .. 2*b+1] = workgroup b's {numerator sum_r -p[r,label]*vmask[r], denominator sum_r vmask[r]}: plain
+// stores, summed by the final kernel -- no atomics (deterministic) and nothing to zero beforehand.  (A
+// hipMemsetAsync of the accumulators used to sit here; captured into a hipGraph as a memset node it was observed to
+// run out of order with the kernels around it on replay, tests/test_gpu_trainer.py::test_graph_replay_equals_eager_steps.)
 __global__ __launch_bounds__(256) void match_loss_partial_kernel(const float* __restrict__ probs, const int64_t* __restrict__ labels,
                                                                  const float* __restrict__ vmask, float* __restrict__ stats,
                                                                  int64_t R, int C) {
@@ -79,16 +82,31 @@ __global__ __launch_bounds__(256) void match_loss_partial_kernel(const float* __
     if (l >= 0 && l < C) num -= probs[r * C + l] * m;
     den += m;
   }
+  __shared__ float part[2][4];
   num = wave_sum(num);
   den = wave_sum(den);
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], num); atomicAdd(&stats[1], den); }
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = num; part[1][threadIdx.x >> 6] = den; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stats[2 * blockIdx.x] = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+    stats[2 * blockIdx.x + 1] = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+  }
 }
 
 // one workgroup: Gram matrix G = E^T E of the label embeddings E [D,C], off-diagonal Frobenius norm;
 // loss = stats[0]/(stats[1]+1e-12) + norm; aux = {G (C*C), norm, denominator}
 __global__ __launch_bounds__(256) void match_loss_final_kernel(const float* __restrict__ E, const float* __restrict__ stats,
-                                                               float* __restrict__ loss, float* __restrict__ aux, int D, int C) {
+                                                               int nparts, float* __restrict__ loss, float* __restrict__ aux,
+                                                               int D, int C) {
   __shared__ float red[4][HC_MAX * HC_MAX];
+  __shared__ float tot[2][4];
+  {   // sum of the per-workgroup partials (nparts <= 256: one per thread)
+    float n_ = threadIdx.x < nparts ? stats[2 * threadIdx.x] : 0.f;
+    float d_ = threadIdx.x < nparts ? stats[2 * threadIdx.x + 1] : 0.f;
+    n_ = wave_sum(n_);
+    d_ = wave_sum(d_);
+    if ((threadIdx.x & 63) == 0) { tot[0][threadIdx.x >> 6] = n_; tot[1][threadIdx.x >> 6] = d_; }
+  }
   float g[HC_MAX * HC_MAX];
 #pragma unroll
   for (int i = 0; i < HC_MAX * HC_MAX; ++i) g[i] = 0.f;
@@ -117,9 +135,11 @@ __global__ __launch_bounds__(256) void match_loss_final_kernel(const float* __re
         if (i != j) nrm += v * v;
       }
     nrm = sqrtf(nrm);
+    const float num = (tot[0][0] + tot[0][1]) + (tot[0][2] + tot[0][3]);
+    const float den = (tot[1][0] + tot[1][1]) + (tot[1][2] + tot[1][3]);
     aux[C * C] = nrm;
-    aux[C * C + 1] = stats[1] + 1e-12f;
-    loss[0] = stats[0] / (stats[1] + 1e-12f) + nrm;
+    aux[C * C + 1] = den + 1e-12f;
+    loss[0] = num / (den + 1e-12f) + nrm;
   }
 }
 
@@ -182,16 +202,17 @@ extern "C" int vmr_gumbel_softmax_bwd(const float* dprobs, const void* dpadded, 
 }
 
 extern "C" int vmr_match_loss_fwd(const float* probs, const int64_t* labels, const float* vmask, const float* E, float* loss,
-                                  float* aux /*[C*C+2] + 2 scratch floats*/, int64_t R, int D, int C, void* stream) {
+                                  float* aux /*[C*C+2] + VMR_MATCH_LOSS_SCRATCH scratch floats*/, int64_t R, int D, int C,
+                                  void* stream) {
   VMR_CHECK(probs && labels && vmask && E && loss && aux, "vmr_match_loss_fwd: null pointer");
   VMR_CHECK(C >= 1 && C <= HC_MAX, "vmr_match_loss_fwd: need 1 <= C <= %d", HC_MAX);
   float* stats = aux + C * C + 2;
-  hipError_t e = hipMemsetAsync(stats, 0, 2 * sizeof(float), (hipStream_t)stream);
-  if (e != hipSuccess) return vmr_fail(-5, "vmr_match_loss_fwd: memset: %s", hipGetErrorString(e));
+  const int nparts = R > 0 ? (int)min((int64_t)256, (R + 255) / 256) : 0;
+  static_assert(VMR_MATCH_LOSS_SCRATCH >= 2 * 256, "scratch holds one {num, den} pair per workgroup");
   if (R > 0)
-    hipLaunchKernelGGL(match_loss_partial_kernel, dim3((unsigned)min((int64_t)256, (R + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, probs, labels, vmask, stats, R, C);
-  hipLaunchKernelGGL(match_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, E, stats, loss, aux, D, C);
+    hipLaunchKernelGGL(match_loss_partial_kernel, dim3((unsigned)nparts), dim3(256), 0, (hipStream_t)stream, probs, labels,
+                       vmask, stats, R, C);
+  hipLaunchKernelGGL(match_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, E, stats, nparts, loss, aux, D, C);
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -796,7 +796,7 @@ class _MatchLoss(torch.autograd.Function):
         vm = vmask.contiguous().float().view(-1)
         assert lab.numel() == R and vm.numel() == R
         loss = torch.empty(1, device=p2.device, dtype=torch.float32)
-        aux = torch.empty(Cc * Cc + 4, device=p2.device, dtype=torch.float32)
+        aux = torch.empty(Cc * Cc + 2 + L.MATCH_LOSS_SCRATCH, device=p2.device, dtype=torch.float32)
         L.check(L.lib().vmr_match_loss_fwd(p2.data_ptr(), lab.data_ptr(), vm.data_ptr(), E.data_ptr(), loss.data_ptr(),
                                            aux.data_ptr(), R, D, Cc, L.stream_ptr()), "vmr_match_loss_fwd")
         ctx.save_for_backward(lab, vm, label_embs, aux)

@@ -56,7 +56,12 @@ class GraphedTrainStep:
         self.static_batch = {k: v.to(dev).clone() for k, v in batch.items()}
         if self.model.drop_step is None:
             self.model.drop_step = torch.zeros(1, device=dev, dtype=torch.int32)
-        s = torch.cuda.Stream()
+        # Warm-up AND capture run on ONE side stream.  autograd pins every AccumulateGrad node to the stream it was
+        # created on (the first backward): capturing on a different stream makes the engine fork the capture onto
+        # the warm-up stream for those nodes ("AccumulateGrad node's stream does not match ..."), and a replayed
+        # graph with such a fork was measured to let LATER work of the launch stream start before the fork's
+        # branch had finished (tests/test_gpu_trainer.py::test_graph_replay_equals_eager_steps).
+        s = self.stream = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(self.warmup):            # eager warm-up: builds the arena, opts kernels into big LDS
@@ -70,13 +75,13 @@ class GraphedTrainStep:
         self.model._cache.clear()                   # every weight cast must be recorded in the graph
         self.g_fb = torch.cuda.CUDAGraph()
         if self.split:
-            with torch.cuda.graph(self.g_fb):
+            with torch.cuda.graph(self.g_fb, stream=s):
                 self.loss, self.out = self._fwd_bwd()
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt):
+            with torch.cuda.graph(self.g_opt, stream=s):
                 self.opt.step()
         else:
-            with torch.cuda.graph(self.g_fb):
+            with torch.cuda.graph(self.g_fb, stream=s):
                 self.loss, self.out = self._fwd_bwd()
                 self.opt.step()
         return self
