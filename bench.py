@@ -8,8 +8,9 @@ already resident in HBM: forward, both losses, backward, gradient all-reduce
 Dropout is ON (droprate 0.2, the reference's configs); weights are random-init.
 
   python bench.py --gpus N --steps K --warmup W
-For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); per-GPU
-batch is fixed at 64 clips (weak scaling).  Rank 0 prints ONE JSON line.
+For N > 1 it runs one rank per GPU over RCCL: either under torch.distributed.run (RANK / WORLD_SIZE /
+MASTER_* in the environment) or, when those are absent, by spawning its own N rank processes before anything
+touches a GPU.  Per-GPU batch is fixed at 64 clips (weak scaling).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -138,6 +139,50 @@ def cpu_baseline(a):
                       f"shapes with B=8 clips, mean of {n} steps after 1 warm-up ({dt:.2f} s/step)"}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, one per GPU, with the
+    torch.distributed environment (rendezvous on 127.0.0.1), and pass rank 0's JSON line through.  The parent never
+    initialises a GPU (no HIP call before or after the spawn) and never replaces itself with another program."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            rc = p.wait() or rc
+            if rc:
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def launcher_selftest(rank: int, world: int):
+    """--selftest-launcher: what a rank does up to and including its first collective, without any GPU work (gloo):
+    lets the launch path be rehearsed on a GPU-less host (tests/test_dp_gloo.py)."""
+    import torch.distributed as dist
+    from vmrframe_amd import dp
+    dp.init_process_group_from_env("gloo")
+    t = torch.ones(4) * (rank + 1)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "world_observed": dist.get_world_size(),
+                          "sum_of_ranks": float(t[0])}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,11 +194,19 @@ def main():
     ap.add_argument("--workload", default="seqpan", choices=["seqpan", "basefast", "banmap"],
                     help="seqpan = BASELINE configs[1] (headline); basefast = configs[3] (T=256); banmap = the BAN "
                          "proposal-map stage of configs[4]")
+    ap.add_argument("--selftest-launcher", action="store_true", help="rendezvous + one gloo all-reduce per rank, no GPU")
+    ap.add_argument("--reduce-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="wire dtype of the gradient all-reduce (N > 1); fp32 = exact sum")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))            # nothing above this line has touched a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if args.selftest_launcher:
+        return launcher_selftest(rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
     # rehearsal hook for a 1-GPU box: VMR_FORCE_DEVICE=0 + VMR_DIST_BACKEND=gloo runs N ranks on one card
     local = int(os.environ.get("VMR_FORCE_DEVICE", local))
@@ -166,7 +219,6 @@ def main():
     from vmrframe_amd.optim import FlatAdamW
     if world > 1:
         dp.init_process_group_from_env(os.environ.get("VMR_DIST_BACKEND", "nccl"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     if args.workload == "banmap":
         from vmrframe_amd.synth import Cfg
@@ -191,10 +243,12 @@ def main():
         model.base_seed = 1234 + rank                # per-rank dropout / Gumbel streams
         torch.manual_seed(1234 + rank)
     dp.broadcast_parameters(model)
+    if world > 1 and hasattr(model, "backward_plan"):
+        model.backward_cuts = True       # cut the backward at the stage boundaries: all-reduce under the next stage
     total_steps = args.steps + args.warmup
     opt = FlatAdamW(model, lr=1e-4, weight_decay=0.01, max_norm=1.0, warmup_steps=0.0 * total_steps,
                     total_steps=10 * total_steps)
-    reducer = dp.GradReducer(model, opt, use_hooks=args.no_graph)
+    reducer = dp.GradReducer(model, opt, reduce_dtype=torch.bfloat16 if args.reduce_dtype == "bf16" else torch.float32)
     if args.workload == "banmap":
         gen = torch.Generator().manual_seed(1234 + rank)
         batch = {"hidden_b": torch.relu(torch.randn(a["B"], a["N"], a["F"], generator=gen)).to(dev),   # post-ReLU features
@@ -207,7 +261,7 @@ def main():
     def eager_step():
         loss, out = engine(model, batch, cfg, "train")
         opt.zero_grad()
-        loss.backward()
+        reducer.backward(loss)       # loss.backward(), stage by stage when N > 1 (each stage's range goes to RCCL)
         reducer.finish()
         opt.step()
         return loss
@@ -219,8 +273,7 @@ def main():
     else:
         # one captured HIP graph per step (vmrframe_amd/trainer.py): the eager loop is launch-bound
         from vmrframe_amd.trainer import GraphedTrainStep
-        gstep = GraphedTrainStep(model, opt, engine, cfg, reducer if world > 1 else None,
-                                 warmup=3, overlap_dw=os.environ.get("VMR_OVERLAP_DW", "0") != "0").capture(batch)
+        gstep = GraphedTrainStep(model, opt, engine, cfg, reducer if world > 1 else None, warmup=3).capture(batch)
         step = gstep
         for _ in range(args.warmup):
             loss = step()
@@ -318,6 +371,9 @@ def main():
                           "global_batch": a["B"] * world, "parallelism": f"dp{world}"},
                "step_mfma_frac": round(value * TRAIN_GFLOP_PER_CLIP * 1e9 / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
                "final_loss": round(final_loss, 4), "hipgraph": not args.no_graph,
+               "dist": None if world == 1 else {"backend": dist.get_backend(), "world_observed": dist.get_world_size(),
+                                                "reduce_dtype": args.reduce_dtype,
+                                                "overlap": "stage-cut backward, one all-reduce per stage range"},
                "roofline": roofline, "roofline_second": roofline2}
         if cq_rec:
             # the CQAttention score kernel (north-star "attention score/softmax/context-gather"): algorithmic

@@ -1,0 +1,201 @@
+"""GPU: the data-parallel path of the REAL model -- the backward pass cut into stages, the
+piecewise-graph trainer that issues one all-reduce per finished stage, and a 2-rank run (gloo, both ranks on this one
+GPU: RCCL refuses two ranks on one device, and the boxes here have one) checked against the mean of the per-shard
+gradients computed by a single process.  The per-rank forward is the reference at the LOCAL batch (the batch-axis
+attention of layers.py:567-574 sees the local batch), so that -- not a full-batch run -- is the expected value."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda")
+
+
+def _build(name, dtype, dev, seed=77):
+    from tests.test_gpu_trainer import build
+    z, cfg, batch, g, weights = load_golden(name)
+    return build(cfg, weights, dtype, dev, g, seed=seed), cfg, batch, g, weights
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+class FakeReducer:
+    """world = 2 without a process group: records what the trainer hands to RCCL, reduces nothing."""
+
+    def __init__(self, model, opt):
+        self.model, self.opt, self.world, self.log = model, opt, 2, []
+
+    def ranges(self):
+        return self.opt.arena.segment_ranges
+
+    def backward(self, loss):
+        self.model.segmented_backward(loss, self.stage_done)
+
+    def stage_done(self, i):
+        self.log.append(i)
+
+    def finish(self):
+        self.log.append("finish")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_stage_cut_backward_equals_plain_backward(dev, dtype):
+    import vmrframe_amd as V
+    from vmrframe_amd.optim import FlatAdamW
+    m, cfg, batch, g, weights = _build("g_small", dtype, dev)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    opt = FlatAdamW(m, lr=0.0, max_norm=1.0)
+    grads = {}
+    for cuts in (False, True, False, True):          # passes 0-1 build the arena; 2-3 are compared
+        m.backward_cuts = cuts
+        loss, out = V.train_engine_SeqPAN(m, dbatch, cfg, "train")
+        opt.zero_grad()
+        order = []
+        if cuts:
+            m.segmented_backward(loss, order.append)
+            assert order == [4, 3, 2, 1, 0]
+        else:
+            loss.backward()
+        opt.step()
+        grads[cuts] = opt.arena.flat_g.clone()
+    tol = 1e-5 if dtype == "fp32" else 5e-2            # (bf16: atomics-order noise of the forward, see test_gpu_trainer)
+    assert _rel(grads[True], grads[False]) < tol
+    # the arena is laid out stage by stage, ranges contiguous and ordered like the forward
+    rg = opt.arena.segment_ranges
+    assert len(rg) == 5 and rg[0][0] == 0 and rg[-1][1] == opt.arena.flat_g.numel()
+    assert all(a[1] == b[0] for a, b in zip(rg[:-1], rg[1:]))
+    for n in opt.names:
+        lo, hi = rg[m.param_segment(n)]
+        assert lo <= opt.offsets[n] < hi, n
+    frac = [(hi - lo) / rg[-1][1] for lo, hi in rg]
+    print("[stages] share of the arena per stage:", [round(f, 3) for f in frac])
+
+
+def test_piecewise_graph_trainer_equals_single_graph(dev):
+    """N > 1 trainer (one graph per backward stage + an optimizer graph, collectives between replays) against the
+    single-graph trainer, 3 steps each from the same state, bf16, dropout off: same weights afterwards, and the
+    stages are handed over last-first, each right after its own graph."""
+    import vmrframe_amd as V
+    from vmrframe_amd.optim import FlatAdamW
+    from vmrframe_amd.trainer import GraphedTrainStep
+    sched = dict(warmup_steps=0.0, total_steps=10)
+    A, cfg, batch, g, weights = _build("g_small", "bf16", dev)
+    optA = FlatAdamW(A, lr=1e-3, weight_decay=0.01, max_norm=1.0, **sched)
+    red = FakeReducer(A, optA)
+    stepA = GraphedTrainStep(A, optA, V.train_engine_SeqPAN, cfg, red, warmup=2).capture(batch)
+    assert len(stepA.pieces) == 5 and stepA.g_opt is not None and A.backward_cuts
+    B, _, _, _, _ = _build("g_small", "bf16", dev)
+    optB = FlatAdamW(B, lr=1e-3, weight_decay=0.01, max_norm=1.0, **sched)
+    stepB = GraphedTrainStep(B, optB, V.train_engine_SeqPAN, cfg, None, warmup=2).capture(batch)
+    assert len(stepB.pieces) == 1
+    for it in range(3):
+        for dst, src in ((optA.arena.flat_p, optB.arena.flat_p), (optA.m, optB.m), (optA.v, optB.v),
+                         (optA.step_t, optB.step_t)):
+            dst.copy_(src)
+        optA.sync_mirrors()
+        before = optB.arena.flat_p.clone()
+        red.log.clear()
+        la, lb = float(stepA().item()), float(stepB().item())
+        torch.cuda.synchronize()
+        assert red.log == [4, 3, 2, 1, 0, "finish"]
+        assert abs(la - lb) < 2e-3 * max(1.0, abs(lb)), (it, la, lb)
+        dA, dB = (optA.arena.flat_p - before).double(), (optB.arena.flat_p - before).double()
+        keep = optB.arena.flat_g.abs() >= 1e-4 * float(optB.arena.flat_g.abs().max())   # (noise-only gradients: see test_gpu_trainer)
+        r = float((dA - dB)[keep].norm() / dB[keep].norm())
+        assert r < 3e-2, (it, r)
+    assert int(optA.step_t.item()) == int(optB.step_t.item()) == 5
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# two ranks (gloo) on this GPU, real model + FlatAdamW + stage-cut overlap protocol
+# --------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rank(rank, world, port, outdir, graph):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import vmrframe_amd as V
+    from vmrframe_amd import dp
+    from vmrframe_amd.optim import FlatAdamW
+    from vmrframe_amd.trainer import GraphedTrainStep
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dp.init_process_group_from_env("gloo")
+    torch.manual_seed(100 + rank)                           # different init per rank: the broadcast must fix it
+    m, cfg, batch, g, weights = _build("g_small", "bf16", dev)
+    if rank == 1:
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.requires_grad:
+                    p.add_(0.01)
+    dp.broadcast_parameters(m)
+    shard = dp.shard_batch(batch, rank, world)
+    m.gumbel_override = g[rank::world].to(dev)
+    m.backward_cuts = True
+    opt = FlatAdamW(m, lr=0.0, max_norm=1.0)
+    red = dp.GradReducer(m, opt)
+    if graph:
+        step = GraphedTrainStep(m, opt, V.train_engine_SeqPAN, cfg, red, warmup=2).capture(shard)
+        step()
+    else:
+        dshard = {k: v.to(dev) for k, v in shard.items()}
+        for _ in range(3):
+            loss, _ = V.train_engine_SeqPAN(m, dshard, cfg, "train")
+            opt.zero_grad(); red.backward(loss); red.finish(); opt.step()
+    torch.cuda.synchronize()
+    assert red.launch_log[-5:] == [4, 3, 2, 1, 0]
+    torch.save({"g": opt.arena.flat_g.cpu(), "names": opt.names, "offsets": opt.offsets,
+                "w": m.P("dual_attention_block_1.dense_1.conv1d.weight").detach().cpu()},
+               os.path.join(outdir, f"rank{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_ranks_real_model_gradient_average(dev, tmp_path, graph):
+    import vmrframe_amd as V
+    from vmrframe_amd import dp
+    from vmrframe_amd.optim import FlatAdamW
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, str(tmp_path), graph)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(500)
+        assert p.exitcode == 0
+    got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
+    assert torch.equal(got[0]["g"], got[1]["g"])                       # both ranks hold the same averaged gradients
+    assert torch.equal(got[0]["w"], got[1]["w"])                       # ... and rank 0's weights
+    # expected: mean over ranks of the single-process gradient on each rank's shard
+    m, cfg, batch, g, weights = _build("g_small", "bf16", dev)
+    opt = FlatAdamW(m, lr=0.0, max_norm=1.0)
+    per = []
+    for r in range(2):
+        shard = {k: v.to(dev) for k, v in dp.shard_batch(batch, r, 2).items()}
+        m.gumbel_override = g[r::2].to(dev)
+        for _ in range(2):
+            loss, _ = V.train_engine_SeqPAN(m, shard, cfg, "train")
+            opt.zero_grad(); loss.backward(); opt.step()
+        per.append(opt.arena.flat_g.cpu().clone())
+    assert opt.names == got[0]["names"]
+    want = (per[0] + per[1]) / 2
+    r_ = _rel(got[0]["g"], want)
+    print(f"[2 ranks, graph={graph}] averaged arena vs mean of shard gradients: rel {r_:.3e}")
+    assert r_ < 5e-2                                                    # bf16 forward noise; a missing average is 0.5-1
+    assert torch.equal(got[0]["w"], m.P("dual_attention_block_1.dense_1.conv1d.weight").detach().cpu())

@@ -209,6 +209,8 @@ class SeqPAN(nn.Module):
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
         self.last_drop_sites = []
         self.sync_timing = True       # reference-style synchronised self-timing of forward (:51-52,85-87)
+        self.backward_cuts = False    # cut the autograd tape at the stage boundaries (see _cut / segmented_backward)
+        self._cuts = []
 
     # -- plumbing -------------------------------------------------------------
     def _register(self, dotted, param):
@@ -234,6 +236,56 @@ class SeqPAN(nn.Module):
             out.append([f"{m}.bilinear_{b}.dense_1.conv1d.bias" for b in (1, 2)])
             out.append([f"{m}.bilinear_{b}.bias_value" for b in (1, 2)])
         return out
+
+    # -- backward segments (data-parallel overlap) ---------------------------------
+    SEGMENT_PREFIXES = (("text_encoder.", "video_affine.", "vfeat_encoder."), ("dual_attention_block_1.",),
+                        ("dual_attention_block_2.",), ("q2v_attn.", "v2q_attn.", "cq_cat.", "match_conv1d.", "label_embs"),
+                        ("predictor.",))
+
+    def param_segment(self, name: str) -> int:
+        """Forward-order stage a parameter belongs to.  The flat gradient arena is laid out stage by stage
+        (optim.FlatArena), so when the backward pass is cut at the stage boundaries (`backward_cuts`) every finished
+        stage is ONE contiguous range of the arena that can go to RCCL while the earlier stages still run."""
+        for i, pre in enumerate(self.SEGMENT_PREFIXES):
+            if name.startswith(pre):
+                return i
+        raise KeyError(name)
+
+    def _cut(self, x, stage: int):
+        """Stage boundary: with `backward_cuts` on, the tape is cut here -- the next stage continues from a detached
+        leaf and `segmented_backward` resumes this stage's tape from that leaf's gradient.  Same arithmetic either
+        way; only where one backward call ends and the next one starts."""
+        if not self.backward_cuts or not torch.is_grad_enabled() or not x.requires_grad:
+            return x
+        leaf = x.detach().requires_grad_(True)
+        self._cuts.append((stage, x, leaf))
+        return leaf
+
+    def backward_plan(self, loss):
+        """The backward pass as a list of (run, done): run() executes one piece of it, last stage first; `done` lists
+        the stages whose gradients are final in the arena once that piece has run.  Without cuts: one piece.  Tensors
+        cut at the same boundary (the fused features and the match scores both leave stage 3) resume together."""
+        cuts, self._cuts = self._cuts, []
+        top = len(self.SEGMENT_PREFIXES) - 1
+        stages = sorted({c[0] for c in cuts}, reverse=True)
+        bounds = stages + [-1]
+        plan = [(loss.backward, list(range(top, bounds[0], -1)))]
+        for j, stage in enumerate(stages):
+            def run(stage=stage):
+                roots = [(x, leaf.grad) for st, x, leaf in cuts if st == stage and leaf.grad is not None]
+                if roots:
+                    torch.autograd.backward([r[0] for r in roots], [r[1] for r in roots])
+            plan.append((run, list(range(stage, bounds[j + 1], -1))))
+        return plan
+
+    def segmented_backward(self, loss, after_stage=None):
+        """loss.backward() in stage-sized pieces; after_stage(i) is called as soon as every gradient of stage i sits
+        in the arena (vmrframe_amd/dp.py launches that range's all-reduce there)."""
+        for run, done in self.backward_plan(loss):
+            run()
+            if after_stage is not None:
+                for i in done:
+                    after_stage(i)
 
     def _group_bias(self, names):
         """Concatenated bias of a grouped GEMM: a zero-copy view of the flat arena when the optimizer
@@ -397,6 +449,7 @@ class SeqPAN(nn.Module):
             torch.cuda.synchronize()
         start = time.time()
         self._cache.state.reset()         # partials a dead backward pass left behind must not reach this one
+        self._cuts = []
         cdt, D = self.compute_dtype, self.dim
         B, T = vmask.shape
         Lq = tmask.shape[1]
@@ -419,7 +472,9 @@ class SeqPAN(nn.Module):
         X = self._conv_block(X, "vfeat_encoder.conv_block", segs, dc, self.ENC_LAYERS)
         rowmask = torch.cat([vmask.reshape(-1), tmask.reshape(-1)])
         for blk in ((1, 2) if self.USE_DUAL_BLOCKS else ()):
+            X = self._cut(X, blk - 1)
             X = self._dual_block(X, f"dual_attention_block_{blk}", vmask, tmask, rowmask, B, T, Lq, dc)
+        X = self._cut(X, 2 if self.USE_DUAL_BLOCKS else 0)
         V3, T3 = X[:Nv].view(B, T, D), X[Nv:].view(B, Lq, D)
         t2v = self._cq_attention("q2v_attn", V3, T3, vmask, tmask, dc)            # [Nv, D]
         v2t = self._cq_attention("v2q_attn", T3, V3, tmask, vmask, dc)            # [Nt, D]
@@ -437,7 +492,7 @@ class SeqPAN(nn.Module):
         noise = None if self.gumbel_override is None else self.gumbel_override.to(mlogits.device).reshape(Nv, 4)
         # Gumbel-softmax (tau 0.3) + the K-padded compute-dtype copy in one kernel
         ms_probs, ms = ops.gumbel_softmax(mlogits, noise, 0.3, gseed, gstep, 8, cdt)
-        match_score = ms_probs.view(B, T, 4)
+        match_score = self._cut(ms_probs.view(B, T, 4), 3)     # (read by lossfun_match only)
         # fuse2 = (fuse + match_score . label_embs^T) * vmask : one GEMM epilogue
         fuse2 = ops.linear(ms, self.P("label_embs"), None, self._cache, residual=fuse,
                            rowscale=vmask.reshape(-1))
@@ -446,6 +501,7 @@ class SeqPAN(nn.Module):
         # accumulates through the residual input): no [Nv, 2D] concat copies.  The fuse2 halves come first so that
         # fuse2's three consumers chain their gradients (tee) instead of meeting in two autograd add passes.
         Ws, We = self.P("predictor.start_hidden.conv1d.weight"), self.P("predictor.end_hidden.conv1d.weight")
+        fuse2 = self._cut(fuse2, 3)
         ps, fuse2 = ops.linear(fuse2, Ws, None, self._cache, kslice=(D, 2 * D), tee=True)
         pe, fuse2 = ops.linear(fuse2, We, None, self._cache, kslice=(D, 2 * D), tee=True)
         sfeat = self._predict_encoder(fuse2, vmask, B, T, dc, "pred.s")

@@ -7,15 +7,22 @@ which cannot work for this model.  Semantics are th
 reference's per-replica forward at the local batch (the batch-axis attention of
 layers.py:567-574 sees the LOCAL batch) with DDP-style gradient averaging.
 
-Gradients live in one flat fp32 arena (vmrframe_amd/optim.py); it is cut into a
-few large buckets that are all-reduced asynchronously as soon as autograd has
-produced every gradient of the bucket (post-accumulate hooks), so the transfer
-overlaps the rest of the backward.  Point-to-point xGMI favours few, large
-messages: ~32 MiB buckets.
+Overlap.  Gradients live in one flat fp32 arena laid out stage by stage in forward
+order (optim.FlatArena.segment_ranges; stages = SeqPAN.SEGMENT_PREFIXES).  The
+backward pass is cut at the stage boundaries (SeqPAN.segmented_backward): as soon
+as a stage's piece of the pass has finished -- predictor first, embeddings last --
+its contiguous arena range goes to RCCL as ONE large message on RCCL's own stream
+while the next piece computes.  Only the first stage's range (text / video
+projections + shared encoder, 8 % of the arena) has nothing left to hide behind.
+Weight gradients are written straight into the arena by the dW kernels, so there
+are no per-parameter autograd hooks to hang the launches on; the cuts are what
+makes "this range is final" known on the host (and they are ordinary graph
+boundaries for the hipGraph trainer).  Point-to-point xGMI favours few, large
+messages: 5 ranges of 20-67 MB instead of ~170 tensors.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.distributed as dist
@@ -65,98 +72,91 @@ def broadcast_parameters(model: torch.nn.Module, src: int = 0, optimizer=None):
 
 
 class GradReducer:
-    """Averages the flat gradient arena across ranks, bucket by bucket, overlapped with
-    backward.  Before the arena exists (first step) it falls back to per-tensor all-reduce
-    of whatever gradients exist.  Parameters whose grad is None are skipped (they stay None
-    on every rank, as the reference's unused tensors do)."""
+    """Averages the flat gradient arena across ranks, one stage range at a time.
 
-    def __init__(self, model: torch.nn.Module, optimizer, bucket_bytes: int = 32 << 20, use_hooks: bool = True):
-        # use_hooks=False: no autograd hooks at all -- finish() all-reduces the arena in bucket-sized
-        # chunks after backward.  Required when backward is replayed from a captured HIP graph (hooks do
-        # not run on replay, and a collective must never be issued while a graph is being captured).
-        self.model, self.opt, self.bucket_bytes, self.use_hooks = model, optimizer, bucket_bytes, use_hooks
+        red = GradReducer(model, opt)
+        ...
+        opt.zero_grad()
+        red.backward(loss)        # == loss.backward(), cut into stages; each finished stage's range is all-reduced
+                                  #    asynchronously while the earlier stages still compute
+        red.finish()              # wait for the collectives (gloo: divide by the world size)
+        opt.step()
+
+    Before the arena exists (the first step) every existing gradient is reduced through one coalesced buffer.
+    Parameters whose grad is None are never touched (they stay None on every rank, as the reference's unused tensors
+    do).  `reduce_dtype=torch.bfloat16` halves the bytes on the wire (SURVEY.md 8e allows it): the range is cast
+    into a bf16 staging buffer, averaged there and cast back; the default keeps the exact fp32 sum."""
+
+    def __init__(self, model: torch.nn.Module, optimizer, reduce_dtype: torch.dtype = torch.float32):
+        self.model, self.opt, self.reduce_dtype = model, optimizer, reduce_dtype
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        # RCCL averages in the collective itself (ncclAvg): no extra 262 MB divide pass over the arena; gloo (CPU
-        # tests) only sums
+        # RCCL averages in the collective itself (ncclAvg): no extra divide pass over the arena; gloo (CPU tests and
+        # the one-GPU rehearsal) only sums
         self.avg = dist.is_initialized() and dist.get_backend() == "nccl"
         self.op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
-        self.buckets: List[dict] = []
-        self.param_bucket = {}
-        self.handles = []
-        self.hooks = []
+        self.handles = []          # (work handle, fp32 range view, staging buffer or None)
+        self.reduced = set()
+        self.staging: Optional[torch.Tensor] = None
+        self.launch_log = []       # stage indices in launch order (tests)
 
-    def _setup_buckets(self):
-        opt = self.opt
-        flat = opt.grad_arena
-        per = max(1, self.bucket_bytes // 4)
-        # cut in REVERSE registration order ~ the order gradients become ready
-        names = list(opt.names)[::-1]
-        params = dict(self.model.named_parameters())
-        cur = None
-        for n in names:
-            o, k = opt.offsets[n], params[n].numel()
-            if cur is None or (cur["hi"] - o) > per:
-                cur = {"lo": o, "hi": o + (k + 7) // 8 * 8, "pending": 0, "count": 0}
-                self.buckets.append(cur)
-            cur["lo"] = o
-            cur["count"] += 1
-            self.param_bucket[n] = cur
-        for n in names:
-            b = self.param_bucket[n]
-            self.hooks.append(params[n].register_post_accumulate_grad_hook(self._make_hook(b)))
-        for b in self.buckets:
-            b["view"] = flat[b["lo"]:b["hi"]]
-            b["pending"] = b["count"]
+    # -- the cut backward pass ----------------------------------------------------
+    def backward(self, loss: torch.Tensor):
+        if hasattr(self.model, "segmented_backward") and getattr(self.model, "backward_cuts", False):
+            self.model.segmented_backward(loss, self.stage_done)
+        else:
+            loss.backward()
 
-    def _make_hook(self, bucket):
-        def hook(_p):
-            bucket["pending"] -= 1
-            if bucket["pending"] == 0:
-                self._launch(bucket)
-        return hook
+    def ranges(self):
+        arena = getattr(self.opt, "arena", None)
+        return None if arena is None else getattr(arena, "segment_ranges", [(0, arena.flat_g.numel())])
 
-    def _launch(self, bucket):
-        if self.world > 1:
-            self.handles.append(dist.all_reduce(bucket["view"], op=self.op, async_op=True))
-        bucket["launched"] = True
+    def stage_done(self, i: int):
+        """Every gradient of stage i is final: send its arena range (callable from a captured-graph trainer too:
+        it only enqueues a collective, on RCCL's stream, ordered after the current stream)."""
+        rg = self.ranges()
+        if self.world == 1 or rg is None or i >= len(rg) or i in self.reduced:
+            return
+        self.reduced.add(i)
+        lo, hi = rg[i]
+        if hi > lo:
+            self._launch(self.opt.grad_arena[lo:hi])
+            self.launch_log.append(i)
+
+    def _launch(self, view: torch.Tensor):
+        if self.reduce_dtype == torch.float32:
+            self.handles.append((dist.all_reduce(view, op=self.op, async_op=True), view, None))
+            return
+        if self.staging is None or self.staging.numel() < self.opt.grad_arena.numel():
+            self.staging = torch.empty(self.opt.grad_arena.numel(), device=view.device, dtype=self.reduce_dtype)
+        off = view.storage_offset() - self.opt.grad_arena.storage_offset()
+        st = self.staging[off:off + view.numel()]
+        st.copy_(view)
+        self.handles.append((dist.all_reduce(st, op=self.op, async_op=True), view, st))
 
     def finish(self):
-        """Call after backward(): wait for the buckets, average, re-arm."""
+        """Call after backward(): reduce whatever stage has not been sent yet, wait, average."""
         if self.world == 1:
             return
-        if self.opt.grad_arena is None:            # first step: arena not built yet
-            for p in self.model.parameters():
-                if p.grad is not None:
-                    dist.all_reduce(p.grad, op=self.op)
-                    if not self.avg:
-                        p.grad.div_(self.world)
+        rg = self.ranges()
+        if rg is None:                 # first step: the arena is not built yet -- one coalesced buffer
+            grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+            if grads:
+                flat = torch.cat([g.reshape(-1).float() for g in grads])
+                dist.all_reduce(flat, op=self.op)
+                if not self.avg:
+                    flat.div_(self.world)
+                o = 0
+                for g in grads:
+                    g.copy_(flat[o:o + g.numel()].view_as(g))
+                    o += g.numel()
             return
-        if not self.use_hooks:
-            flat = self.opt.grad_arena
-            per = max(1, self.bucket_bytes // 4)
-            hs = [dist.all_reduce(flat[o:o + per], op=self.op, async_op=True)
-                  for o in range(0, flat.numel(), per)]
-            for h in hs:
-                h.wait()
-            if not self.avg:
-                flat.div_(self.world)
-            return
-        if not self.buckets:
-            # arena was just built by the previous optimizer step but hooks were not armed for
-            # this backward: reduce the whole arena in one go, then arm the hooks.
-            dist.all_reduce(self.opt.grad_arena, op=self.op)
-            if not self.avg:
-                self.opt.grad_arena.div_(self.world)
-            self._setup_buckets()
-            return
-        for b in self.buckets:                     # parameters that got no gradient this step
-            if not b.get("launched"):
-                self._launch(b)
-        for h in self.handles:
+        for i in range(len(rg) - 1, -1, -1):
+            self.stage_done(i)
+        for h, view, st in self.handles:
             h.wait()
+            if st is not None:
+                view.copy_(st)
+            if not self.avg:
+                view.div_(self.world)
         self.handles.clear()
-        if not self.avg:
-            self.opt.grad_arena.div_(self.world)
-        for b in self.buckets:
-            b["pending"] = b["count"]
-            b["launched"] = False
+        self.reduced.clear()

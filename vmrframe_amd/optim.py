@@ -42,9 +42,17 @@ class FlatArena:
         # compute-dtype mirror is a single [sum N, K] matrix without any per-step concat / cast
         groups = model.weight_groups() if hasattr(model, "weight_groups") else []
         have = dict(named)
-        first = [n for grp in groups if all(g in have for g in grp) for n in grp]
-        seen = set(first)
-        named = [(n, have[n]) for n in first] + [(n, p) for n, p in named if n not in seen]
+        # forward-order stages (model.param_segment): the arena is laid out stage by stage, so a finished stage of
+        # the backward pass is ONE contiguous range that data-parallel ranks can all-reduce while earlier stages run
+        seg_of = (lambda n: model.param_segment(n)) if hasattr(model, "param_segment") else (lambda n: 0)
+        nseg = 1 + max(seg_of(n) for n, _ in named)
+        order = []
+        for sg in range(nseg):
+            first = [n for grp in groups if all(g in have for g in grp) and seg_of(grp[0]) == sg for n in grp]
+            assert all(seg_of(n) == sg for n in first), "a weight group straddles two stages"
+            seen = set(first)
+            order += first + [n for n, _ in named if seg_of(n) == sg and n not in seen]
+        named = [(n, have[n]) for n in order]
         dev = named[0][1].device
         total, offs = 0, {}
         for n, p in named:
@@ -65,6 +73,15 @@ class FlatArena:
         self.names: List[str] = [n for n, _ in named]
         self.params = [p for _, p in named]
         self.offsets = offs
+        # [lo, hi) of every stage inside the arenas (empty stages: lo == hi)
+        self.segment_ranges = []
+        lo = 0
+        for sg in range(nseg):
+            mine = [n for n in self.names if seg_of(n) == sg]
+            hi = (offs[mine[-1]] + (have[mine[-1]].numel() + 7) // 8 * 8) if mine else lo
+            self.segment_ranges.append((lo, hi))
+            lo = hi
+        assert lo == total
         self.flat_w = None
         self._t_count = 0
         if bf16_mirror:
