@@ -304,12 +304,20 @@ def main():
         s_.record(); launch(); e_.record()
         cq_rec.append((s_, e_, B_, Ll, Ls, D_))
     ops.CQ_HOOK = cq_hook
+    cqa_rec = []
+
+    def cqa_hook(launch, which, B_, Lc_, Lq_, D_):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record(); launch(); e_.record()
+        cqa_rec.append((s_, e_, which, B_, Lc_, Lq_, D_))
+    ops.CQ_APPLY_HOOK = cqa_hook
     for _ in range(2):          # every rank takes part (the steps contain the gradient all-reduce)
         eager_step()
     torch.cuda.synchronize()
     ops.GEMM_HOOK = None
     ops.GEMM2_HOOK = None
     ops.CQ_HOOK = None
+    ops.CQ_APPLY_HOOK = None
     timed_steps_for_hook = 2
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -389,6 +397,31 @@ def main():
                                       "frac": round(by / t_ / 8e12, 4), "algorithmic_bytes_per_launch": by,
                                       "mfma_frac": round(fl / t_ / (MFMA_BF16_PEAK_TFLOPS * 1e12), 5),
                                       "note": "AI = 16 flop/B: HBM-bound by construction (<= 5 % of MFMA peak stand-alone)"}
+        fw = [r for r in cqa_rec if r[2] == "fwd" and r[4] >= r[5]]     # q2v direction (context = video)
+        if fw and cq_rec and gs:
+            # the north-star's named target, reported under that name: the fused CQ block =
+            # score + both softmaxes + apply stage (two fused kernels) + cqa_linear (the LDS-DMA GEMM), q2v direction.
+            # FLOPs: SURVEY 8d's 1.12 GFLOP per clip (2*T*4D*D for cqa_linear + the three K = L contractions + the score);
+            # bytes: read C, Q once + write the [T, D] output once (the concat stays on chip in the ideal schedule).
+            _, _, _, B_, Lc_, Lq_, D_ = fw[0]
+            t_apply = sum(r[0].elapsed_time(r[1]) for r in fw) / len(fw) * 1e-3
+            t_score = sum(r[0].elapsed_time(r[1]) for r in cq_rec if r[3] == Lc_) / max(1, sum(1 for r in cq_rec if r[3] == Lc_)) * 1e-3
+            cqa = [r for r in timer.records if abs(r[2] - 2.0 * B_ * Lc_ * 4 * D_ * D_) < 1.0]        # [B*T, D, 4D] products
+            t_lin = sum(r[0].elapsed_time(r[1]) for r in cqa) / max(1, len(cqa)) * 1e-3 if cqa else float("nan")
+            flops = B_ * (2.0 * Lc_ * 4 * D_ * D_ + 3 * 2.0 * Lc_ * Lq_ * D_ + 2.0 * Lc_ * Lq_ * D_)
+            nbytes = B_ * ((Lc_ + Lq_) * D_ * 2 + Lc_ * D_ * 2)
+            t_all = t_score + t_apply + t_lin
+            out["fused_cq_block"] = {
+                "what": "q2v CQAttention block (models/layers.py:417-437): cq_score_kernel + cq_apply_fwd + cqa_linear GEMM",
+                "us": {"score": round(t_score * 1e6, 1), "apply": round(t_apply * 1e6, 1), "cqa_linear": round(t_lin * 1e6, 1)},
+                "gflop": round(flops / 1e9, 2), "mfma": {"achieved": round(flops / t_all / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                                          "unit": "TFLOP/s", "frac": round(flops / t_all / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4)},
+                "hbm": {"achieved": round(nbytes / t_all / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(nbytes / t_all / 8e12, 4), "algorithmic_bytes": nbytes},
+                "apply_kernel_hbm": {"bytes": B_ * ((Lc_ + Lq_) * D_ * 2 + Lc_ * 4 * D_ * 2),
+                                     "achieved_GBps": round(B_ * ((Lc_ + Lq_) * D_ * 2 + Lc_ * 4 * D_ * 2) / t_apply / 1e9, 1),
+                                     "frac": round(B_ * ((Lc_ + Lq_) * D_ * 2 + Lc_ * 4 * D_ * 2) / t_apply / 8e12, 4),
+                                     "note": "stand-alone apply kernel: reads C, Q, writes the [T, 4D] concat"}}
         if args.workload != "seqpan":
             out["step_mfma_frac"] = None     # the 58 GFLOP/clip figure is SeqPAN's
         if world == 1 and not args.no_cpu_baseline and args.workload == "seqpan":

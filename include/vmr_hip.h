@@ -319,11 +319,39 @@ int vmr_splitk_reduce(const float* slab, float* dst, int nsplit, int64_t n, int 
  * orient 1 (context = short stream): Srow = P_v, Scol = P_t as [B,Ls,ldP] (columns v, zero padded to ldP)
  * -- exactly the (S_row, S_col) layout of vmr_cq_softmax_fwd, whose backward consumes them.  The short operand is
  * staged in LDS by DMA, the long operand is streamed from HBM once as MFMA fragments, the score tile stays in
- * registers.  bf16, D %% 256 == 0 (vmr_cq_score_supported). */
+ * registers.  bf16, D %% 256 == 0 (vmr_cq_score_supported).
+ * Second output form (either pair may be null): Pt_lm / Pv_lm, fp32 "long-major" [B, Ll, SP], SP = Ls rounded up to 8
+ * (P_t = softmax over t, P_v = softmax over v; columns t >= Ls are 0) -- what the fused apply kernels read row by
+ * row with scalar loads, in both orientations. */
 int vmr_cq_score_supported(int Ll, int Ls, int D, int dtype);
 int vmr_cq_score_fwd(const void* lng, const void* short_op, const float* shortterm, const float* mask_long,
-                     const float* mask_short, void* Srow, void* Scol, int B, int Ll, int Ls, int D, int ldP,
-                     int orient, int dtype, void* stream);
+                     const float* mask_short, void* Srow, void* Scol, float* Pt_lm, float* Pv_lm, int B, int Ll,
+                     int Ls, int D, int ldP, int orient, int dtype, void* stream);
+
+/* ------------------------------------------------- CQAttention apply stage (fused) and the block's backward
+ * reference models/layers.py:422-424: c2q = S_.Q, q2c = (S_.S_t^T).C [re-associated as S_.(S_t^T.C)],
+ * out = cat[C, c2q, C*c2q, C*q2c] -> [B*Lc, 4D], the input of cqa_linear.  ctx [B,Lc,D], qry [B,Lq,D] bf16.
+ * S_lm / St_lm: S_ (softmax over q) and S_t (softmax over c) as fp32 LONG-MAJOR arrays [B, Ll, SP] (Ll = the longer
+ * of Lc / Lq, SP = the shorter rounded up to 8): with the context long they are indexed [c][q], with the context
+ * short [q][c] -- i.e. (Pt_lm, Pv_lm) of vmr_cq_score_fwd for orient 0 and (Pv_lm, Pt_lm) for orient 1.
+ * One workgroup per (clip, 128-channel slice); c2q / mid / q2c never exist in HBM.  bf16, D %% 128 == 0, one stream
+ * <= 32 rows and the other <= 256 (vmr_cq_apply_supported).
+ * vmr_cq_apply_bwd: dcat4 [B*Lc,4D] -> dctx, dqry (the apply stage's share) and `parts`, fp32
+ *   [B][D/128][2][LcP][LqP] (LcP, LqP = Lc, Lq rounded up to 16): per-slice partials of dS_ and dS_t, indexed (c, q).
+ * vmr_cq_softmax_bwd_parts: sums the slices and applies both softmax backwards: dS_lm fp32 long-major [B, Ll, SP]
+ *   and dterm[b, s] = sum_l dS (the gradient of the rank-1 term on the short stream).
+ * vmr_cq_score_bwd: S2[l,s] = lng[l,:].sht[s,:] => dlng = dS.sht, dsht = dS^T.lng (the two score operands). */
+#define VMR_CQ_APPLY_PARTS_FLOATS(B, Lc, Lq, D) \
+  ((int64_t)(B) * ((D) / 128) * 2 * (((Lc) + 15) / 16 * 16) * (((Lq) + 15) / 16 * 16))
+int vmr_cq_apply_supported(int Lc, int Lq, int D, int dtype);
+int vmr_cq_apply_fwd(const void* ctx, const void* qry, const float* S_lm, const float* St_lm, void* out, int B, int Lc,
+                     int Lq, int D, int dtype, void* stream);
+int vmr_cq_apply_bwd(const void* dcat4, const void* ctx, const void* qry, const float* S_lm, const float* St_lm,
+                     void* dctx, void* dqry, float* parts, int B, int Lc, int Lq, int D, int dtype, void* stream);
+int vmr_cq_softmax_bwd_parts(const float* parts, const float* S_lm, const float* St_lm, float* dS_lm, float* dterm,
+                             int B, int Lc, int Lq, int D, void* stream);
+int vmr_cq_score_bwd(const void* lng, const void* sht, const float* dS_lm, void* dlng, void* dsht, int B, int Ll, int Ls,
+                     int D, int dtype, void* stream);
 
 /* ------------------------------------------------------------ WeightedPool
  * reference models/layers.py:440-453: alpha = softmax_l(x[b,l,:].w + (1-mask[b,l])*-1e30),

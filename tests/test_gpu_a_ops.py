@@ -664,6 +664,59 @@ def test_cq_score_kernel_matches_composed_path(dev, dims, orient):
     _close(Sr, Cr, 1e-2, "fused vs composed S_row"); _close(Sc, Cc, 1e-2, "fused vs composed S_col")
 
 
+@pytest.mark.parametrize("dims", [(64, 128, 20, 1024), (3, 70, 9, 256), (2, 128, 32, 512), (2, 33, 1, 256), (5, 128, 17, 768)])
+@pytest.mark.parametrize("orient", [0, 1])
+def test_fused_cq_block_matches_torch(dev, dims, orient):
+    """csrc/cqapply.hip + cqscore.hip: the whole CQAttention core (trilinear score, both masked softmaxes, c2q,
+    q2c = S_.(S_t^T.C), the 4-way concat; reference models/layers.py:417-424) forward and backward against fp32 torch
+    autograd on the same bf16 inputs, both directions (context = video / context = query), ragged lengths, and the
+    composed HIP path (batched GEMMs + cat4) on the same inputs."""
+    ops = _ops()
+    B, Ll, Ls, D = dims
+    torch.manual_seed(53)
+    dt = torch.bfloat16
+    lng = (torch.randn(B, Ll, D, device=dev) / math.sqrt(D) * 4).to(dt).requires_grad_(True)     # the score operands
+    sht = torch.randn(B, Ls, D, device=dev).to(dt).requires_grad_(True)
+    term = torch.randn(B, Ls, device=dev, requires_grad=True)
+    Lc, Lq = (Ll, Ls) if orient == 0 else (Ls, Ll)
+    ctx = torch.randn(B, Lc, D, device=dev).to(dt).requires_grad_(True)                            # the apply-stage streams
+    qry = torch.randn(B, Lq, D, device=dev).to(dt).requires_grad_(True)
+    ll = torch.randint(1, Ll + 1, (B,), device=dev); ll[0] = Ll
+    ls = torch.randint(1, Ls + 1, (B,), device=dev); ls[0] = Ls
+    ml = (torch.arange(Ll, device=dev)[None] < ll[:, None]).float()
+    ms = (torch.arange(Ls, device=dev)[None] < ls[:, None]).float()
+    assert ops.cq_block_supported(Lc, Lq, D, dt)
+    out = ops.cq_block(ctx, qry, lng, sht, term, ml, ms, orient)
+    assert out.shape == (B * Lc, 4 * D)
+    f = lambda t: t.detach().float().requires_grad_(True)
+    cr, qr, lr, sr, tr = f(ctx), f(qry), f(lng), f(sht), term.detach().clone().requires_grad_(True)
+    if orient == 0:
+        S = lr @ sr.transpose(1, 2) + tr[:, None, :]
+        cmask, qmask = ml, ms
+    else:
+        S = sr @ lr.transpose(1, 2) + tr[:, :, None]
+        cmask, qmask = ms, ml
+    S_ = torch.softmax(S + (1 - qmask[:, None, :]) * -1e30, dim=2)
+    S_t = torch.softmax(S + (1 - cmask[:, :, None]) * -1e30, dim=1)
+    c2q = S_ @ qr
+    q2c = (S_ @ S_t.transpose(1, 2)) @ cr                                  # the reference's association (layers.py:423)
+    ref = torch.cat([cr, c2q, cr * c2q, cr * q2c], dim=2).reshape(B * Lc, 4 * D)
+    _close(out, ref, 2e-2, "cat4")
+    g = torch.randn_like(ref).to(dt)
+    ga = torch.autograd.grad(out, [ctx, qry, lng, sht, term], g)
+    gb = torch.autograd.grad(ref, [cr, qr, lr, sr, tr], g.float())
+    for a, b, name in zip(ga, gb, ("dctx", "dqry", "dlong", "dshort", "dterm")):
+        _close(a, b, 4e-2, name)
+    # the composed path (score kernel + three batched GEMMs + cat4) on the same inputs
+    Sp, Stp = ops.cq_score(lng, sht, term, ml, ms, orient)
+    c2 = ops.bmm(Sp, qry, 0, 1); mid = ops.bmm(Stp, ctx, 1, 1); q2 = ops.bmm(Sp, mid, 0, 1)
+    comp = ops.cat4(ctx.reshape(B * Lc, D), c2.reshape(B * Lc, D), q2.reshape(B * Lc, D))
+    _close(out, comp, 1e-2, "fused vs composed cat4")
+    gc = torch.autograd.grad(comp, [ctx, qry, lng, sht, term], g)
+    for a, b, name in zip(ga, gc, ("dctx", "dqry", "dlong", "dshort", "dterm")):
+        _close(a, b, 6e-2, name + " fused vs composed")   # (composed: bf16 probabilities; fused: fp32)
+
+
 def test_soft_ce_matches_torch(dev):
     ops = _ops()
     torch.manual_seed(6)

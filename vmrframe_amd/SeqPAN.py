@@ -398,9 +398,12 @@ class SeqPAN(nn.Module):
         w4C, w4Q, w4mlu = self.P(prefix + ".w4C"), self.P(prefix + ".w4Q"), self.P(prefix + ".w4mlu")
         cd = ops.dropout(ctx, dc.next(prefix + ".c"))
         qd = ops.dropout(qry, dc.next(prefix + ".q"))
+        whole = ops.cq_block_supported(Lc, Lq, D, cdt)   # score + softmaxes + apply stage as fused kernels each way
         if Lq <= Lc:      # (rank-1 terms: one scale-shift kernel + one matrix-vector kernel on the short stream)
             bop = ops.scale_shift(qd, w4mlu, w4C)
             colterm = ops.narrow_linear(qd.reshape(B * Lq, D), w4Q, None, N=1).view(B, Lq)
+            if whole:
+                return self._lin(ops.cq_block(ctx, qry, cd, bop, colterm, cmask, qmask, 0), prefix + ".cqa_linear")
             fused = ops.cq_score_supported(Lc, Lq, D, cdt)
             if fused:     # score + both softmaxes in one kernel: short operand in LDS, video rows streamed once
                 S_p, S_tp = ops.cq_score(cd, bop, colterm, cmask, qmask, 0)
@@ -409,6 +412,8 @@ class SeqPAN(nn.Module):
         else:
             aop = ops.scale_shift(cd, w4mlu, w4Q)
             rowterm = ops.narrow_linear(cd.reshape(B * Lc, D), w4C, None, N=1).view(B, Lc)
+            if whole:
+                return self._lin(ops.cq_block(ctx, qry, qd, aop, rowterm, qmask, cmask, 1), prefix + ".cqa_linear")
             fused = ops.cq_score_supported(Lq, Lc, D, cdt)
             if fused:
                 S_p, S_tp = ops.cq_score(qd, aop, rowterm, qmask, cmask, 1)

@@ -20,6 +20,11 @@ LN_BWD_MAX_BLOCKS = 8192   # == VMR_LN_BWD_MAX_BLOCKS
 MATCH_LOSS_SCRATCH = 512   # == VMR_MATCH_LOSS_SCRATCH
 
 
+def cq_apply_parts_floats(B: int, Lc: int, Lq: int, D: int) -> int:
+    """== VMR_CQ_APPLY_PARTS_FLOATS(B, Lc, Lq, D)"""
+    return B * (D // 128) * 2 * ((Lc + 15) // 16 * 16) * ((Lq + 15) // 16 * 16)
+
+
 def ln_bwd_ws_floats(rows: int, D: int) -> int:
     """== VMR_LN_BWD_WS_FLOATS(rows, D)"""
     return ((rows + 7) // 8) * 2 * (512 if D <= 512 else (1024 if D <= 1024 else 2048))
@@ -97,7 +102,12 @@ SIGNATURES = {
     "vmr_char_cnn_bwd": [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U, _P, _P],
     "vmr_resample_pad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     "vmr_cq_score_supported": [_I, _I, _I, _I],
-    "vmr_cq_score_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vmr_cq_score_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vmr_cq_apply_supported": [_I, _I, _I, _I],
+    "vmr_cq_apply_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vmr_cq_apply_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vmr_cq_softmax_bwd_parts": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vmr_cq_score_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vmr_cq_softmax_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_cq_softmax_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_soft_ce_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],

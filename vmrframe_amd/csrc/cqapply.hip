@@ -1,0 +1,713 @@
+// cqapply.hip -- the apply stage of CQAttention (reference models/layers.py:422-424) and the block's backward, fused:
+//     c2q = S_ . Q          mid = S_t^T . C          q2c = S_ . mid   ( == (S_ . S_t^T) . C re-associated )
+//     out = [C | c2q | C*c2q | C*q2c]                                  (the input of cqa_linear)
+// S_ / S_t are the two masked softmaxes of the trilinear score.
+//
+// Shapes: one stream is long (video, <= 256 rows), the other short (query, <= 32 rows), both [rows, D].  All three
+// contractions have K = 20..128 and N = D: per clip 15-50 MFLOP against 1.3 MB of mandatory traffic (the 4-way concat
+// alone is 1 MB) -- HBM-bound, so the kernels are organised around memory, not MFMA:
+//   * workgroup = (clip, 128-channel slice): 512 workgroups at cfg2, every CU busy (the composed path ran 14 launches
+//     of a 128-wide register-staged GEMM per direction with K or N = 20);
+//   * thread = one bf16 channel PAIR (4-byte accesses, 256 B per wave-instruction); the SHORT stream's rows of that
+//     pair live in registers; a wave walks rows of the LONG stream;
+//   * the probabilities are wave-uniform: they come in as fp32 "long-major" arrays [B, Ll, SP] (SP = short length
+//     rounded up to 8, written by cqscore.hip); a row is one coalesced load (lane s holds p[s]) and reaches the FMAs
+//     through v_readlane (see ld_probs);
+//   * the long stream is read from HBM once per pass, NB = 8 row loads in flight per thread; `mid` / c2q / q2c never
+//     exist in HBM; the concat is written straight from registers.
+// Backward (per clip and slice): recomputes mid / c2q / q2c, produces dC, dQ in the same layout, and the THREE K = D
+// contractions (dS_ = dc2q.Q^T + dq2c.mid^T, dS_t = C.dmid^T) as per-slice fp32 partial [Lc, Lq] tiles on MFMA --
+// operands built in fragment layout straight from global 16-byte loads (dc2q = g2 + g3*C, dq2c = g4*C) or read from
+// small bf16 LDS images (mid, dmid).  cq_softmax_bwd_parts sums the slices and applies both softmax backwards (dS,
+// long-major fp32); cq_score_bwd turns dS into the gradients of the two score operands with the same skeleton.
+// bf16 only; anything else stays on the composed path (ops.py).
+#include "common.h"
+
+namespace {
+
+constexpr int DS = 128;          // channels per workgroup
+constexpr int IMG_LD = DS + 8;   // bf16 LDS image row: 272 B (16 rows hit 16 different 16-byte bank groups)
+constexpr int NB = 8;            // long-stream rows requested back to back before any is consumed
+
+struct ApplyArgs {
+  const bf16_t* C; const bf16_t* Q;      // ctx [B,Lc,D], qry [B,Lq,D]
+  const float* A1; const float* A2;      // S_ and S_t, long-major fp32 [B, Ll, SP]
+  bf16_t* out;                           // fwd: cat4 [B*Lc, 4D]
+  const bf16_t* g;                       // bwd: dcat4 [B*Lc, 4D]
+  bf16_t* dC; bf16_t* dQ; float* parts;  // bwd outputs; parts [B][nsl][2][LcP][LqP] fp32, indexed (c, q)
+  int Lc, Lq, D, LcP, LqP;
+};
+
+__device__ __forceinline__ void st2(bf16_t* p, float a, float b) { const float v[2] = {a, b}; Vec2<bf16_t>::store(p, v); }
+__device__ __forceinline__ uint32_t ldw(const bf16_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+__device__ __forceinline__ float lo16(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi16(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+// NB rows of one channel pair, unconditional (row index clamped: a conditional load gets its own s_waitcnt)
+__device__ __forceinline__ void ld_rows(const bf16_t* base, int64_t ld, int r0, int rlast, uint32_t (&v)[NB]) {
+#pragma unroll
+  for (int j = 0; j < NB; ++j) v[j] = ldw(base + (int64_t)min(r0 + j, rlast) * ld);
+}
+// the short stream's rows of this thread's channel pair -> registers (rows past `n`: zero)
+template <int SP>
+__device__ __forceinline__ void ld_short(const bf16_t* base, int64_t ld, int n, float (&r)[SP][2]) {
+  uint32_t w[SP];
+#pragma unroll
+  for (int s = 0; s < SP; ++s) w[s] = ldw(base + (int64_t)min(s, n - 1) * ld);
+#pragma unroll
+  for (int s = 0; s < SP; ++s) { r[s][0] = s < n ? lo16(w[s]) : 0.f; r[s][1] = s < n ? hi16(w[s]) : 0.f; }
+}
+
+// A row of SP probabilities is loaded ONCE per wave as one coalesced vector load -- lane s holds p[s] -- in the same
+// batch as the long-stream rows, and broadcast to the FMAs through v_readlane (an SGPR operand).  (Tried before: fp32
+// LDS images read as wave-uniform ds_read_b128 -- the LDS pipe became the bound, SQ_WAIT_INST_LDS = half of all wave
+// cycles; plain `prow[s]` global reads -- hipcc turned only some of them into s_load, the rest into 64-lane same-address
+// vector loads whose latency sat exposed in every row.)
+template <int SP>
+__device__ __forceinline__ void ld_probs(const float* __restrict__ A, int r0, int rlast, int lane, float (&pv)[NB]) {
+  const int col = lane < SP ? lane : 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) pv[j] = A[(int64_t)min(r0 + j, rlast) * SP + col];
+}
+__device__ __forceinline__ float bcast(float v, int s) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), s)); }
+template <int SP>
+__device__ __forceinline__ void dot_rows(float pv, const float (&r)[SP][2], float& o0, float& o1) {
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int s = 0; s < SP; ++s) { const float p = bcast(pv, s); a0 += p * r[s][0]; a1 += p * r[s][1]; }
+  o0 = a0; o1 = a1;
+}
+template <int SP>
+__device__ __forceinline__ void axpy_rows(float pv, float x0, float x1, float (&acc)[SP][2]) {
+#pragma unroll
+  for (int s = 0; s < SP; ++s) { const float p = bcast(pv, s); acc[s][0] += p * x0; acc[s][1] += p * x1; }
+}
+// Cross-wave sum of per-thread accumulators acc[SP][2]: every wave parks its partial in its own slot of
+// red[4][SP][DS] (plain 8-byte stores), a barrier, then whoever needs a row adds the four slots.  (LDS float atomics
+// into one shared [SP][DS] tile were the first version: ds_add_f32 runs at ~120 cycles per wave-instruction and the
+// 48-144 of them per wave were 2/3 of these kernels' time.)
+template <int SP>
+__device__ __forceinline__ void red_put(float* __restrict__ red, int w, const float (&acc)[SP][2], int lane) {
+#pragma unroll
+  for (int s = 0; s < SP; ++s) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    *reinterpret_cast<f32x2*>(red + ((w * SP + s) * DS + 2 * lane)) = (f32x2){acc[s][0], acc[s][1]};
+  }
+}
+template <int SP>
+__device__ __forceinline__ void red_row(const float* __restrict__ red, int s, int lane, float& o0, float& o1) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 t = *reinterpret_cast<const f32x2*>(red + (s * DS + 2 * lane));
+#pragma unroll
+  for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x2*>(red + ((w * SP + s) * DS + 2 * lane));
+  o0 = t[0]; o1 = t[1];
+}
+template <int SP>
+__device__ __forceinline__ void red_get(const float* __restrict__ red, float (&r)[SP][2], int lane) {
+#pragma unroll
+  for (int s = 0; s < SP; ++s) red_row<SP>(red, s, lane, r[s][0], r[s][1]);
+}
+#define WAVE_ID() __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))
+
+// =====================================================================================================================
+// forward, context = LONG stream (query short): A1[c][q] = S_, A2[c][q] = S_t
+// =====================================================================================================================
+template <int SP>
+__global__ __launch_bounds__(256) void cq_apply_fwd_clong(ApplyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);          // [4][SP][DS]
+  const int lane = threadIdx.x & 63, w = WAVE_ID();
+  const int b = blockIdx.y, d0 = blockIdx.x * DS + 2 * lane, D = a.D;
+  const bf16_t* Cb = a.C + (int64_t)b * a.Lc * D + d0;
+  const float* A1 = a.A1 + (int64_t)b * a.Lc * SP;
+  const float* A2 = a.A2 + (int64_t)b * a.Lc * SP;
+  float Qr[SP][2], mid[SP][2];
+  ld_short<SP>(a.Q + (int64_t)b * a.Lq * D + d0, D, a.Lq, Qr);
+#pragma unroll
+  for (int q = 0; q < SP; ++q) mid[q][0] = mid[q][1] = 0.f;
+  for (int c0 = w * NB; c0 < a.Lc; c0 += 4 * NB) {      // mid = S_t^T . C over this wave's rows
+    uint32_t cr[NB];
+    float p2[NB];
+    ld_rows(Cb, D, c0, a.Lc - 1, cr);
+    ld_probs<SP>(A2, c0, a.Lc - 1, lane, p2);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float ok = c0 + j < a.Lc ? 1.f : 0.f;
+      axpy_rows<SP>(p2[j], ok * lo16(cr[j]), ok * hi16(cr[j]), mid);
+    }
+  }
+  red_put<SP>(red, w, mid, lane);
+  __syncthreads();
+  red_get<SP>(red, mid, lane);
+  bf16_t* ob = a.out + (int64_t)b * a.Lc * 4 * D + d0;
+  for (int c0 = w * NB; c0 < a.Lc; c0 += 4 * NB) {
+    uint32_t cr[NB];
+    float p1[NB];
+    ld_rows(Cb, D, c0, a.Lc - 1, cr);
+    ld_probs<SP>(A1, c0, a.Lc - 1, lane, p1);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int c = c0 + j;
+      float x0, x1, y0, y1;
+      const float c0f = lo16(cr[j]), c1f = hi16(cr[j]);
+      dot_rows<SP>(p1[j], Qr, x0, x1);                  // c2q
+      dot_rows<SP>(p1[j], mid, y0, y1);                 // q2c
+      if (c < a.Lc) {
+        bf16_t* o = ob + (int64_t)c * 4 * D;
+        *reinterpret_cast<uint32_t*>(o) = cr[j];
+        st2(o + D, x0, x1);
+        st2(o + 2 * D, c0f * x0, c1f * x1);
+        st2(o + 3 * D, c0f * y0, c1f * y1);
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
+// forward, context = SHORT stream (query long): A1[q][c] = S_[c,q], A2[q][c] = S_t[c,q]
+// =====================================================================================================================
+template <int SP>
+__global__ __launch_bounds__(256) void cq_apply_fwd_cshort(ApplyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);          // [2][4][SP][DS]
+  const int lane = threadIdx.x & 63, w = WAVE_ID();
+  const int b = blockIdx.y, d0 = blockIdx.x * DS + 2 * lane, D = a.D;
+  const bf16_t* Cb = a.C + (int64_t)b * a.Lc * D + d0;
+  const bf16_t* Qb = a.Q + (int64_t)b * a.Lq * D + d0;
+  const float* A1 = a.A1 + (int64_t)b * a.Lq * SP;
+  const float* A2 = a.A2 + (int64_t)b * a.Lq * SP;
+  float Cr[SP][2], a1[SP][2], a2[SP][2];
+  ld_short<SP>(Cb, D, a.Lc, Cr);
+#pragma unroll
+  for (int c = 0; c < SP; ++c) a1[c][0] = a1[c][1] = a2[c][0] = a2[c][1] = 0.f;
+  for (int q0 = w * NB; q0 < a.Lq; q0 += 4 * NB) {
+    uint32_t qr[NB];
+    float p1[NB], p2[NB];
+    ld_rows(Qb, D, q0, a.Lq - 1, qr);
+    ld_probs<SP>(A1, q0, a.Lq - 1, lane, p1);
+    ld_probs<SP>(A2, q0, a.Lq - 1, lane, p2);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float ok = q0 + j < a.Lq ? 1.f : 0.f;
+      float m0, m1;
+      dot_rows<SP>(p2[j], Cr, m0, m1);                                  // mid[q] = sum_c S_t[c,q] C[c]
+      axpy_rows<SP>(p1[j], ok * lo16(qr[j]), ok * hi16(qr[j]), a1);     // c2q[c] += S_[c,q] Q[q]
+      axpy_rows<SP>(p1[j], ok * m0, ok * m1, a2);                       // q2c[c] += S_[c,q] mid[q]
+    }
+  }
+  red_put<SP>(red, w, a1, lane);
+  red_put<SP>(red + 4 * SP * DS, w, a2, lane);
+  __syncthreads();
+  bf16_t* ob = a.out + (int64_t)b * a.Lc * 4 * D + d0;
+  for (int c = w; c < a.Lc; c += 4) {
+    const uint32_t cw = ldw(Cb + (int64_t)c * D);
+    float x0, x1, y0, y1;
+    red_row<SP>(red, c, lane, x0, x1);
+    red_row<SP>(red + 4 * SP * DS, c, lane, y0, y1);
+    bf16_t* o = ob + (int64_t)c * 4 * D;
+    *reinterpret_cast<uint32_t*>(o) = cw;
+    st2(o + D, x0, x1);
+    st2(o + 2 * D, lo16(cw) * x0, hi16(cw) * x1);
+    st2(o + 3 * D, lo16(cw) * y0, hi16(cw) * y1);
+  }
+}
+
+// =====================================================================================================================
+// backward: the shared MFMA phase.  parts[0][c][q] = sum_d dc2q[c,d] Q[q,d] + dq2c[c,d] mid[q,d]   (d S_ partial)
+//                                   parts[1][c][q] = sum_d C[c,d] dmid[q,d]                          (d S_t partial)
+// A operand (rows -> m) = the query side (Q from global; mid, dmid from bf16 LDS images), B operand (rows -> n) = the
+// context side, built in fragment layout from global 16-byte loads.  Result lane: c = n0 + (lane & 15), q = m0 + (lane >> 4) * 4 + r.
+// =====================================================================================================================
+__device__ __forceinline__ bf16x8 ldfrag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+__device__ __forceinline__ void mfma_phase(const ApplyArgs& a, int b, int slice, const bf16_t* midI, const bf16_t* dmidI, int lane,
+                                           int w) {
+  const int D = a.D, mt_n = a.LqP / 16, nt_n = a.LcP / 16;
+  const int kq = (lane >> 4) * 8;
+  const bf16_t* Cb = a.C + (int64_t)b * a.Lc * D + slice * DS;
+  const bf16_t* Qb = a.Q + (int64_t)b * a.Lq * D + slice * DS;
+  const bf16_t* gb = a.g + (int64_t)b * a.Lc * 4 * D + slice * DS;
+  float* pb = a.parts + ((int64_t)b * gridDim.x + slice) * 2 * a.LcP * a.LqP;
+  for (int t = w; t < mt_n * nt_n; t += 4) {
+    const int mt = t % mt_n, nt = t / mt_n;
+    const int qrow = mt * 16 + (lane & 15), crow = nt * 16 + (lane & 15);
+    const int qg = min(qrow, a.Lq - 1), cg = min(crow, a.Lc - 1);     // clamped: those products land in padding
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < DS / 32; ++ks) {
+      const int k = ks * 32 + kq;
+      const bf16x8 fq = ldfrag(Qb + (int64_t)qg * D + k);
+      const bf16x8 fm = ldfrag(midI + qrow * IMG_LD + k);
+      const bf16x8 fd = ldfrag(dmidI + qrow * IMG_LD + k);
+      const bf16x8 c8 = ldfrag(Cb + (int64_t)cg * D + k);
+      const bf16x8 g2 = ldfrag(gb + (int64_t)cg * 4 * D + D + k);
+      const bf16x8 g3 = ldfrag(gb + (int64_t)cg * 4 * D + 2 * D + k);
+      const bf16x8 g4 = ldfrag(gb + (int64_t)cg * 4 * D + 3 * D + k);
+      bf16x8 dc2q, dq2c;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float cf = (float)c8[e];
+        dc2q[e] = (bf16_t)((float)g2[e] + (float)g3[e] * cf);
+        dq2c[e] = (bf16_t)((float)g4[e] * cf);
+      }
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, dc2q, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm, dq2c, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd, c8, acc2, 0, 0, 0);
+    }
+    const int q0 = mt * 16 + (lane >> 4) * 4;
+    float* p1 = pb + (int64_t)crow * a.LqP + q0;
+    *reinterpret_cast<f32x4*>(p1) = acc1;
+    *reinterpret_cast<f32x4*>(p1 + (int64_t)a.LcP * a.LqP) = acc2;
+  }
+}
+
+// =====================================================================================================================
+// backward, context = LONG stream
+// =====================================================================================================================
+template <int SP>
+__global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);                   // [2][4][SP][DS]
+  bf16_t* midI = reinterpret_cast<bf16_t*>(red + 8 * SP * DS);   // [LqP][IMG_LD]
+  bf16_t* dmidI = midI + a.LqP * IMG_LD;
+  const int lane = threadIdx.x & 63, w = WAVE_ID();
+  const int b = blockIdx.y, slice = blockIdx.x, d0 = slice * DS + 2 * lane, D = a.D;
+  const bf16_t* Cb = a.C + (int64_t)b * a.Lc * D + d0;
+  const bf16_t* gb = a.g + (int64_t)b * a.Lc * 4 * D + d0;
+  const float* A1 = a.A1 + (int64_t)b * a.Lc * SP;
+  const float* A2 = a.A2 + (int64_t)b * a.Lc * SP;
+  float Qr[SP][2], mid[SP][2];
+  ld_short<SP>(a.Q + (int64_t)b * a.Lq * D + d0, D, a.Lq, Qr);
+  for (int i = threadIdx.x; i < 2 * a.LqP * IMG_LD; i += 256) midI[i] = (bf16_t)0.f;
+#pragma unroll
+  for (int q = 0; q < SP; ++q) mid[q][0] = mid[q][1] = 0.f;
+  for (int c0 = w * NB; c0 < a.Lc; c0 += 4 * NB) {      // mid (recomputed)
+    uint32_t cr[NB];
+    float p2[NB];
+    ld_rows(Cb, D, c0, a.Lc - 1, cr);
+    ld_probs<SP>(A2, c0, a.Lc - 1, lane, p2);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float ok = c0 + j < a.Lc ? 1.f : 0.f;
+      axpy_rows<SP>(p2[j], ok * lo16(cr[j]), ok * hi16(cr[j]), mid);
+    }
+  }
+  red_put<SP>(red, w, mid, lane);
+  __syncthreads();
+  red_get<SP>(red, mid, lane);
+  if (w == 0) {
+#pragma unroll
+    for (int q = 0; q < SP; ++q)
+      if (q < a.Lq) st2(midI + q * IMG_LD + 2 * lane, mid[q][0], mid[q][1]);
+  }
+  __syncthreads();                                      // everyone has read the mid partials: the slots are re-used below
+  // ---- dQ = S_^T . dc2q, dmid = S_^T . dq2c over this wave's rows
+  float dQa[SP][2], dMa[SP][2];
+#pragma unroll
+  for (int q = 0; q < SP; ++q) dQa[q][0] = dQa[q][1] = dMa[q][0] = dMa[q][1] = 0.f;
+  for (int c0 = w * NB; c0 < a.Lc; c0 += 4 * NB) {
+    uint32_t cr[NB], r2[NB], r3[NB], r4[NB];
+    ld_rows(Cb, D, c0, a.Lc - 1, cr);
+    ld_rows(gb + D, 4 * D, c0, a.Lc - 1, r2);
+    ld_rows(gb + 2 * D, 4 * D, c0, a.Lc - 1, r3);
+    ld_rows(gb + 3 * D, 4 * D, c0, a.Lc - 1, r4);
+    float p1[NB];
+    ld_probs<SP>(A1, c0, a.Lc - 1, lane, p1);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float ok = c0 + j < a.Lc ? 1.f : 0.f;
+      axpy_rows<SP>(p1[j], ok * (lo16(r2[j]) + lo16(r3[j]) * lo16(cr[j])), ok * (hi16(r2[j]) + hi16(r3[j]) * hi16(cr[j])), dQa);
+      axpy_rows<SP>(p1[j], ok * lo16(r4[j]) * lo16(cr[j]), ok * hi16(r4[j]) * hi16(cr[j]), dMa);
+    }
+  }
+  red_put<SP>(red, w, dQa, lane);
+  red_put<SP>(red + 4 * SP * DS, w, dMa, lane);
+  __syncthreads();
+  bf16_t* dQb = a.dQ + (int64_t)b * a.Lq * D + d0;
+  for (int q = w; q < a.Lq; q += 4) {
+    float x0, x1;
+    red_row<SP>(red, q, lane, x0, x1);
+    st2(dQb + (int64_t)q * D, x0, x1);
+  }
+  red_get<SP>(red + 4 * SP * DS, dMa, lane);
+  if (w == 0) {
+#pragma unroll
+    for (int q = 0; q < SP; ++q)
+      if (q < a.Lq) st2(dmidI + q * IMG_LD + 2 * lane, dMa[q][0], dMa[q][1]);
+  }
+  // ---- dC = g1 + g3*c2q + g4*q2c + S_t . dmid
+  bf16_t* dCb = a.dC + (int64_t)b * a.Lc * D + d0;
+  for (int c0 = w * NB; c0 < a.Lc; c0 += 4 * NB) {
+    uint32_t r1[NB], r3[NB], r4[NB];
+    ld_rows(gb, 4 * D, c0, a.Lc - 1, r1);
+    ld_rows(gb + 2 * D, 4 * D, c0, a.Lc - 1, r3);
+    ld_rows(gb + 3 * D, 4 * D, c0, a.Lc - 1, r4);
+    float p1[NB], p2[NB];
+    ld_probs<SP>(A1, c0, a.Lc - 1, lane, p1);
+    ld_probs<SP>(A2, c0, a.Lc - 1, lane, p2);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int c = c0 + j;
+      float x0, x1, y0, y1, z0, z1;
+      dot_rows<SP>(p1[j], Qr, x0, x1);
+      dot_rows<SP>(p1[j], mid, y0, y1);
+      dot_rows<SP>(p2[j], dMa, z0, z1);
+      if (c < a.Lc)
+        st2(dCb + (int64_t)c * D, lo16(r1[j]) + lo16(r3[j]) * x0 + lo16(r4[j]) * y0 + z0,
+            hi16(r1[j]) + hi16(r3[j]) * x1 + hi16(r4[j]) * y1 + z1);
+    }
+  }
+  __syncthreads();                                      // the dmid image is complete
+  mfma_phase(a, b, slice, midI, dmidI, lane, w);
+}
+
+// =====================================================================================================================
+// backward, context = SHORT stream
+// =====================================================================================================================
+template <int SP>
+__global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);                   // [4][SP][DS], used for three reductions in turn
+  bf16_t* midI = reinterpret_cast<bf16_t*>(red + 4 * SP * DS);   // [LqP][IMG_LD]
+  bf16_t* dmidI = midI + a.LqP * IMG_LD;
+  const int lane = threadIdx.x & 63, w = WAVE_ID();
+  const int b = blockIdx.y, slice = blockIdx.x, d0 = slice * DS + 2 * lane, D = a.D;
+  const bf16_t* Cb = a.C + (int64_t)b * a.Lc * D + d0;
+  const bf16_t* Qb = a.Q + (int64_t)b * a.Lq * D + d0;
+  const bf16_t* gb = a.g + (int64_t)b * a.Lc * 4 * D + d0;
+  const float* A1 = a.A1 + (int64_t)b * a.Lq * SP;
+  const float* A2 = a.A2 + (int64_t)b * a.Lq * SP;
+  for (int r = a.Lq + w; r < a.LqP; r += 4) {           // image rows past Lq feed padded tile rows: zero
+    st2(midI + r * IMG_LD + 2 * lane, 0.f, 0.f);
+    st2(dmidI + r * IMG_LD + 2 * lane, 0.f, 0.f);
+  }
+  __syncthreads();
+  bf16_t* dQb = a.dQ + (int64_t)b * a.Lq * D + d0;
+  constexpr int RW = SP / 4;                            // context rows c = w, w + 4, ... of this wave (<= SP / 4)
+  float xr[RW][2], yr[RW][2], zr[RW][2];
+  {   // pass A: forward quantities (c2q, q2c accumulators; the mid image)
+    float Cr[SP][2], a1[SP][2], a2[SP][2];
+    ld_short<SP>(Cb, D, a.Lc, Cr);
+#pragma unroll
+    for (int c = 0; c < SP; ++c) a1[c][0] = a1[c][1] = a2[c][0] = a2[c][1] = 0.f;
+    for (int q0 = w * NB; q0 < a.Lq; q0 += 4 * NB) {
+      uint32_t qr[NB];
+      float p1[NB], p2[NB];
+      ld_rows(Qb, D, q0, a.Lq - 1, qr);
+      ld_probs<SP>(A1, q0, a.Lq - 1, lane, p1);
+      ld_probs<SP>(A2, q0, a.Lq - 1, lane, p2);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const float ok = q0 + j < a.Lq ? 1.f : 0.f;
+        float m0, m1;
+        dot_rows<SP>(p2[j], Cr, m0, m1);
+        if (q0 + j < a.Lq) st2(midI + (q0 + j) * IMG_LD + 2 * lane, m0, m1);
+        axpy_rows<SP>(p1[j], ok * lo16(qr[j]), ok * hi16(qr[j]), a1);
+        axpy_rows<SP>(p1[j], ok * m0, ok * m1, a2);
+      }
+    }
+    red_put<SP>(red, w, a1, lane);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RW; ++k) red_row<SP>(red, min(w + 4 * k, SP - 1), lane, xr[k][0], xr[k][1]);
+    __syncthreads();
+    red_put<SP>(red, w, a2, lane);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RW; ++k) red_row<SP>(red, min(w + 4 * k, SP - 1), lane, yr[k][0], yr[k][1]);
+    __syncthreads();
+  }
+  {   // pass B: dQ rows, the dmid image, dC_mid accumulators
+    float X1[SP][2], X2[SP][2], a3[SP][2];               // dc2q, dq2c rows of this channel pair
+#pragma unroll
+    for (int c = 0; c < SP; ++c) {
+      const int cc = min(c, a.Lc - 1);
+      const bf16_t* gr = gb + (int64_t)cc * 4 * D;
+      const uint32_t cv = ldw(Cb + (int64_t)cc * D), g2 = ldw(gr + D), g3 = ldw(gr + 2 * D), g4 = ldw(gr + 3 * D);
+      const float ok = c < a.Lc ? 1.f : 0.f;
+      X1[c][0] = ok * (lo16(g2) + lo16(g3) * lo16(cv)); X1[c][1] = ok * (hi16(g2) + hi16(g3) * hi16(cv));
+      X2[c][0] = ok * (lo16(g4) * lo16(cv)); X2[c][1] = ok * (hi16(g4) * hi16(cv));
+      a3[c][0] = a3[c][1] = 0.f;
+    }
+    for (int q0 = w * NB; q0 < a.Lq; q0 += 4 * NB) {
+      float p1[NB], p2[NB];
+      ld_probs<SP>(A1, q0, a.Lq - 1, lane, p1);
+      ld_probs<SP>(A2, q0, a.Lq - 1, lane, p2);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int q = q0 + j;
+        const float ok = q < a.Lq ? 1.f : 0.f;
+        float x0, x1, m0, m1;
+        dot_rows<SP>(p1[j], X1, x0, x1);                 // dQ[q] = sum_c S_[c,q] dc2q[c]
+        dot_rows<SP>(p1[j], X2, m0, m1);                 // dmid[q] = sum_c S_[c,q] dq2c[c]
+        if (q < a.Lq) {
+          st2(dQb + (int64_t)q * D, x0, x1);
+          st2(dmidI + q * IMG_LD + 2 * lane, m0, m1);
+        }
+        axpy_rows<SP>(p2[j], ok * m0, ok * m1, a3);      // dC_mid[c] += S_t[c,q] dmid[q]
+      }
+    }
+    red_put<SP>(red, w, a3, lane);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < RW; ++k) red_row<SP>(red, min(w + 4 * k, SP - 1), lane, zr[k][0], zr[k][1]);
+  bf16_t* dCb = a.dC + (int64_t)b * a.Lc * D + d0;
+#pragma unroll
+  for (int k = 0; k < RW; ++k) {
+    const int c = w + 4 * k;
+    if (c < a.Lc) {
+      const bf16_t* gr = gb + (int64_t)c * 4 * D;
+      const uint32_t g1 = ldw(gr), g3 = ldw(gr + 2 * D), g4 = ldw(gr + 3 * D);
+      st2(dCb + (int64_t)c * D, lo16(g1) + lo16(g3) * xr[k][0] + lo16(g4) * yr[k][0] + zr[k][0],
+          hi16(g1) + hi16(g3) * xr[k][1] + hi16(g4) * yr[k][1] + zr[k][1]);
+    }
+  }
+  mfma_phase(a, b, slice, midI, dmidI, lane, w);
+}
+
+// =====================================================================================================================
+// both softmax backwards on the summed per-slice partials, everything long-major [Ll][SP] (l = long index, s = short):
+//   context long  (c = l, q = s): dS = S_ (dS_ - rowdot_l(dS_ S_)) + S_t (dS_t - coldot_s(dS_t S_t))
+//   context short (c = s, q = l): dS = S_ (dS_ - coldot_s(dS_ S_)) + S_t (dS_t - rowdot_l(dS_t S_t))
+//   dterm[s] = sum_l dS[l][s]   (the gradient of the rank-1 term that rides on the short stream)
+// =====================================================================================================================
+__global__ __launch_bounds__(1024) void cq_softmax_bwd_parts_kernel(const float* __restrict__ parts, int nparts,
+                                                                   const float* __restrict__ A1, const float* __restrict__ A2,
+                                                                   float* __restrict__ dS, float* __restrict__ dterm, int Ll,
+                                                                   int Ls, int SP, int LcP, int LqP, int ctx_long) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n = Ll * SP;
+  float* g1 = reinterpret_cast<float*>(smem);          // dS_ (long-major), later dS
+  float* g2 = g1 + n;                                  // dS_t
+  float* p1 = g2 + n;                                  // S_
+  float* p2 = p1 + n;                                  // S_t
+  float* cdot = p2 + n;                                // [SP]
+  float* stripe = cdot + SP;                           // [1024]
+  const int NT = blockDim.x, NW = NT >> 6;             // 1024 threads: the partial sums are latency-bound, 12 -> 3 rounds
+  const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* pb = parts + (int64_t)b * nparts * 2 * LcP * LqP;
+  const int64_t tile = (int64_t)LcP * LqP;
+  // element (l, s) of the partial tiles: (c, q) = (l, s) or (s, l)
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const int l = i / SP, s = i - l * SP;
+    float s1 = 0.f, s2 = 0.f;
+    if (s < Ls) {
+      const float* pp = pb + (ctx_long ? (int64_t)l * LqP + s : (int64_t)s * LqP + l);
+#pragma unroll 8
+      for (int p = 0; p < nparts; ++p) { s1 += pp[(int64_t)p * 2 * tile]; s2 += pp[(int64_t)p * 2 * tile + tile]; }
+    }
+    g1[i] = s1; g2[i] = s2;
+    p1[i] = A1[(int64_t)b * n + i];
+    p2[i] = A2[(int64_t)b * n + i];
+  }
+  __syncthreads();
+  // column dots (over l, per s) of the matrix whose softmax ran over the long index: 256 / SP stripes of rows
+  const float* gcol = ctx_long ? g2 : g1;
+  const float* pcol = ctx_long ? p2 : p1;
+  const int NS = NT / SP, ps = threadIdx.x % SP, pst = threadIdx.x / SP;
+  {
+    float d = 0.f;
+    if (pst < NS)
+      for (int l = pst; l < Ll; l += NS) d += gcol[l * SP + ps] * pcol[l * SP + ps];
+    stripe[threadIdx.x] = d;
+    __syncthreads();
+    if (threadIdx.x < SP) {
+      float t = 0.f;
+      for (int k = 0; k < NS; ++k) t += stripe[k * SP + threadIdx.x];
+      cdot[threadIdx.x] = t;
+    }
+  }
+  __syncthreads();
+  float* grow = ctx_long ? g1 : g2;
+  const float* prow = ctx_long ? p1 : p2;
+  for (int l = w; l < Ll; l += NW) {                   // row dots (over s, per l) + the combination
+    float d = lane < SP ? grow[l * SP + lane] * prow[l * SP + lane] : 0.f;
+    d = wave_sum(d);
+    if (lane < SP) {
+      const int i = l * SP + lane;
+      const float g = prow[i] * (grow[i] - d) + pcol[i] * (gcol[i] - cdot[lane]);
+      dS[(int64_t)b * n + i] = g;                      // (padding columns: all probabilities are zero there)
+      grow[i] = g;                                     // (a lane only ever re-reads its own element)
+    }
+  }
+  __syncthreads();
+  {
+    float t = 0.f;
+    if (pst < NS)
+      for (int l = pst; l < Ll; l += NS) t += grow[l * SP + ps];
+    stripe[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x < Ls) {
+      float u = 0.f;
+      for (int k = 0; k < NS; ++k) u += stripe[k * SP + threadIdx.x];
+      dterm[(int64_t)b * Ls + threadIdx.x] = u;
+    }
+  }
+}
+
+// =====================================================================================================================
+// score backward products: S2[l,s] = long[l,:] . short[s,:]  =>  dlong[l,:] = sum_s dS[l,s] short[s,:],
+//                                                                 dshort[s,:] = sum_l dS[l,s] long[l,:]
+// dS: fp32 long-major [B, Ll, SP] (scalar-loaded rows)
+// =====================================================================================================================
+struct ScoreBwdArgs {
+  const bf16_t* lng; const bf16_t* sht; const float* dS; bf16_t* dlng; bf16_t* dsht;
+  int Ll, Ls, D;
+};
+
+template <int SP>
+__global__ __launch_bounds__(256) void cq_score_bwd_kernel(ScoreBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);          // [4][SP][DS]
+  const int lane = threadIdx.x & 63, w = WAVE_ID();
+  const int b = blockIdx.y, d0 = blockIdx.x * DS + 2 * lane, D = a.D;
+  const float* dSb = a.dS + (int64_t)b * a.Ll * SP;
+  const bf16_t* Lb = a.lng + (int64_t)b * a.Ll * D + d0;
+  bf16_t* dLb = a.dlng + (int64_t)b * a.Ll * D + d0;
+  float Sreg[SP][2], acc[SP][2];
+  ld_short<SP>(a.sht + (int64_t)b * a.Ls * D + d0, D, a.Ls, Sreg);
+#pragma unroll
+  for (int s = 0; s < SP; ++s) acc[s][0] = acc[s][1] = 0.f;
+  for (int r0 = w * NB; r0 < a.Ll; r0 += 4 * NB) {
+    uint32_t lr[NB];
+    float pd[NB];
+    ld_rows(Lb, D, r0, a.Ll - 1, lr);
+    ld_probs<SP>(dSb, r0, a.Ll - 1, lane, pd);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int r = r0 + j;
+      const float ok = r < a.Ll ? 1.f : 0.f;
+      float x0, x1;
+      dot_rows<SP>(pd[j], Sreg, x0, x1);                // d(long)[r] = sum_s dS[r,s] short[s]
+      if (r < a.Ll) st2(dLb + (int64_t)r * D, x0, x1);
+      axpy_rows<SP>(pd[j], ok * lo16(lr[j]), ok * hi16(lr[j]), acc);   // d(short)[s] += dS[r,s] long[r]
+    }
+  }
+  red_put<SP>(red, w, acc, lane);
+  __syncthreads();
+  bf16_t* dSh = a.dsht + (int64_t)b * a.Ls * D + d0;
+  for (int s = w; s < a.Ls; s += 4) {
+    float x0, x1;
+    red_row<SP>(red, s, lane, x0, x1);
+    st2(dSh + (int64_t)s * D, x0, x1);
+  }
+}
+
+inline int sp_of(int n) { return n <= 8 ? 8 : (n <= 16 ? 16 : (n <= 24 ? 24 : 32)); }
+
+int set_lds(const void* fn, size_t bytes, const char* what) {
+  if (bytes <= 64 * 1024) return 0;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return vmr_fail(-5, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+}  // namespace
+
+// the fused apply kernels take: bf16, D a multiple of 128, one stream <= 32 rows, the other <= 256
+extern "C" int vmr_cq_apply_supported(int Lc, int Lq, int D, int dtype) {
+  if (dtype != VMR_BF16 || D % DS != 0 || Lc < 1 || Lq < 1) return 0;
+  const int shorter = Lc < Lq ? Lc : Lq, longer = Lc < Lq ? Lq : Lc;
+  return shorter <= 32 && longer <= 256;
+}
+
+#define CQ_DISPATCH_SP(SPV, KERNEL, ...)                                                              \
+  switch (SPV) {                                                                                       \
+    case 8: { auto fn = KERNEL<8>; __VA_ARGS__ } break;                                                \
+    case 16: { auto fn = KERNEL<16>; __VA_ARGS__ } break;                                              \
+    case 24: { auto fn = KERNEL<24>; __VA_ARGS__ } break;                                              \
+    default: { auto fn = KERNEL<32>; __VA_ARGS__ } break;                                              \
+  }
+
+extern "C" int vmr_cq_apply_fwd(const void* ctx, const void* qry, const float* S_lm, const float* St_lm, void* out, int B, int Lc,
+                                int Lq, int D, int dtype, void* stream) {
+  VMR_CHECK(ctx && qry && S_lm && St_lm && out, "vmr_cq_apply_fwd: null pointer");
+  VMR_CHECK(vmr_cq_apply_supported(Lc, Lq, D, dtype), "vmr_cq_apply_fwd: unsupported shape Lc=%d Lq=%d D=%d", Lc, Lq, D);
+  VMR_CHECK((((uintptr_t)S_lm | (uintptr_t)St_lm | (uintptr_t)ctx | (uintptr_t)qry | (uintptr_t)out) & 15) == 0,
+            "vmr_cq_apply_fwd: 16-byte alignment");
+  if (B == 0) return 0;
+  ApplyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.C = (const bf16_t*)ctx; a.Q = (const bf16_t*)qry; a.A1 = S_lm; a.A2 = St_lm; a.out = (bf16_t*)out;
+  a.Lc = Lc; a.Lq = Lq; a.D = D;
+  const dim3 grid(D / DS, B);
+  if (Lq <= Lc) {
+    const int SP = sp_of(Lq);
+    const size_t lds = (size_t)4 * SP * DS * 4;
+    CQ_DISPATCH_SP(SP, cq_apply_fwd_clong, if (int rc = set_lds((const void*)fn, lds, "vmr_cq_apply_fwd")) return rc;
+                   hipLaunchKernelGGL(fn, grid, dim3(256), lds, (hipStream_t)stream, a);)
+  } else {
+    const int SP = sp_of(Lc);
+    const size_t lds = (size_t)8 * SP * DS * 4;
+    CQ_DISPATCH_SP(SP, cq_apply_fwd_cshort, if (int rc = set_lds((const void*)fn, lds, "vmr_cq_apply_fwd")) return rc;
+                   hipLaunchKernelGGL(fn, grid, dim3(256), lds, (hipStream_t)stream, a);)
+  }
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_cq_apply_bwd(const void* dcat4, const void* ctx, const void* qry, const float* S_lm, const float* St_lm,
+                                void* dctx, void* dqry, float* parts, int B, int Lc, int Lq, int D, int dtype, void* stream) {
+  VMR_CHECK(dcat4 && ctx && qry && S_lm && St_lm && dctx && dqry && parts, "vmr_cq_apply_bwd: null pointer");
+  VMR_CHECK(vmr_cq_apply_supported(Lc, Lq, D, dtype), "vmr_cq_apply_bwd: unsupported shape Lc=%d Lq=%d D=%d", Lc, Lq, D);
+  VMR_CHECK((((uintptr_t)dcat4 | (uintptr_t)ctx | (uintptr_t)qry | (uintptr_t)parts | (uintptr_t)S_lm | (uintptr_t)St_lm) & 15) == 0,
+            "vmr_cq_apply_bwd: 16-byte alignment");
+  if (B == 0) return 0;
+  ApplyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.C = (const bf16_t*)ctx; a.Q = (const bf16_t*)qry; a.A1 = S_lm; a.A2 = St_lm; a.g = (const bf16_t*)dcat4;
+  a.dC = (bf16_t*)dctx; a.dQ = (bf16_t*)dqry; a.parts = parts;
+  a.Lc = Lc; a.Lq = Lq; a.D = D;
+  a.LcP = (Lc + 15) / 16 * 16; a.LqP = (Lq + 15) / 16 * 16;
+  const dim3 grid(D / DS, B);
+  const size_t img = (size_t)2 * a.LqP * IMG_LD * 2;
+  if (Lq <= Lc) {
+    const int SP = sp_of(Lq);
+    const size_t lds = (size_t)8 * SP * DS * 4 + img;
+    VMR_CHECK(lds <= 160 * 1024, "vmr_cq_apply_bwd: does not fit LDS (%zu B)", lds);
+    CQ_DISPATCH_SP(SP, cq_apply_bwd_clong, if (int rc = set_lds((const void*)fn, lds, "vmr_cq_apply_bwd")) return rc;
+                   hipLaunchKernelGGL(fn, grid, dim3(256), lds, (hipStream_t)stream, a);)
+  } else {
+    const int SP = sp_of(Lc);
+    const size_t lds = (size_t)4 * SP * DS * 4 + img;
+    VMR_CHECK(lds <= 160 * 1024, "vmr_cq_apply_bwd: does not fit LDS (%zu B)", lds);
+    CQ_DISPATCH_SP(SP, cq_apply_bwd_cshort, if (int rc = set_lds((const void*)fn, lds, "vmr_cq_apply_bwd")) return rc;
+                   hipLaunchKernelGGL(fn, grid, dim3(256), lds, (hipStream_t)stream, a);)
+  }
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_cq_softmax_bwd_parts(const float* parts, const float* S_lm, const float* St_lm, float* dS_lm, float* dterm,
+                                        int B, int Lc, int Lq, int D, void* stream) {
+  VMR_CHECK(parts && S_lm && St_lm && dS_lm && dterm, "vmr_cq_softmax_bwd_parts: null pointer");
+  VMR_CHECK(D % DS == 0 && Lc >= 1 && Lq >= 1 && (Lc <= 32 || Lq <= 32), "vmr_cq_softmax_bwd_parts: bad dims");
+  if (B == 0) return 0;
+  const int ctx_long = Lq <= Lc ? 1 : 0;
+  const int Ll = ctx_long ? Lc : Lq, Ls = ctx_long ? Lq : Lc, SP = sp_of(Ls);
+  const size_t lds = ((size_t)4 * Ll * SP + SP + 1024) * 4;
+  VMR_CHECK(lds <= 160 * 1024, "vmr_cq_softmax_bwd_parts: score tile %dx%d does not fit LDS", Ll, SP);
+  if (int rc = set_lds((const void*)cq_softmax_bwd_parts_kernel, lds, "vmr_cq_softmax_bwd_parts")) return rc;
+  hipLaunchKernelGGL(cq_softmax_bwd_parts_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, parts, D / DS, S_lm, St_lm, dS_lm,
+                     dterm, Ll, Ls, SP, (Lc + 15) / 16 * 16, (Lq + 15) / 16 * 16, ctx_long);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_cq_score_bwd(const void* lng, const void* sht, const float* dS_lm, void* dlng, void* dsht, int B, int Ll, int Ls,
+                                int D, int dtype, void* stream) {
+  VMR_CHECK(lng && sht && dS_lm && dlng && dsht, "vmr_cq_score_bwd: null pointer");
+  VMR_CHECK(dtype == VMR_BF16 && D % DS == 0 && Ls >= 1 && Ls <= 32 && Ll >= 1 && ((uintptr_t)dS_lm & 15) == 0,
+            "vmr_cq_score_bwd: unsupported shape Ll=%d Ls=%d D=%d", Ll, Ls, D);
+  if (B == 0) return 0;
+  ScoreBwdArgs a;
+  a.lng = (const bf16_t*)lng; a.sht = (const bf16_t*)sht; a.dS = dS_lm; a.dlng = (bf16_t*)dlng; a.dsht = (bf16_t*)dsht;
+  a.Ll = Ll; a.Ls = Ls; a.D = D;
+  const dim3 grid(D / DS, B);
+  const int SP = sp_of(Ls);
+  const size_t lds = (size_t)4 * SP * DS * 4;
+  CQ_DISPATCH_SP(SP, cq_score_bwd_kernel, if (int rc = set_lds((const void*)fn, lds, "vmr_cq_score_bwd")) return rc;
+                 hipLaunchKernelGGL(fn, grid, dim3(256), lds, (hipStream_t)stream, a);)
+  VMR_LAUNCH_CHECK();
+  return 0;
+}

@@ -18,8 +18,9 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 
 struct CqArgs {
   const bf16_t* lng; const bf16_t* sht; const float* shortterm; const float* mask_long; const float* mask_short;
-  bf16_t* Srow; bf16_t* Scol;
-  int Ll, Ls, D, ldP, orient;
+  bf16_t* Srow; bf16_t* Scol;      // nullable: the composed path's bf16 [B, rows, ldP] pair
+  float* Pt32; float* Pv32;        // nullable: fp32 long-major [B, Ll, SP32] (softmax over t / over v) for cqapply.hip
+  int Ll, Ls, D, ldP, orient, SP32;
 };
 
 __global__ __launch_bounds__(512) void cq_score_kernel(CqArgs a) {
@@ -158,6 +159,11 @@ __global__ __launch_bounds__(512) void cq_score_kernel(CqArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { pt[r] = xt[j][r] * invt; pv[r] = xv[j][r] * cs[j][r]; }
     const int t0 = j * 16 + (lane >> 4) * 4;
+    if (a.Pt32 && t0 < a.SP32) {     // (t >= Ls: both probabilities are exactly 0)
+      *reinterpret_cast<f32x4*>(a.Pt32 + ((int64_t)b * a.Ll + v) * a.SP32 + t0) = (f32x4){pt[0], pt[1], pt[2], pt[3]};
+      *reinterpret_cast<f32x4*>(a.Pv32 + ((int64_t)b * a.Ll + v) * a.SP32 + t0) = (f32x4){pv[0], pv[1], pv[2], pv[3]};
+    }
+    if (!a.Srow) continue;
     if (a.orient == 0) {
       if (t0 < a.ldP) {
         Vec4<bf16_t>::store(a.Srow + ((int64_t)b * a.Ll + v) * a.ldP + t0, pt);
@@ -193,16 +199,20 @@ extern "C" int vmr_cq_score_supported(int Ll, int Ls, int D, int dtype) {
 }
 
 extern "C" int vmr_cq_score_fwd(const void* lng, const void* sht, const float* shortterm, const float* mask_long,
-                                const float* mask_short, void* Srow, void* Scol, int B, int Ll, int Ls, int D, int ldP,
-                                int orient, int dtype, void* stream) {
-  VMR_CHECK(lng && sht && shortterm && mask_long && mask_short && Srow && Scol, "vmr_cq_score_fwd: null pointer");
+                                const float* mask_short, void* Srow, void* Scol, float* Pt_lm, float* Pv_lm, int B, int Ll,
+                                int Ls, int D, int ldP, int orient, int dtype, void* stream) {
+  VMR_CHECK(lng && sht && shortterm && mask_long && mask_short, "vmr_cq_score_fwd: null pointer");
+  VMR_CHECK((Srow && Scol) || (Pt_lm && Pv_lm), "vmr_cq_score_fwd: no output requested");
+  VMR_CHECK((!Srow) == (!Scol) && (!Pt_lm) == (!Pv_lm), "vmr_cq_score_fwd: outputs come in pairs");
+  VMR_CHECK((((uintptr_t)Pt_lm | (uintptr_t)Pv_lm) & 15) == 0, "vmr_cq_score_fwd: fp32 outputs must be 16-byte aligned");
   VMR_CHECK(vmr_cq_score_supported(Ll, Ls, D, dtype), "vmr_cq_score_fwd: unsupported shape Ll=%d Ls=%d D=%d", Ll, Ls, D);
   VMR_CHECK(orient == 0 || orient == 1, "vmr_cq_score_fwd: bad orientation");
-  VMR_CHECK(ldP % 4 == 0 && ldP >= (orient == 0 ? Ls : Ll), "vmr_cq_score_fwd: bad ldP");
+  VMR_CHECK(!Srow || (ldP % 4 == 0 && ldP >= (orient == 0 ? Ls : Ll)), "vmr_cq_score_fwd: bad ldP");
   if (B == 0) return 0;
   CqArgs a;
   a.lng = (const bf16_t*)lng; a.sht = (const bf16_t*)sht; a.shortterm = shortterm; a.mask_long = mask_long;
   a.mask_short = mask_short; a.Srow = (bf16_t*)Srow; a.Scol = (bf16_t*)Scol;
+  a.Pt32 = Pt_lm; a.Pv32 = Pv_lm; a.SP32 = (Ls + 7) / 8 * 8;
   a.Ll = Ll; a.Ls = Ls; a.D = D; a.ldP = ldP; a.orient = orient;
   const int smem = 32 * D * 2 + 8 * 32 * 4;
   if (smem > 64 * 1024) {
@@ -215,7 +225,7 @@ extern "C" int vmr_cq_score_fwd(const void* lng, const void* sht, const float* s
   }
   hipLaunchKernelGGL(cq_score_kernel, dim3(B), dim3(512), smem, (hipStream_t)stream, a);
   VMR_LAUNCH_CHECK();
-  if (orient == 1 && ldP > Ll) {
+  if (Srow && orient == 1 && ldP > Ll) {
     const int64_t rows = (int64_t)B * Ls;
     hipLaunchKernelGGL(cq_pad_zero_kernel, dim3((unsigned)min((int64_t)1024, (rows * (ldP - Ll) + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, (bf16_t*)Srow, (bf16_t*)Scol, rows, Ll, ldP);

@@ -1437,8 +1437,8 @@ class _CQScore(torch.autograd.Function):
         st = shortterm.contiguous().float()
         def launch():
             L.check(L.lib().vmr_cq_score_fwd(lng.data_ptr(), short_op.data_ptr(), st.data_ptr(), mask_long.data_ptr(),
-                                             mask_short.data_ptr(), Srow.data_ptr(), Scol.data_ptr(), B, Ll, Ls, D, ldP,
-                                             orient, L.dtype_code(lng), L.stream_ptr()), "vmr_cq_score_fwd")
+                                             mask_short.data_ptr(), Srow.data_ptr(), Scol.data_ptr(), None, None, B, Ll, Ls,
+                                             D, ldP, orient, L.dtype_code(lng), L.stream_ptr()), "vmr_cq_score_fwd")
         if CQ_HOOK is not None:
             CQ_HOOK(launch, B, Ll, Ls, D)
         else:
@@ -1474,6 +1474,98 @@ class _CQScore(torch.autograd.Function):
             dshort = _bmm_raw(dS, lng, 0, 1)                     # [B,Ls,Ll] . [B,Ll,D]
             dlong = _bmm_raw(dS, short_op, 1, 1)                 # [B,Ls,Ll]^T . [B,Ls,D]
         return dlong, dshort, dterm.reshape(tshape), None, None, None
+
+
+class _CQBlock(torch.autograd.Function):
+    """The whole CQAttention core (reference models/layers.py:417-424) as fused launches:
+    forward  = vmr_cq_score_fwd (trilinear similarity + both masked softmaxes, written as fp32 long-major rows) ->
+               vmr_cq_apply_fwd (c2q, S_t^T.C, q2c and the 4-way concat, one workgroup per clip and 128-channel slice);
+    backward = vmr_cq_apply_bwd (dctx, dqry and per-slice partials of dS_ / dS_t) -> vmr_cq_softmax_bwd_parts ->
+               vmr_cq_score_bwd (gradients of the two score operands).
+    The two probability matrices ([B, Ll, SP] fp32, 1.5 MB each at cfg2) are the only intermediates in HBM.
+    Inputs: ctx [B,Lc,D], qry [B,Lq,D] (apply stage), lng / short_op (the score operands: the long stream, possibly a
+    dropout copy, and the rank-1-folded short operand), shortterm [B,Ls]; orient 0: context is the long stream."""
+
+    @staticmethod
+    def forward(ctx_, ctx, qry, lng, short_op, shortterm, mask_long, mask_short, orient):
+        L.require_gpu(ctx, qry, lng, short_op)
+        B, Lc, D = ctx.shape
+        Lq = qry.shape[1]
+        ctx, qry, lng, short_op = ctx.contiguous(), qry.contiguous(), lng.contiguous(), short_op.contiguous()
+        Ll, Ls = lng.shape[1], short_op.shape[1]
+        assert (Ll, Ls) == ((Lc, Lq) if orient == 0 else (Lq, Lc))
+        SP = _rup(Ls, 8)
+        Pt = torch.empty(B, Ll, SP, device=ctx.device, dtype=torch.float32)      # softmax over the short index
+        Pv = torch.empty_like(Pt)                                                # softmax over the long index
+        st = shortterm.contiguous().float()
+        lib, stream = L.lib(), L.stream_ptr()
+
+        def launch():
+            L.check(lib.vmr_cq_score_fwd(lng.data_ptr(), short_op.data_ptr(), st.data_ptr(), mask_long.data_ptr(),
+                                         mask_short.data_ptr(), None, None, Pt.data_ptr(), Pv.data_ptr(), B, Ll, Ls, D, 0,
+                                         orient, L.dtype_code(lng), stream), "vmr_cq_score_fwd")
+        if CQ_HOOK is not None:
+            CQ_HOOK(launch, B, Ll, Ls, D)
+        else:
+            launch()
+        # S_ = softmax over q, S_t = softmax over c: q is the short index when the context is the long stream
+        S_, S_t = (Pt, Pv) if orient == 0 else (Pv, Pt)
+        out = torch.empty(B * Lc, 4 * D, device=ctx.device, dtype=ctx.dtype)
+
+        def apply_():
+            L.check(lib.vmr_cq_apply_fwd(ctx.data_ptr(), qry.data_ptr(), S_.data_ptr(), S_t.data_ptr(), out.data_ptr(), B, Lc,
+                                         Lq, D, L.dtype_code(ctx), stream), "vmr_cq_apply_fwd")
+        if CQ_APPLY_HOOK is not None:
+            CQ_APPLY_HOOK(apply_, "fwd", B, Lc, Lq, D)
+        else:
+            apply_()
+        ctx_.save_for_backward(ctx, qry, lng, short_op, S_, S_t)
+        ctx_.meta = (B, Lc, Lq, D, orient, tuple(shortterm.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx_, dout):
+        ctx, qry, lng, short_op, S_, S_t = ctx_.saved_tensors
+        B, Lc, Lq, D, orient, tshape = ctx_.meta
+        dev, lib, stream = ctx.device, L.lib(), L.stream_ptr()
+        dout = dout.contiguous()
+        dctx, dqry = torch.empty_like(ctx), torch.empty_like(qry)
+        parts = torch.empty(L.cq_apply_parts_floats(B, Lc, Lq, D), device=dev, dtype=torch.float32)
+
+        def apply_():
+            L.check(lib.vmr_cq_apply_bwd(dout.data_ptr(), ctx.data_ptr(), qry.data_ptr(), S_.data_ptr(), S_t.data_ptr(),
+                                         dctx.data_ptr(), dqry.data_ptr(), parts.data_ptr(), B, Lc, Lq, D,
+                                         L.dtype_code(ctx), stream), "vmr_cq_apply_bwd")
+        if CQ_APPLY_HOOK is not None:
+            CQ_APPLY_HOOK(apply_, "bwd", B, Lc, Lq, D)
+        else:
+            apply_()
+        Ll, Ls = lng.shape[1], short_op.shape[1]
+        dS = torch.empty_like(S_)                                   # fp32 long-major [B, Ll, SP]
+        dterm = torch.empty(B, Ls, device=dev, dtype=torch.float32)
+        L.check(lib.vmr_cq_softmax_bwd_parts(parts.data_ptr(), S_.data_ptr(), S_t.data_ptr(), dS.data_ptr(), dterm.data_ptr(),
+                                             B, Lc, Lq, D, stream), "vmr_cq_softmax_bwd_parts")
+        dlng, dshort = torch.empty_like(lng), torch.empty_like(short_op)
+        L.check(lib.vmr_cq_score_bwd(lng.data_ptr(), short_op.data_ptr(), dS.data_ptr(), dlng.data_ptr(), dshort.data_ptr(), B,
+                                     Ll, Ls, D, L.dtype_code(lng), stream), "vmr_cq_score_bwd")
+        return dctx, dqry, dlng, dshort, dterm.reshape(tshape), None, None, None
+
+
+CQ_APPLY_HOOK = None   # bench.py: callable(launch, "fwd"|"bwd", B, Lc, Lq, D) around the fused CQ apply kernels
+FUSED_CQ_APPLY = os.environ.get("VMR_FUSED_CQ_APPLY", "1") != "0"   # csrc/cqapply.hip
+
+
+def cq_block_supported(Lc, Lq, D, dtype):
+    """Both halves of the fused CQAttention core take this shape (score kernel: long stream <= 128 rows)."""
+    Ll, Ls = max(Lc, Lq), min(Lc, Lq)
+    code = L.F32 if dtype == torch.float32 else L.BF16
+    return (FUSED_CQ_APPLY and cq_score_supported(Ll, Ls, D, dtype) and
+            bool(L.lib().vmr_cq_apply_supported(Lc, Lq, D, code)))
+
+
+def cq_block(ctx, qry, lng, short_op, shortterm, mask_long, mask_short, orient):
+    """cat4 [B*Lc, 4D] of CQAttention from the context / query streams and the two score operands."""
+    return _CQBlock.apply(ctx, qry, lng, short_op, shortterm, mask_long.contiguous(), mask_short.contiguous(), orient)
 
 
 def cq_score_supported(Ll, Ls, D, dtype):
