@@ -36,11 +36,12 @@ def bench(M,N,K,ta,tb,flags=0,splitk=1,iters=50, epi=False, tag=""):
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     t=e0.elapsed_time(e1)*1e-3/iters
     print(f"v={os.environ.get('VMR_GEMM_DMA','3')} {tag} M{M} N{N} K{K} ta{ta} tb{tb} sk{splitk} epi{int(epi)}: {t*1e6:7.1f} us {2*M*N*K/t/1e12:7.1f} TF", flush=True)
-for (M,N,K,ta,tb) in [(8192,1024,1024,0,0),(9472,1024,1024,0,0),(9472,3072,1024,0,0),(8192,1024,4096,0,0),(9472,1024,1024,0,1),(8192,1024,1024,0,1)]:
-    bench(M,N,K,ta,tb)
-bench(9472,1024,1024,0,0,epi=True)
-bench(8192,1024,1024,0,0,epi=True)
-for sk in (2,4,8):
-    bench(1024,1024,9472,1,1,flags=L.EPI_ACCUM,splitk=sk)
-bench(3072,1024,9472,1,1,flags=L.EPI_ACCUM,splitk=2)
-bench(3072,1024,9472,1,1,flags=L.EPI_ACCUM,splitk=4)
+if __name__ == '__main__':
+    for (M,N,K,ta,tb) in [(8192,1024,1024,0,0),(9472,1024,1024,0,0),(9472,3072,1024,0,0),(8192,1024,4096,0,0),(9472,1024,1024,0,1),(8192,1024,1024,0,1)]:
+        bench(M,N,K,ta,tb)
+    bench(9472,1024,1024,0,0,epi=True)
+    bench(8192,1024,1024,0,0,epi=True)
+    for sk in (2,4,8):
+        bench(1024,1024,9472,1,1,flags=L.EPI_ACCUM,splitk=sk)
+    bench(3072,1024,9472,1,1,flags=L.EPI_ACCUM,splitk=2)
+    bench(3072,1024,9472,1,1,flags=L.EPI_ACCUM,splitk=4)

@@ -465,9 +465,9 @@ __device__ __forceinline__ void dma_operand(const bf16_t* __restrict__ P, int64_
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #define VMR_VMCNT_CASE(n) else if (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  VMR_VMCNT_CASE(4); VMR_VMCNT_CASE(6); VMR_VMCNT_CASE(7); VMR_VMCNT_CASE(8); VMR_VMCNT_CASE(9);
+  VMR_VMCNT_CASE(4); VMR_VMCNT_CASE(5); VMR_VMCNT_CASE(6); VMR_VMCNT_CASE(7); VMR_VMCNT_CASE(8); VMR_VMCNT_CASE(9);
   VMR_VMCNT_CASE(12); VMR_VMCNT_CASE(14); VMR_VMCNT_CASE(16); VMR_VMCNT_CASE(18);
-  else static_assert(N == 0 || N == 4 || N == 6 || N == 7 || N == 8 || N == 9 || N == 12 || N == 14 || N == 16 || N == 18,
+  else static_assert(N == 0 || N == 4 || N == 5 || N == 6 || N == 7 || N == 8 || N == 9 || N == 12 || N == 14 || N == 16 || N == 18,
                      "add the immediate");
 #undef VMR_VMCNT_CASE
 }
@@ -726,6 +726,111 @@ template <bool TA, bool TB, int BK, int NST, int MT = 4, int WM = 2>
 __global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   gemm_dma_body<TA, TB, BK, NST, MT, WM>(g, tiles_m, tiles_n, smem, blockIdx.x, blockIdx.z, gridDim.z);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One 512-thread workgroup per CU, (64 * MT) x 128 tile (MT = 4: 256 rows, MT = 5: 320 rows), x.W^T layout only, with
+// the operand rings sized by what bounds this loop: the L2 -> LDS fill (~65 GB/s per CU whatever the schedule).
+//   * bytes per flop: 320x128 fetches 448 rows per K-step for 5.2 MFLOP -- 0.70 of what two co-resident 160x128
+//     tiles fetch -- so a fill-bound loop gets 1.4x faster, PROVIDED the fill queue never runs dry;
+//   * with two stages (the WM = 4 instantiation of gemm_dma_body) it does run dry: a stage can only be re-requested
+//     after the barrier that frees it, so every K-step pays one L2 round trip (~1 us) with nothing in flight -- the
+//     reason that variant lost on single-round grids;
+//   * here the A operand (40 of a stage's 56 KiB) has THREE buffers and is requested two K-steps ahead, the weight
+//     operand TWO buffers and one step ahead: 3 x 40 + 2 x 16 = 152 KiB of the 160.  Issue order inside a step is
+//     W(kt+1) then A(kt+2), so the counted wait at the top of step kt+1 -- "everything but the last A request" --
+//     retires exactly A(kt+1) and W(kt+1) (vmcnt counts in issue order).
+// Same LDS images, fragment reads, swapped-operand MFMAs and register-direct 16-byte epilogue as gemm_dma_body.
+template <int MT, int NSB = (MT == 5 ? 2 : 3)>
+__device__ __forceinline__ void gemm_dma_a3b2_body(const vmr_gemm_t& g, int tiles_m, int tiles_n, unsigned char* smem) {
+  constexpr int BK = 64, NW = 8, TBM = MT * 64;
+  constexpr int OPA = TBM * BK * 2, OPB = 128 * BK * 2;
+  constexpr int LPA = OPA / 1024 / NW;       // A loads per wave per K-step (4 or 5); the weight tile: 2
+  constexpr int LPB = OPB / 1024 / NW;
+  unsigned char* ringA = smem;               // 3 x OPA
+  unsigned char* ringB = smem + 3 * OPA;     // NSB x OPB (3 where the tile leaves room: W two steps ahead as well)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const TileCoord tc = tile_coord(g, tiles_m, tiles_n, blockIdx.x, 0, 1);
+  const int m0 = tc.tm * TBM, n0 = tc.tn * BN;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = g.K / BK;
+  u32x2 rres[MT][4];
+  if (g.flags & VMR_EPI_RESIDUAL) {          // oldest in the vmcnt order: hidden under the whole K loop
+    const bf16_t* Rsd = reinterpret_cast<const bf16_t*>(g.residual);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const bf16_t* rrow = Rsd + (int64_t)(min(m0 + wm * (MT * 16) + (lane & 15) + i * 16, g.M - 1) / g.res_div) * g.ldr +
+                           n0 + wn * 64;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const uint4 w = *reinterpret_cast<const uint4*>(rrow + quad_col<true>(2 * k, lane >> 4));
+        rres[i][2 * k] = (u32x2){w.x, w.y};
+        rres[i][2 * k + 1] = (u32x2){w.z, w.w};
+      }
+    }
+  }
+  auto issueA = [&](int kt) { dma_operand<true, BK, TBM, NW>(A, g.lda, m0, kt * BK, ringA + (kt % 3) * OPA, wid, lane, g.M - 1); };
+  auto issueB = [&](int kt) { dma_operand<true, BK, 128, NW, true>(B, g.ldb, n0, kt * BK, ringB + (kt % NSB) * OPB, wid, lane); };
+  issueA(0);
+  issueB(0);
+  if (nk > 1) {
+    if (NSB == 3) issueB(1);
+    issueA(1);
+  }
+  bf16x8 fa[2][MT], fb[2][4];
+  auto mma = [&](int buf) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0);  // C^T tile
+    __builtin_amdgcn_s_setprio(0);
+  };
+  for (int kt = 0; kt < nk; ++kt) {
+    // A(kt), W(kt) of this wave have landed; only the request(s) of step kt+1 issued last may still be in flight
+    if (kt + 1 < nk) wait_vmcnt<(NSB == 3 ? LPA + LPB : LPA)>();
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of step kt-1 are complete
+    __builtin_amdgcn_s_barrier();                         // every wave's part of step kt is in LDS; step kt-1's buffers are free
+    if (NSB == 3) {
+      if (kt + 2 < nk) { issueB(kt + 2); issueA(kt + 2); }
+    } else {
+      if (kt + 1 < nk) issueB(kt + 1);
+      if (kt + 2 < nk) issueA(kt + 2);
+    }
+    const unsigned char* curA = ringA + (kt % 3) * OPA;
+    const unsigned char* curB = ringB + (kt % NSB) * OPB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int buf = kk & 1;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[buf][i] = read_frag<true, BK>(curA, wm * MT + i, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[buf][j] = read_frag<true, BK>(curB, wn * 4 + j, kk, lane);
+      if (kk > 0) mma(0);
+      else if (kt > 0) mma(1);
+    }
+  }
+  if (nk > 0) mma(1);
+  epilogue_direct<MT, true>(g, acc, wm, wn, lane, m0, n0, 0,
+                            (g.flags & VMR_EPI_OUT_F32) ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C))
+                                                        : reinterpret_cast<bf16_t*>(g.C),
+                            rres, reinterpret_cast<bf16_t*>(g.aux));
+}
+
+template <int MT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gemm_dma_a3b2_body<MT>(g, tiles_m, tiles_n, smem);
 }
 
 // Two independent products in ONE launch: workgroups [0, nblk2) run problem 2 (a split-K weight-gradient product
@@ -1029,6 +1134,35 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
                        (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));
   const double c128 = dma_ok ? rounds_cost((int64_t)tiles_m * tiles_n * Z, 1.0) : 1e30;
   const double c160 = (tall_ok && dma_ok) ? rounds_cost((int64_t)cdiv(g.M, 160) * tiles_n * Z, 1.25) : 1e30;
+  // big tiles, one workgroup per CU (gemm_dma_a3b2_body): VMR_GEMM_BIG = 0 (default) off, 1 where the rounds model
+  // says so, 2 wherever the shape allows.  Measured (scratch/gemm_big_ab.py, graph-timed, rotating operands): within
+  // +-5 % of the two-per-CU tiles on every shape of the step ([8192,1024,1024] 25.6 vs 24.6 us, [9472,3072,1024] 82.8 vs
+  // 83.3, K = 4096 77.2 vs 77.6) although it fetches 25-30 % fewer bytes per flop: with one barrier per K-step the MFMA,
+  // LDS-read and fill phases of a workgroup do not overlap well enough for the fill rate to be what binds.  The vendor
+  // BLAS on the same shapes (scratch/gemm_vs_blas.py): 24.8 us at [9472,1024,1024] (ours 27.5), 57 us at
+  // [9472,3072,1024] (ours 80) -- the K = 1024 products of this model are prologue / epilogue bound for everybody.
+  static int g_big = -1;
+  if (g_big < 0) {
+    const char* e = getenv("VMR_GEMM_BIG");
+    g_big = e ? atoi(e) : 0;
+  }
+  if (g_big && tall_ok && dma_ok && !g.transB && Z == 1 && g.K >= 192 && g.M >= 256 && !(g.flags & VMR_EPI_SLAB)) {
+    // one round of <= 256 tiles, or whole rounds of 256-row tiles; otherwise the 2-per-CU kernels keep the shape
+    const int t4 = cdiv(g.M, 256) * tiles_n, t5 = cdiv(g.M, 320) * tiles_n;
+    const double r4 = (double)((t4 + 255) / 256) * 256.0, r5 = (double)((t5 + 255) / 256) * 320.0;   // rows of work per CU
+    const int mt = r5 < r4 ? 5 : 4;
+    const int64_t tiles = mt == 5 ? t5 : t4;
+    const double waste = (double)(((tiles + 255) / 256) * 256) / (double)tiles;   // idle CU share of the last round
+    if (g_big >= 2 || waste <= 1.10) {
+      const int tm = cdiv(g.M, mt * 64);
+      const int smem = 3 * (mt * 64) * 128 + (mt == 5 ? 2 : 3) * 128 * 128;
+      gemm_fn bf = mt == 5 ? (gemm_fn)gemm_bf16_big_kernel<5> : (gemm_fn)gemm_bf16_big_kernel<4>;
+      if (int rc = set_smem_once(bf, smem)) return rc;
+      hipLaunchKernelGGL(bf, dim3((unsigned)(tm * tiles_n)), dim3(512), smem, (hipStream_t)stream, g, tm, tiles_n);
+      VMR_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (g_wide && tall_ok && dma_ok && !g.transB && g.M >= 320) {
     const int tm = cdiv(g.M, 320);
     const int64_t rounds = ((int64_t)tm * tiles_n * Z + 255) / 256;
