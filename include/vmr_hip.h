@@ -282,6 +282,16 @@ int vmr_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t r
 int vmr_relu_bwd_bias(int mode, const void* dy, const void* h, void* dz, float* db, int64_t rows,
                       int D, int64_t ld, float scale, int dtype, float drop_p, uint32_t drop_seed,
                       const uint32_t* drop_step, float* db2, float db_scale, void* stream);
+/* WordEmbedding.forward (layers.py:28-48) without the per-call table concat: out[i, 0:wd] = drop(row(ids[i])) in
+ * `dtype`, row(0) = pad_vec, row(1) = unk_vec, row(k>=2) = glove_vec[k-2] (fp32 [1,wd], [1,wd], [nglove,wd]); out is
+ * the [n, ldo] matrix that feeds query_conv1d; columns [zero_from, zero_to) are zero-filled (K padding), the columns
+ * in between belong to vmr_char_cnn_fwd.  Dropout: counter stream index i*wd + c.
+ * bwd: dunk[c] += sum_{i: ids[i]==1} drop'(dout[i,c]) (the only trainable row; ACCUMULATED). */
+int vmr_word_embedding_fwd(const int64_t* ids, const float* pad_vec, const float* unk_vec, const float* glove_vec,
+                           void* out, int64_t n, int wd, int64_t nglove, int64_t ldo, int zero_from, int zero_to,
+                           int dtype, float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream);
+int vmr_word_embedding_bwd(const int64_t* ids, const void* dout, float* dunk, int64_t n, int wd, int64_t ldo, int dtype,
+                           float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream);
 /* out[i,:] = table[idx[i],:] (fp32): WordEmbedding / CharacterEmbedding lookups
  * (layers.py:42-48,66).  bwd: dtable[idx[i],:] += dout[i,:] for idx != padding_idx
  * (dtable accumulated with float atomics; the caller zeroes it). */

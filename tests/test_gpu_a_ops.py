@@ -717,6 +717,51 @@ def test_fused_cq_block_matches_torch(dev, dims, orient):
         _close(a, b, 6e-2, name + " fused vs composed")   # (composed: bf16 probabilities; fused: fp32)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_text_embed_matches_torch(dev, dt):
+    """ops.text_embed (vmr_word_embedding_fwd/bwd + vmr_char_cnn_fwd/bwd into one [words, ldo] matrix) against the
+    reference's WordEmbedding + CharacterEmbedding composed in torch (models/layers.py:28-75), dropout off: the word
+    columns are an exact gather of pad / unk / glove rows, the zero padding is zero, and only unk_vec / the char
+    parameters receive gradients."""
+    ops = _ops()
+    torch.manual_seed(3)
+    B, Lq, Cc, nw, nc, wd, CD = 5, 9, 7, 40, 30, 300, 100
+    wid = torch.randint(0, nw, (B, Lq), device=dev); wid[0, :3] = torch.tensor([0, 1, 1], device=dev)
+    cid = torch.randint(0, nc, (B, Lq, Cc), device=dev)
+    pad = torch.zeros(1, wd, device=dev); pad[0, 5] = 0.25                  # (a loaded checkpoint may hold anything)
+    unk = torch.randn(1, wd, device=dev, requires_grad=True)
+    glove = torch.randn(nw - 2, wd, device=dev)
+    table = torch.randn(nc, CD, device=dev, requires_grad=True)
+    ws = [torch.randn(10 * (k + 1), CD, 1, k + 1, device=dev, requires_grad=True) for k in range(4)]
+    bs = [torch.randn(10 * (k + 1), device=dev, requires_grad=True) for k in range(4)]
+    ldo = 400 if dt == torch.float32 else 512
+    out = ops.text_embed(wid, cid, pad, unk, glove, table, ws, bs, ops.NO_DROP, ops.NO_DROP, dt, ldo)
+    assert out.shape == (B * Lq, ldo) and out.dtype == dt
+    ref_w = torch.cat([pad, unk, glove], 0)[wid.reshape(-1)]
+    assert torch.equal(out[:, :wd].float(), ref_w.to(dt).float())
+    assert float(out[:, 400:].abs().max() if ldo > 400 else 0.0) == 0.0
+    ce = torch.nn.functional.embedding(cid, table, padding_idx=0).permute(0, 3, 1, 2)          # [B, CD, L, C]
+    feats = [torch.relu(torch.nn.functional.conv2d(ce, w, b)).amax(dim=3).permute(0, 2, 1) for w, b in zip(ws, bs)]
+    ref_c = torch.cat(feats, 2).reshape(B * Lq, 100)
+    _close(out[:, wd:400], ref_c, 2e-2 if dt == torch.bfloat16 else 1e-4, "char features")
+    g = torch.randn(B * Lq, ldo, device=dev).to(dt)
+    ga = torch.autograd.grad(out, [unk, table, *ws, *bs], g)
+    ref = torch.cat([ref_w, ref_c], 1)
+    gb = torch.autograd.grad(ref, [unk, table, *ws, *bs], g[:, :400].float())
+    for a, b, n in zip(ga, gb, ["unk", "table"] + [f"w{k}" for k in range(4)] + [f"b{k}" for k in range(4)]):
+        if dt == torch.bfloat16 and n != "unk":
+            continue      # (the bf16 CNN stages bf16-rounded rows / weights: covered, with a rounding-aware reference, by test_char_cnn_fwd_bwd)
+        _close(a, b, 1e-2 if dt == torch.bfloat16 else 1e-3, n)
+    # dropout on: the counter mask is regenerated identically in the backward (same keep pattern as the forward)
+    d = (0.3, 4242, None)
+    o2 = ops.text_embed(wid, cid, pad, unk, glove, table, ws, bs, d, ops.NO_DROP, torch.float32, 400)
+    kept = (o2[:, :wd] != 0) | (ref_w == 0)
+    assert 0.6 < float(kept.float().mean()) < 0.8
+    gu = torch.autograd.grad(o2, unk, torch.ones_like(o2))[0]
+    want = (kept[wid.reshape(-1) == 1].float() / 0.7).sum(0, keepdim=True)
+    _close(gu, want, 1e-4, "unk gradient under dropout")
+
+
 def test_soft_ce_matches_torch(dev):
     ops = _ops()
     torch.manual_seed(6)

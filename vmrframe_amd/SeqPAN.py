@@ -35,6 +35,10 @@ from . import ops
 NEG = -1e30  # reference models/layers.py:9
 
 
+def _rup128(x: int) -> int:
+    return (x + 127) // 128 * 128
+
+
 def _cfg_get(obj, name, default=None):
     try:
         return getattr(obj, name)
@@ -327,28 +331,19 @@ class SeqPAN(nn.Module):
 
     # -- stages ---------------------------------------------------------------
     def _text_embedding(self, word_ids, char_ids, dc):
-        """Embedding.forward (reference layers.py:87-93): word gather + char CNN are
-        index / window glue in torch; every contraction runs on the HIP GEMM."""
+        """Embedding.forward (reference layers.py:87-93): word lookup + dropout and the character CNN write their
+        column ranges of one [words, 512] matrix (ops.text_embed: two kernels), then query_conv1d on the HIP GEMM."""
         cdt = self.compute_dtype
-        B, Lq = word_ids.shape
         pre = "text_encoder."
-        table = torch.cat([self.P(pre + "word_emb.pad_vec"), self.P(pre + "word_emb.unk_vec"),
-                           self.P(pre + "word_emb.glove_vec")], 0)
-        wemb = ops.embedding(word_ids, table, 0)
-        if dc.p > 0:
-            wemb = F.dropout(wemb, dc.p, True)
-        # character CNN: lookup + dropout + 4 x (conv + ReLU + max over positions) in one kernel (csrc/charcnn.hip)
-        cfeat = ops.char_cnn(char_ids, self.P(pre + "char_emb.char_emb.weight"),
+        width = self.word_dim + 100                                                       # 400
+        # zero columns up to a multiple of 128 (400 -> 512): query_conv1d and its dX / dW products then run on the
+        # LDS-DMA GEMM (K and N multiples of 64 / 128) instead of the bounds-checked kernel
+        ldo = width if cdt == torch.float32 else _rup128(width)
+        emb = ops.text_embed(word_ids, char_ids, self.P(pre + "word_emb.pad_vec"), self.P(pre + "word_emb.unk_vec"),
+                             self.P(pre + "word_emb.glove_vec"), self.P(pre + "char_emb.char_emb.weight"),
                              [self.P(f"{pre}char_emb.char_convs.{i}.0.weight") for i in range(4)],
                              [self.P(f"{pre}char_emb.char_convs.{i}.0.bias") for i in range(4)],
-                             dc.next("text.char"), cdt)
-        feats = [ops.to_dtype(wemb.reshape(B * Lq, -1), cdt), cfeat]
-        width = sum(f.shape[1] for f in feats)                                           # 400
-        if cdt != torch.float32 and width % 128:
-            # zero columns up to a multiple of 128 (400 -> 512): query_conv1d and its dX / dW products then run on
-            # the LDS-DMA GEMM (K and N multiples of 64 / 128) instead of the bounds-checked kernel
-            feats.append(torch.zeros(B * Lq, -width % 128, device=cfeat.device, dtype=cdt))
-        emb = torch.cat(feats, dim=1)
+                             dc.next("text.word"), dc.next("text.char"), cdt, ldo)
         return self._lin(emb, pre + "query_conv1d")
 
     def _dual_block(self, X, prefix, vmask, tmask, rowmask, B, T, Lq, dc):

@@ -115,6 +115,8 @@ SIGNATURES = {
     "vmr_cast": [_P, _I, _P, _I, _L, _I, _L, _L, _F, _U, _P, _P],
     "vmr_relu_bwd_bias": [_I, _P, _P, _P, _P, _L, _I, _L, _F, _I, _F, _U, _P, _P, _F, _P],
     "vmr_dropout_mask": [_P, _L, _F, _U, _P],
+    "vmr_word_embedding_fwd": [_P, _P, _P, _P, _P, _L, _I, _L, _L, _I, _I, _I, _F, _U, _P, _P],
+    "vmr_word_embedding_bwd": [_P, _P, _P, _L, _I, _L, _I, _F, _U, _P, _P],
     "vmr_embedding_fwd": [_P, _P, _P, _L, _I, _L, _P],
     "vmr_embedding_bwd": [_P, _P, _P, _L, _I, _L, _L, _P],
     "vmr_eltwise": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],

@@ -156,6 +156,68 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const int64_t* __
   }
 }
 
+// -------------------------------------------- WordEmbedding (reference models/layers.py:28-48)
+// out[i, 0:wd] = drop(row(ids[i])), row(0) = pad_vec, row(1) = unk_vec, row(k >= 2) = glove_vec[k - 2]: the reference
+// concatenates the three parameters into one table on every forward (4.8 MB at 4000 words) and gathers from that;
+// here the three pieces are indexed in place, the embedding dropout (layers.py:46) is applied on the way and the
+// result lands in the compute dtype directly inside the [words, ldo] matrix that feeds query_conv1d.  Columns
+// [zero_from, zero_to) of every row are zeroed as well (the K padding of that GEMM); the columns between belong to the
+// character CNN (charcnn.hip), which writes them itself.
+template <typename T>
+__global__ __launch_bounds__(256) void word_embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ pad,
+                                                             const float* __restrict__ unk, const float* __restrict__ glove,
+                                                             T* __restrict__ out, int64_t n, int wd, int64_t nglove, int64_t ldo,
+                                                             int zero_from, int zero_to, float drop_p, uint32_t seed0,
+                                                             const uint32_t* __restrict__ step) {
+  const uint32_t seed = vmr_seed(seed0, step);
+  const uint32_t thresh = vmr_drop_thresh(drop_p);
+  const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const int q4 = wd / 4, z4 = (zero_to - zero_from) / 4, per = q4 + z4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * per; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / per;
+    const int local = (int)(i - row * per);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    int col;
+    if (local < q4) {
+      col = local * 4;
+      int64_t id = ids[row];
+      id = id < 0 ? 0 : (id > nglove + 1 ? nglove + 1 : id);           // never read outside the pieces
+      const float* src = id == 0 ? pad : (id == 1 ? unk : glove + (id - 2) * wd);
+      Vec4<float>::load(src + col, v);
+      if (drop_p > 0.f) {
+        const uint2 h = vmr_hash4(seed, (uint64_t)(row * wd + col) >> 2);
+        v[0] = (h.x & 0xFFFFu) >= thresh ? v[0] * dscale : 0.f;
+        v[1] = (h.x >> 16) >= thresh ? v[1] * dscale : 0.f;
+        v[2] = (h.y & 0xFFFFu) >= thresh ? v[2] * dscale : 0.f;
+        v[3] = (h.y >> 16) >= thresh ? v[3] * dscale : 0.f;
+      }
+    } else {
+      col = zero_from + (local - q4) * 4;
+    }
+    Vec4<T>::store(out + row * ldo + col, v);
+  }
+}
+
+// the only trainable row is unk_vec (pad_vec and glove_vec are frozen, layers.py:33,37): dunk[c] += sum over the words
+// with id 1 of the dropped gradient.  One wave per word; unknown words are rare, so the float atomics are too.
+template <typename T>
+__global__ __launch_bounds__(256) void word_embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dout,
+                                                             float* __restrict__ dunk, int64_t n, int wd, int64_t ldo, float drop_p,
+                                                             uint32_t seed0, const uint32_t* __restrict__ step) {
+  const uint32_t seed = vmr_seed(seed0, step);
+  const uint32_t thresh = vmr_drop_thresh(drop_p);
+  const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * 4) {
+    if (ids[row] != 1) continue;
+    for (int c = lane; c < wd; c += 64) {
+      float g = to_f<T>(dout[row * ldo + c]);
+      if (drop_p > 0.f) g = vmr_keep(seed, (uint64_t)(row * wd + c), thresh) ? g * dscale : 0.f;
+      atomicAdd(&dunk[c], g);
+    }
+  }
+}
+
 // -------------------------------------------- boundary-label cross-entropy
 // loss = mean_b( -sum_t ys*log_softmax(zs) ) + same for the end logits.
 // grid = 2*B waves (one wave per (which, b) row); T <= 64*16.
@@ -464,6 +526,44 @@ extern "C" int vmr_adamw(float* p, const float* g, float* m, float* v, const uin
   hipLaunchKernelGGL(adamw_kernel, dim3((int)min((int64_t)4096, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      p, g, m, v, decay, (bf16_t*)p_bf16, gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, step_dev,
                      warmup_steps, total_steps, n);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_word_embedding_fwd(const int64_t* ids, const float* pad_vec, const float* unk_vec, const float* glove_vec,
+                                      void* out, int64_t n, int wd, int64_t nglove, int64_t ldo, int zero_from, int zero_to,
+                                      int dtype, float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream) {
+  VMR_CHECK(ids && pad_vec && unk_vec && glove_vec && out, "vmr_word_embedding_fwd: null pointer");
+  VMR_CHECK(dtype == VMR_F32 || dtype == VMR_BF16, "vmr_word_embedding_fwd: bad dtype");
+  VMR_CHECK(wd > 0 && wd % 4 == 0 && ldo % 4 == 0 && ldo >= wd && nglove >= 0, "vmr_word_embedding_fwd: wd / ldo must be multiples of 4");
+  VMR_CHECK(zero_to >= zero_from && (zero_to - zero_from) % 4 == 0 && zero_from % 4 == 0 && zero_to <= ldo && (zero_to == zero_from || zero_from >= wd),
+            "vmr_word_embedding_fwd: bad zero range");
+  VMR_CHECK((((uintptr_t)pad_vec | (uintptr_t)unk_vec | (uintptr_t)glove_vec | (uintptr_t)out) & 15) == 0, "vmr_word_embedding_fwd: 16-byte alignment");
+  if (n == 0) return 0;
+  const int64_t work = n * (wd / 4 + (zero_to - zero_from) / 4);
+  const int grid = (int)min((int64_t)4096, (work + 255) / 256);
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(word_embed_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, pad_vec, unk_vec, glove_vec,
+                       (bf16_t*)out, n, wd, nglove, ldo, zero_from, zero_to, drop_p, drop_seed, drop_step);
+  else
+    hipLaunchKernelGGL(word_embed_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, pad_vec, unk_vec, glove_vec,
+                       (float*)out, n, wd, nglove, ldo, zero_from, zero_to, drop_p, drop_seed, drop_step);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_word_embedding_bwd(const int64_t* ids, const void* dout, float* dunk, int64_t n, int wd, int64_t ldo, int dtype,
+                                      float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream) {
+  VMR_CHECK(ids && dout && dunk, "vmr_word_embedding_bwd: null pointer");
+  VMR_CHECK(dtype == VMR_F32 || dtype == VMR_BF16, "vmr_word_embedding_bwd: bad dtype");
+  if (n == 0) return 0;
+  const int grid = (int)min((int64_t)1024, (n + 3) / 4);
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(word_embed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, (const bf16_t*)dout, dunk, n,
+                       wd, ldo, drop_p, drop_seed, drop_step);
+  else
+    hipLaunchKernelGGL(word_embed_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, (const float*)dout, dunk, n,
+                       wd, ldo, drop_p, drop_seed, drop_step);
   VMR_LAUNCH_CHECK();
   return 0;
 }

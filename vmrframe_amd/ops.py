@@ -916,6 +916,77 @@ class _CharCnn(torch.autograd.Function):
         return (None, None if gtab is not None else dtab, None, None, *gw_ret)
 
 
+class _TextEmbed(torch.autograd.Function):
+    """Embedding.forward up to the concat (reference models/layers.py:87-91): word lookup (+ dropout) and the character
+    CNN write their column ranges of ONE [words, ldo] matrix in the compute dtype -- [0, wd) words, [wd, wd + OT) chars,
+    the rest zero (K padding of query_conv1d) -- two launches, no table concat / cast / cat / zero-fill glue.  Only
+    unk_vec, the character table and the character convolutions receive gradients (pad_vec / glove_vec are frozen)."""
+
+    @staticmethod
+    def forward(ctx, word_ids, char_ids, pad_vec, unk_vec, glove, table, drop_w, drop_c, dtype, ldo, *wb):
+        L.require_gpu(word_ids, char_ids, glove, table)
+        ws_, bs_ = wb[:4], wb[4:]
+        wid, cid = word_ids.contiguous(), char_ids.contiguous()
+        n, wd = wid.numel(), glove.shape[1]
+        Cc, CD = cid.shape[-1], table.shape[1]
+        oc = [w.shape[0] for w in ws_]
+        OT = sum(oc)
+        assert cid.numel() // Cc == n and ldo >= wd + OT and wd % 4 == 0
+        out = torch.empty(n, ldo, device=glove.device, dtype=dtype)
+        dt = L.dtype_code(out)
+        lib, st = L.lib(), L.stream_ptr()
+        L.check(lib.vmr_word_embedding_fwd(wid.data_ptr(), pad_vec.data_ptr(), unk_vec.data_ptr(), glove.data_ptr(), out.data_ptr(),
+                                           n, wd, glove.shape[0], ldo, wd + OT, ldo, dt, drop_w[0], drop_w[1], _ptr(drop_w[2]), st),
+                "vmr_word_embedding_fwd")
+        amax = torch.empty(n, OT, device=table.device, dtype=torch.int8)
+        wp = (C.c_void_p * 4)(*[w.data_ptr() for w in ws_])
+        bp = (C.c_void_p * 4)(*[b.data_ptr() for b in bs_])
+        ocp = (C.c_int * 4)(*oc)
+        cout = out[:, wd:]                                   # the character columns: same row stride
+        L.check(lib.vmr_char_cnn_fwd(cid.data_ptr(), table.data_ptr(), wp, bp, ocp, cout.data_ptr(), ldo, amax.data_ptr(), n, Cc, CD,
+                                     dt, drop_c[0], drop_c[1], _ptr(drop_c[2]), st), "vmr_char_cnn_fwd")
+        ctx.save_for_backward(wid, cid, table, out, amax, unk_vec, *wb)
+        ctx.meta = (drop_w, drop_c, oc, n, wd, Cc, CD, OT, ldo)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        wid, cid, table, out, amax, unk_vec, *wb = ctx.saved_tensors
+        drop_w, drop_c, oc, n, wd, Cc, CD, OT, ldo = ctx.meta
+        ws_, bs_ = wb[:4], wb[4:]
+        dout = dout.contiguous()
+        dev, dt = out.device, L.dtype_code(out)
+        lib, st = L.lib(), L.stream_ptr()
+        gu = main_grad(unk_vec)
+        dunk = gu if gu is not None else torch.zeros_like(unk_vec, dtype=torch.float32)
+        L.check(lib.vmr_word_embedding_bwd(wid.data_ptr(), dout.data_ptr(), dunk.data_ptr(), n, wd, ldo, dt, drop_w[0], drop_w[1],
+                                           _ptr(drop_w[2]), st), "vmr_word_embedding_bwd")
+        gts = [main_grad(t) for t in (*ws_, *bs_)]
+        direct = all(g is not None for g in gts)
+        gws = [g if direct else torch.zeros_like(t, dtype=torch.float32) for g, t in zip(gts[:4], ws_)]
+        gbs = [g if direct else torch.zeros_like(t, dtype=torch.float32) for g, t in zip(gts[4:], bs_)]
+        gtab = main_grad(table)
+        dtab = gtab if gtab is not None else torch.zeros_like(table, dtype=torch.float32)
+        ocp = (C.c_int * 4)(*oc)
+        ws = torch.empty(lib.vmr_char_cnn_ws_floats(n, CD, ocp, dt), device=dev, dtype=torch.float32)
+        wp = (C.c_void_p * 4)(*[w.data_ptr() for w in ws_])
+        bp = (C.c_void_p * 4)(*[b.data_ptr() for b in bs_])
+        dwp = (C.c_void_p * 4)(*[g.data_ptr() for g in gws])
+        dbp = (C.c_void_p * 4)(*[g.data_ptr() for g in gbs])
+        L.check(lib.vmr_char_cnn_bwd(dout[:, wd:].data_ptr(), out[:, wd:].data_ptr(), ldo, amax.data_ptr(), cid.data_ptr(),
+                                     table.data_ptr(), wp, bp, ocp, dwp, dbp, dtab.data_ptr(), ws.data_ptr(), n, Cc, CD, dt,
+                                     drop_c[0], drop_c[1], _ptr(drop_c[2]), st), "vmr_char_cnn_bwd")
+        gw_ret = [None] * 8 if direct else [*gws, *gbs]
+        return (None, None, None, None if gu is not None else dunk, None, None if gtab is not None else dtab, None, None, None,
+                None, *gw_ret)
+
+
+def text_embed(word_ids, char_ids, pad_vec, unk_vec, glove, table, conv_weights, conv_biases, drop_w, drop_c, dtype, ldo):
+    """[words, ldo] = [dropout(word vectors) | char-CNN features | 0] in `dtype` (the input of query_conv1d)."""
+    return _TextEmbed.apply(word_ids, char_ids, pad_vec, unk_vec, glove, table, drop_w, drop_c, dtype, ldo,
+                            *conv_weights, *conv_biases)
+
+
 def char_cnn(char_ids, table, conv_weights, conv_biases, drop, dtype):
     """char_ids int64 [..., C]; table fp32 [num_chars, char_dim]; 4 conv weights [10k, char_dim, 1, k] + biases
     -> [words, sum(out channels)] in `dtype`."""
