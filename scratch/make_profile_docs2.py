@@ -1,0 +1,79 @@
+"""profiles/ artefacts from a scratch/profile_round2.sh run: python scratch/make_profile_docs2.py r2_prof_a r02_a"""
+import csv, json, os, re, sys, shutil
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+S = os.path.join(ROOT, "gpurun_out", src)
+P = os.path.join(ROOT, "profiles")
+shutil.copy(os.path.join(S, "trace", "t_kernel_stats.csv"), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
+line = [l for l in open(os.path.join(S, "trace.log")) if l.startswith('{"metric"')]
+bench = json.loads(line[-1]) if line else {}
+rows = list(csv.DictReader(open(os.path.join(S, "trace", "t_kernel_stats.csv"))))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+steps = bench.get("steps", 10) + bench.get("warmup", 2) + 2 + 3   # timed + warm-up + instrumented eager + graph warm-up
+
+def load(name):
+    return list(csv.DictReader(open(os.path.join(S, name, "pmc_by_kernel.csv"))))
+fe, wr, mf = load("pmc_fetch"), load("pmc_write"), load("pmc_mfma")
+def val(tbl, pat, col):
+    n = t = 0.0
+    for r in tbl:
+        if re.search(pat, r["kernel"]) and r.get(col):
+            n += float(r["launches"]); t += float(r["launches"]) * float(r[col])
+    return int(n), (t / n if n else 0.0)
+# ---- HBM-side traffic (FETCH_SIZE / WRITE_SIZE are in KB; gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2)
+hb = []
+names = sorted({r["kernel"] for r in fe} | {r["kernel"] for r in wr})
+for k in names:
+    pat = re.escape(k)
+    nf, f = val(fe, "^" + pat + "$", "FETCH_SIZE"); nw, w = val(wr, "^" + pat + "$", "WRITE_SIZE")
+    hb.append((k, nf, f, w, (2 * f + w) * 1024))
+hb.sort(key=lambda r: -r[1] * r[4])
+with open(os.path.join(P, f"{tag}_pmc_hbm_summary.csv"), "w") as o:
+    w_ = csv.writer(o); w_.writerow(["kernel", "launches", "FETCH_SIZE_KB_mean", "WRITE_SIZE_KB_mean", "hbm_bytes_per_launch(2*FETCH+WRITE)"])
+    for r in hb[:60]:
+        w_.writerow([r[0], r[1], round(r[2], 1), round(r[3], 1), int(r[4])])
+# ---- MFMA utilisation: SQ_VALU_MFMA_BUSY_CYCLES (SIMD cycles with an MFMA executing, summed over the chip) against
+# the SIMD cycles of the dispatch: GRBM_GUI_ACTIVE is summed over the 8 XCDs, 256 CUs x 4 SIMDs
+mrows = []
+for r in mf:
+    g = float(r["GRBM_GUI_ACTIVE"] or 0); b = float(r["SQ_VALU_MFMA_BUSY_CYCLES"] or 0); mo = float(r["SQ_INSTS_VALU_MFMA_MOPS_BF16"] or 0)
+    if b <= 0: continue
+    mrows.append((r["kernel"], int(float(r["launches"])), b, g, b / (g / 8 * 1024), mo * 512))
+mrows.sort(key=lambda r: -r[1] * r[2])
+with open(os.path.join(P, f"{tag}_pmc_mfma_summary.csv"), "w") as o:
+    w_ = csv.writer(o); w_.writerow(["kernel", "launches", "SQ_VALU_MFMA_BUSY_CYCLES_mean", "GRBM_GUI_ACTIVE_mean", "mfma_util=busy/(gui/8*1024)", "bf16_mfma_flop_per_launch(MOPS*512)"])
+    for r in mrows:
+        w_.writerow([r[0], r[1], int(r[2]), int(r[3]), round(r[4], 4), int(r[5])])
+def traffic(pat, label):
+    nf, f = val(fe, pat, "FETCH_SIZE"); nw, w = val(wr, pat, "WRITE_SIZE"); nm, u = 0, 0.0
+    n = t = 0.0
+    for r in mrows:
+        if re.search(pat, r[0]): n += r[1]; t += r[1] * r[4]
+    return {"kernel": label, "launches": nf, "FETCH_SIZE_KB": round(f, 2), "WRITE_SIZE_KB": round(w, 2),
+            "hbm_bytes_per_launch": int((2 * f + w) * 1024), "mfma_util": round(t / n, 4) if n else None}
+tj = traffic(r"gemm_bf16_dma_kernel<false, false", "gemm_bf16_dma_kernel<false,false,64,2,{4|5}> (NT), all launches of one train step (mixed epilogues)")
+tj["source"] = ("rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE (three separate passes) over "
+                "`python bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline`; launch-weighted means (scratch/profile_round2.sh)")
+tj["correction"] = "gfx950: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact"
+tj["merged"] = traffic(r"gemm_bf16_dma2_kernel", "gemm_bf16_dma2_kernel<{4|5}> (dW slabs + dX + previous layer's slab reduction), all launches of one train step")
+tj["cq_apply_fwd"] = traffic(r"cq_apply_fwd", "cq_apply_fwd_{clong,cshort} (fused CQAttention apply stage)")
+tj["cq_score"] = traffic(r"cq_score_kernel", "cq_score_kernel")
+json.dump(tj, open(os.path.join(P, "gemm_traffic.json"), "w"), indent=1)
+with open(os.path.join(P, f"{tag}_summary.md"), "w") as o:
+    o.write(f"# Round 2, {tag} -- rocprofv3 of the default bench\n\n")
+    o.write("Commands (scratch/profile_round2.sh, 1x MI355X, cfg2, bf16, dropout 0.2): `rocprofv3 --kernel-trace --stats --output-format csv -- "
+            "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline` (hipGraph replay); then three PMC-only passes over "
+            "`python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline`: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, "
+            "`--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_WAVE_CYCLES GRBM_GUI_ACTIVE`.\n\n")
+    if bench:
+        o.write(f"Bench line of the traced run: {bench['ms_per_step']} ms/step, {bench['value']} clips/s; roofline {json.dumps(bench.get('roofline'))}\n\n")
+    o.write(f"Kernel time summed over the traced run: {tot/1e6:.1f} ms over {steps} steps = {tot/1e6/steps:.2f} ms/step.\n\n"
+            "| kernel | calls/step | avg us | us/step | % | MFMA util | HBM MB/launch |\n|---|---|---|---|---|---|---|\n")
+    mu = {r[0]: r[4] for r in mrows}; hbm = {r[0]: r[4] for r in hb}
+    for r in rows[:40]:
+        k = r["Name"][:100]
+        o.write(f"| `{k[:90]}` | {int(r['Calls'])/steps:.1f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e3/steps:.0f} | {float(r['Percentage']):.1f} | "
+                f"{mu.get(k, 0):.3f} | {hbm.get(k, 0)/1e6:.1f} |\n")
+    o.write("\nMFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); cross-check: SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 = the "
+            "launch's bf16 MFMA flops.  HBM MB = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH correction).\n")
+print(json.dumps(tj)[:600]); print("bench:", bench.get("ms_per_step"), bench.get("value"))
