@@ -37,6 +37,9 @@ int vmr_sizeof_gemm_desc(void); /* ABI guard for foreign-language bindings of vm
 /* Test utility (no reference counterpart): fills the whole LDS of every CU with `pattern`, so that a kernel reading
  * LDS it never wrote yields the pattern instead of its predecessor's leftovers.  scratch_u32: 4 device bytes. */
 int vmr_debug_poison_lds(uint32_t pattern, void* scratch_u32, void* stream);
+/* Test / A-B utility: tile-variant policy of vmr_gemm for the 256 x 256 "8-phase" kernel: 0 never, 1 where the rounds
+ * model picks it (default, also VMR_GEMM_P8), 2 wherever the shape allows; -1 re-reads the environment. */
+int vmr_debug_set_gemm_p8(int mode);
 
 /* ------------------------------------------------------------------ GEMM
  * C[z] = epilogue(alpha * opA(A[z]) . opB(B[z]))

@@ -10,7 +10,8 @@ def bench(M,N,K,ta,tb,flags=0,splitk=1,iters=50, epi=False, tag=""):
     As=[(torch.randn(K,M,device=dev) if ta else torch.randn(M,K,device=dev)).to(dt) for _ in range(nset)]
     Bs=[(torch.randn(K,N,device=dev) if tb else torch.randn(N,K,device=dev)).to(dt) for _ in range(nset)]
     acc = bool(flags & L.EPI_ACCUM)
-    Cs=[torch.zeros(M,N,device=dev,dtype=torch.float32 if acc else dt) for _ in range(nset)]
+    slab = bool(flags & L.EPI_SLAB)
+    Cs=[torch.zeros((splitk if slab else 1)*M,N,device=dev,dtype=torch.float32 if (acc or slab) else dt) for _ in range(nset)]
     descs=[]
     keep=[]
     for i in range(nset):

@@ -87,6 +87,49 @@ def test_gemm_lds_dma_kernels_exact(dev, shape):
         assert torch.equal(out, (h + res.float()).to(dt)), (shape, tb)
 
 
+def test_gemm_8phase_kernel_exact(dev):
+    """The 256 x 256 8-phase kernel (gemm_p8_body), forced wherever the shape allows: K-contiguous operands (plain,
+    ragged last row tile, fused epilogue with 16-byte permuted stores) and the transposed-operand split-K slab layout,
+    bit-exact on small integers; then the default policy on a shape the rounds model gives to it."""
+    ops = _ops()
+    from vmrframe_amd import _lib as L
+    dt = torch.bfloat16
+    lib = L.lib()
+    try:
+        lib.vmr_debug_set_gemm_p8(2)
+        for (M, N, K) in [(256, 256, 128), (768, 512, 448), (9472, 1024, 1024), (1288, 256, 256), (264, 512, 128)]:
+            torch.manual_seed(M + N + K)
+            A, B = _ints(M, K, dt, dev), _ints(N, K, dt, dev)
+            ref = A.float() @ B.float().t()
+            assert torch.equal(ops.mm(A, B, 0, 0, out_f32=True), ref), (M, N, K)
+            assert torch.equal(ops.mm(A, B, 0, 0), ref.to(dt)), (M, N, K)
+            bias = torch.randn(N, device=dev)
+            res = _ints(M, N, dt, dev)
+            out = torch.empty(M, N, device=dev, dtype=dt)
+            aux = torch.empty_like(out)
+            ops.gemm(A, B, out, M, N, K, 0, 0, K, K, N, dtype=L.BF16, bias=bias, residual=res, aux=aux, ldr=N,
+                     flags=L.EPI_BIAS | L.EPI_RELU | L.EPI_DROPOUT | L.EPI_RESIDUAL | L.EPI_AUX, drop=(0.25, 9, None))
+            mask = ops.dropout_mask(M * N, 0.25, 9, dev).view(M, N)
+            h = torch.relu(ref + bias) * mask
+            assert torch.equal(aux, h.to(dt)) and torch.equal(out, (h + res.float()).to(dt)), (M, N, K)
+        for (M, N, K, sk) in [(256, 256, 256, 1), (1024, 1024, 2368, 4), (1024, 1024, 9472, 6), (512, 256, 576, 3)]:
+            torch.manual_seed(K)
+            A, B = _ints(K, M, dt, dev), _ints(K, N, dt, dev)
+            ref = A.float().t() @ B.float()
+            if sk == 1:
+                out = ops.mm(A, B, 1, 1, out_f32=True)
+            else:
+                ws = torch.empty(sk, M, N, device=dev)
+                ops.gemm(A, B, ws, M, N, K, 1, 1, M, N, N, dtype=L.BF16, flags=L.EPI_SLAB, splitk=sk)
+                out = ws.sum(0)
+            assert torch.equal(out, ref), (M, N, K, sk)
+    finally:
+        lib.vmr_debug_set_gemm_p8(-1)
+    M, N, K = 9472, 3072, 320                     # 444 tiles of 256 x 256: the default policy's choice
+    A, B = _ints(M, K, dt, dev), _ints(N, K, dt, dev)
+    assert torch.equal(ops.mm(A, B, 0, 0, out_f32=True), A.float() @ B.float().t())
+
+
 @pytest.mark.parametrize("shape", [(1024, 1024, 2112, 8), (256, 128, 1024, 4), (1024, 1024, 8192, 8)])
 def test_gemm_splitk_slabs_colsum(dev, shape):
     """Weight-gradient shape: dW = A^T.B with split-K slabs (plain fp32 partials + vmr_splitk_reduce) and the

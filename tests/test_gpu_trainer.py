@@ -263,14 +263,17 @@ def test_load_state_dict_after_arena_build_refreshes_bf16_mirrors(dev):
     for _ in range(2):                                   # the weights move well away from the checkpoint
         loss, _ = V.train_engine_SeqPAN(m, dbatch, cfg, "train")
         opt.zero_grad(); loss.backward(); opt.step()
-    moved, _ = V.train_engine_SeqPAN(m, dbatch, cfg, "train")
+    moved, moved_out = V.train_engine_SeqPAN(m, dbatch, cfg, "train")
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()})
     loss, out = V.train_engine_SeqPAN(m, dbatch, cfg, "train")
     fresh = build(cfg, weights, "bf16", dev, g)
     loss_f, out_f = V.train_engine_SeqPAN(fresh, dbatch, cfg, "train")
     assert abs(moved.item() - loss_f.item()) > 1e-2       # (the two optimizer steps did change the loss)
-    assert torch.allclose(out["slogits"].float(), out_f["slogits"].float(), atol=1e-4, rtol=1e-4)
-    assert abs(loss.item() - loss_f.item()) < 1e-4 * max(1.0, abs(loss_f.item()))
+    # (not bit-equal: the few-tile products split K over idle CUs with fp32 atomics, whose order flips bf16 last bits
+    #  from run to run -- measured 0 to 1.1e-3 relative between two fresh models; stale mirrors are 20x the norm)
+    assert rel(moved_out["slogits"].float(), out_f["slogits"].float()) > 0.5
+    assert rel(out["slogits"].float(), out_f["slogits"].float()) < 1e-2
+    assert abs(loss.item() - loss_f.item()) < 5e-3 * max(1.0, abs(loss_f.item()))
     # ... and the backward's K-major copies: gradients of the reloaded model == the fresh model's
     opt.zero_grad(); loss.backward()
     loss_f.backward()

@@ -127,6 +127,7 @@ SIGNATURES = {
     "vmr_map2d_scatter": [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     "vmr_sumsq": [_P, _P, _L, _P],
     "vmr_debug_poison_lds": [_U, _P, _P],
+    "vmr_debug_set_gemm_p8": [_I],
     "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P, _F, _F, _L, _P],
 }
 

@@ -833,6 +833,225 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(vmr_gemm_t g, int
   gemm_dma_a3b2_body<MT>(g, tiles_m, tiles_n, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, ONE 512-thread workgroup per CU, eight phases per two K-tiles ("8-phase" schedule, the guide's
+// cdna_hip_programming.md section 5 template re-derived for this library's LDS images and swapped-operand epilogue).
+//   * 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 = acc[8][4]; a PHASE is one 64 x 32 quadrant of it over the whole
+//     K-tile: 16 MFMAs.  Quadrant order (A rows, B cols): (lo,lo) (lo,hi) (hi,hi) (hi,lo); the B-lo fragments stay in
+//     registers from phase 1 to phase 4, so a K-tile's four LDS units are last read in phases 1, 1, 2, 3:
+//         unit 0 "Alo" = the rows every wave reads in phase 1 (rows {0..63, 128..191} of the A tile),
+//         unit 1 "Blo" = weight rows c*64 + [0,32) of the four 64-column groups, unit 2 "Bhi" = c*64 + [32,64),
+//         unit 3 "Ahi" = A rows {64..127, 192..255}          (16 KiB each = two 1-KiB LDS-DMA blocks per wave).
+//   * two K-tile buffers (2 x 64 KiB).  Phase P (counted over the whole K loop) stages unit P + 6 -- the slot whose last
+//     read was two or three phases ago -- so every unit is requested 5-6 phases before its first read, and one counted
+//     wait per phase, "all but the four youngest units" (vmcnt(8)), retires exactly the unit the NEXT phase reads first.
+//   * the two wave rows (wm = 0 / 1, one wave of each per SIMD) run one barrier apart: while one group issues its 16
+//     MFMAs (s_setprio 1) the other issues fragment reads, its share of the LDS-DMA requests and the wait; two raw
+//     s_barriers per phase keep them alternating.  Hazards (both groups): a unit is read one phase AFTER the phase whose
+//     pre-barrier wait retired it, and re-staged at least two phases after its last read.
+// Layouts: TR = false: both operands K-contiguous (x.W^T: the forward products, dX on the K-major weight copies);
+// TR = true: both operands stored [K][rows] (the weight gradient dz^T.x), [64][128] images read with ds_read_b64_tr_b16.
+constexpr int P8_UNIT = 16384, P8_BUF = 4 * P8_UNIT, P8_SMEM = 2 * P8_BUF;
+
+template <int N> __device__ __forceinline__ void p8_vmcnt() {
+  if constexpr (N >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool TR, bool PERM>
+__device__ __forceinline__ void gemm_p8_body(const vmr_gemm_t& g, int tiles_m, int tiles_n, unsigned char* smem, int bid,
+                                             int dbg = 0) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  // tile / split of this workgroup (same conventions as tile_coord: the K split rides in the low bits of the id)
+  int ks = 0, logical = bid;
+  if (g.splitk > 1) {
+    ks = bid % g.splitk;
+    logical = bid / g.splitk;
+  } else {
+    const int nblk = tiles_m * tiles_n, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  int k_begin = 0, k_end = g.K;
+  if (g.splitk > 1) {
+    int chunk = (g.K + g.splitk - 1) / g.splitk;
+    chunk = (chunk + 63) / 64 * 64;
+    k_begin = ks * chunk;
+    k_end = min(g.K, k_begin + chunk);
+  }
+  const int nk = k_end > k_begin ? (k_end - k_begin) / 64 : 0;
+  const int U = 4 * nk;                                    // staging units of this workgroup
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+  const int64_t coff = (g.flags & VMR_EPI_SLAB) ? (int64_t)ks * g.M * g.ldc : 0;
+
+  // per-lane source offsets (elements) of this wave's two LDS-DMA blocks of each unit kind
+  int offA[2][2], offB[2][2];                              // [lo/hi][block]
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = wid * 2 + jj;                            // 1-KiB block of the 16-KiB unit
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+      if constexpr (!TR) {
+        const int row = 8 * j + (lane >> 3);               // image row (128 B each), 16-B chunk swizzled by the row
+        const int c = (lane & 7) ^ (row & 7);
+        const int arow = (row >> 6) * 128 + hi * 64 + (row & 63);
+        const int w = row & 31, tj = w >> 4, r = w & 15;
+        const int brow = (row >> 5) * 64 + hi * 32 + (PERM ? ((r >> 2) * 8 + tj * 4 + (r & 3)) : w);
+        offA[hi][jj] = min(m0 + arow, g.M - 1) * (int)g.lda + c * 8;
+        offB[hi][jj] = (n0 + brow) * (int)g.ldb + c * 8;
+      } else {
+        const int r = 4 * j + (lane >> 4);                 // k row of the [64][128] image (256 B each)
+        const int ph16 = lane & 15;
+        const int col = (((ph16 >> 1) ^ swz_tr(r)) * 2 + (ph16 & 1)) * 8;
+        offA[hi][jj] = r * (int)g.lda + m0 + (col >> 6) * 128 + hi * 64 + (col & 63);
+        offB[hi][jj] = r * (int)g.ldb + n0 + (col >> 5) * 64 + hi * 32 + (col & 31);
+      }
+    }
+  }
+  // unit u -> (K-tile u >> 2, kind u & 3: Alo, Blo, Bhi, Ahi)
+  auto stage = [&](int u) {
+    const int t = u >> 2, kind = u & 3;
+    unsigned char* dst = smem + (t & 1) * P8_BUF + kind * P8_UNIT + wid * 2048;
+    const int k0 = k_begin + t * 64;
+    const bool isA = kind == 0 || kind == 3;
+    const int hi = kind >> 1;                              // kinds 2, 3 are the hi halves
+    const bf16_t* base = isA ? A : B;
+    const int64_t kadv = TR ? (int64_t)k0 * (isA ? g.lda : g.ldb) : (int64_t)k0;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int off = isA ? offA[hi][jj] : offB[hi][jj];
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(base + kadv + off), (lvoid_t*)(dst + jj * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (nk > 0) {
+    // prologue: units 0..5 (K-tile 0 and the first two units of K-tile 1)
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
+      if (u < U) stage(u);
+    if (U > 6) p8_vmcnt<8>();       // units 0, 1 landed (this wave's parts)
+    else p8_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();             // the second wave row runs one barrier behind
+    bf16x8 fa[4][2], flo[2][2], fhi[2][2];
+    auto mma = [&](int ih, const bf16x8 (&fb)[2][2], int jh) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[ih * 4 + i][jh * 2 + j] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);  // C^T tile
+      __builtin_amdgcn_s_setprio(0);
+    };
+    for (int t = 0; t < nk; ++t) {
+      const unsigned char* cur = smem + (t & 1) * P8_BUF;
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const int P = 4 * t + ph;
+        // 1. this phase's fragment reads
+        if (dbg & 4) {
+        } else if (ph == 0) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) flo[j][kk] = read_frag<!TR, 64>(cur + 1 * P8_UNIT, wn * 2 + j, kk, lane);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag<!TR, 64>(cur + 0 * P8_UNIT, wm * 4 + i, kk, lane);
+        } else if (ph == 1) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fhi[j][kk] = read_frag<!TR, 64>(cur + 2 * P8_UNIT, wn * 2 + j, kk, lane);
+        } else if (ph == 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag<!TR, 64>(cur + 3 * P8_UNIT, wm * 4 + i, kk, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // 2. one unit of a later K-tile, then "everything the next phase reads has landed" (this wave's parts)
+        const int u = P + 6;
+        if (u < U) {
+          if (!(dbg & 1)) stage(u);
+          p8_vmcnt<8>();
+        } else {
+          const int rem = U - 3 - P;                       // units still allowed in flight: 3, 2, 1, 0
+          if (rem >= 3) p8_vmcnt<6>();
+          else if (rem == 2) p8_vmcnt<4>();
+          else if (rem == 1) p8_vmcnt<2>();
+          else p8_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // 3. the quadrant
+        if (!(dbg & 2)) {
+        if (ph == 0) mma(0, flo, 0);
+        else if (ph == 1) mma(0, fhi, 1);
+        else if (ph == 2) mma(1, fhi, 1);
+        else mma(1, flo, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();             // pairs with the second wave row's last barrier
+  }
+  // register-direct epilogue (the residual quads are requested here: during the K loop their 64 registers hold fragments)
+  u32x2 rres[8][4];
+  if (g.flags & VMR_EPI_RESIDUAL) {
+    const bf16_t* Rsd = reinterpret_cast<const bf16_t*>(g.residual) + coff;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bf16_t* rrow = Rsd + (int64_t)(min(m0 + wm * 128 + (lane & 15) + i * 16, g.M - 1) / g.res_div) * g.ldr + n0 + wn * 64;
+      if constexpr (PERM) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const uint4 w = *reinterpret_cast<const uint4*>(rrow + quad_col<true>(2 * k, lane >> 4));
+          rres[i][2 * k] = (u32x2){w.x, w.y};
+          rres[i][2 * k + 1] = (u32x2){w.z, w.w};
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rres[i][j] = *reinterpret_cast<const u32x2*>(rrow + quad_col<false>(j, lane >> 4));
+      }
+    }
+  }
+  epilogue_direct<8, PERM>(g, acc, wm, wn, lane, m0, n0, 0,
+                           (g.flags & VMR_EPI_OUT_F32) ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
+                                                       : reinterpret_cast<bf16_t*>(g.C) + coff,
+                           rres, reinterpret_cast<bf16_t*>(g.aux) + coff);
+}
+
+template <bool TR>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gemm_p8_body<TR, !TR>(g, tiles_m, tiles_n, smem, blockIdx.x);
+}
+template <bool TR>   // ablation build: dbg bit 0 = no LDS-DMA requests inside the K loop, bit 1 = no MFMAs, bit 2 = no fragment reads
+__global__ __launch_bounds__(512, 1) void gemm_bf16_p8_dbg_kernel(vmr_gemm_t g, int tiles_m, int tiles_n, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gemm_p8_body<TR, !TR>(g, tiles_m, tiles_n, smem, blockIdx.x, dbg);
+}
+
 // Two independent products in ONE launch: workgroups [0, nblk2) run problem 2 (a split-K weight-gradient product
 // dW = dz^T.x writing slabs), the rest problem 1 (an x.W^T-layout product: the input gradient dX = dz.Wt^T).  Single-round
 // grids run every workgroup in phase (fill, K loop, epilogue burst); back to back in one grid, the second problem's
@@ -1011,6 +1230,7 @@ Pick pick_trans(int ta, int tb, int dtype, int bk) {
   return pick_dtype<true, true, AL>(dtype, bk);
 }
 
+int g_p8 = -1;        // VMR_GEMM_P8 / vmr_debug_set_gemm_p8: 256 x 256 8-phase kernel 0 never, 1 (default) by the rounds model, 2 wherever allowed
 int g_gemm_bk = 0;   // 0 = not read yet; VMR_GEMM_BK=32|64 selects the bf16 K-step of the register-staged path
 int g_gemm_dma = -1;  // VMR_GEMM_DMA: 0 off (register-staged kernel only), 1: BK=32 x 4 stages, 2 (default): BK=64 x 2 stages
 
@@ -1063,6 +1283,34 @@ bool gemm_aligned(const vmr_gemm_t& g) {   // 16-byte accesses everywhere
     if (g.flags & VMR_EPI_AUX) al = al && aligned16(g.aux);
   }
   return al;
+}
+
+// shapes the 8-phase kernel takes: bf16, both operands K-contiguous (ragged M allowed) or both stored [K][rows]
+// (M, N multiples of 256), N a multiple of 256, K-ranges of whole 64-deep tiles, plain or slab / fp32 stores
+bool p8_ok(const vmr_gemm_t& g, int64_t Z) {
+  if (g.dtype != VMR_BF16 || Z != 1 || g.transA != g.transB || !gemm_aligned(g)) return false;
+  if (g.N % 256 != 0 || g.K % 64 != 0 || g.M % 8 != 0 || g.M < 256) return false;
+  if (g.transA && g.M % 256 != 0) return false;
+  if (g.flags & VMR_EPI_ACCUM) return false;
+  if (g.a_colsum) return false;
+  if ((g.flags & VMR_EPI_BIAS) && !(aligned16(g.bias) && aligned16(g.bias2))) return false;
+  const int sk = g.splitk > 1 ? g.splitk : 1;
+  if (sk > 1 && !(g.flags & VMR_EPI_SLAB)) return false;
+  int64_t chunk = (g.K + sk - 1) / sk;
+  chunk = (chunk + 63) / 64 * 64;
+  if (chunk * (sk - 1) >= g.K || g.K - chunk * (sk - 1) < 64) return false;          // every split gets at least one K-tile
+  // per-lane source offsets are 32-bit element offsets
+  const int64_t ea = g.transA ? (int64_t)64 * g.lda + g.M : (int64_t)g.M * g.lda;
+  const int64_t eb = g.transB ? (int64_t)64 * g.ldb + g.N : (int64_t)g.N * g.ldb;
+  return ea < (1ll << 31) && eb < (1ll << 31);
+}
+// Measured (scratch/p8_bench.py, same box, us): [9472,3072,1024] 69 vs 84 (320x128 tiles), 4096^3 113 vs 158, 8192^3 827
+// vs 1092 -- but [9472,1024,1024] 33 vs 31, [9472,2048,1024] 60 vs 58, [8192,1024,4096] 87 vs 79: 256 x 256 tiles pay only
+// when they fill at least 85 % of the CUs of every round (148 tiles of 256 CUs do not).
+bool p8_wins(const vmr_gemm_t& g, int64_t tiles) {
+  (void)g;
+  const int64_t rounds = (tiles + 255) / 256;
+  return (double)tiles / (double)(rounds * 256) >= 0.85;
 }
 
 }  // namespace
@@ -1145,6 +1393,35 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   if (g_big < 0) {
     const char* e = getenv("VMR_GEMM_BIG");
     g_big = e ? atoi(e) : 0;
+  }
+  // 256 x 256 tiles, 8-phase schedule (gemm_p8_body): VMR_GEMM_P8 = 0 off, 1 where the rounds model says so, 2 wherever
+  // the shape allows
+  if (g_p8 < 0) {
+    const char* e = getenv("VMR_GEMM_P8");
+    g_p8 = e ? atoi(e) : 1;
+  }
+  if (g_p8 && p8_ok(g, (int64_t)g.Z1 * g.Z2)) {
+    const int tm = cdiv(g.M, 256), tn = g.N / 256;
+    const int64_t tiles = (int64_t)tm * tn * g.splitk;
+    if (g_p8 >= 2 || p8_wins(g, tiles)) {
+      static int g_p8dbg = -1;
+      if (g_p8dbg < 0) {
+        const char* e = getenv("VMR_P8_DBG");
+        g_p8dbg = e ? atoi(e) : 0;
+      }
+      if (g_p8dbg) {
+        auto df = g.transA ? gemm_bf16_p8_dbg_kernel<true> : gemm_bf16_p8_dbg_kernel<false>;
+        if (int rc = set_smem_once((gemm_fn)(void*)df, P8_SMEM)) return rc;
+        hipLaunchKernelGGL(df, dim3((unsigned)tiles), dim3(512), P8_SMEM, (hipStream_t)stream, g, tm, tn, g_p8dbg);
+        VMR_LAUNCH_CHECK();
+        return 0;
+      }
+      gemm_fn pf = g.transA ? (gemm_fn)gemm_bf16_p8_kernel<true> : (gemm_fn)gemm_bf16_p8_kernel<false>;
+      if (int rc = set_smem_once(pf, P8_SMEM)) return rc;
+      hipLaunchKernelGGL(pf, dim3((unsigned)tiles), dim3(512), P8_SMEM, (hipStream_t)stream, g, tm, tn);
+      VMR_LAUNCH_CHECK();
+      return 0;
+    }
   }
   if (g_big && tall_ok && dma_ok && !g.transB && Z == 1 && g.K >= 192 && g.M >= 256 && !(g.flags & VMR_EPI_SLAB)) {
     // one round of <= 256 tiles, or whole rounds of 256-row tiles; otherwise the 2-per-CU kernels keep the shape
@@ -1295,6 +1572,11 @@ extern "C" int vmr_gemm2_reduce(const vmr_gemm_t* p1, const vmr_gemm_t* p2, cons
                        tn1, g2, tm2, tn2, nblk2, nblk1 + nblk2, rj);
   }
   VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_debug_set_gemm_p8(int mode) {
+  g_p8 = mode;
   return 0;
 }
 
