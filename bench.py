@@ -403,7 +403,7 @@ def main():
             # bytes = read long + short operand, write both probability matrices (bf16); flops = the QK^T contraction
             us = [s_.elapsed_time(e_) * 1e3 for (s_, e_, *_r) in cq_rec]
             _, _, B_, Ll, Ls, D_ = cq_rec[0]
-            by = B_ * ((Ll + Ls) * D_ * 2 + 2 * Ll * ((Ls + 7) // 8 * 8) * 2)
+            by = B_ * ((Ll + Ls) * D_ * 2 + 2 * Ll * ((Ls + 7) // 8 * 8) * 4)     # (fp32 probability pair)
             fl = 2.0 * B_ * Ll * Ls * D_
             t_ = sum(us) / len(us) * 1e-6
             out["cq_score_kernel"] = {"kernel": "cq_score_kernel (trilinear QK^T + both masked softmaxes, one launch)",

@@ -23,9 +23,13 @@ struct CqArgs {
   int Ll, Ls, D, ldP, orient, SP32;
 };
 
+// NKS = D / 32 k-steps, compile-time: the fragment pipeline below must be straight-line code.  (With a run-time trip
+// count and guarded re-requests hipcc put "s_waitcnt vmcnt(0)" in front of every MFMA pair -- 16 of the 32 k-steps each
+// paid a full HBM round trip, and the eight guarded shortterm / mask loads another eight: 18 us for 20 MB.)
+template <int NKS>
 __global__ __launch_bounds__(512) void cq_score_kernel(CqArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int D = a.D, RB = D * 2, CPRW = RB / 16;           // bytes / 16-B chunks per short-operand row
+  constexpr int D = NKS * 32, RB = D * 2, CPRW = RB / 16;  // bytes / 16-B chunks per short-operand row
   unsigned char* Ss = smem;                                // [32][RB]
   float* red = reinterpret_cast<float*>(smem + 32 * RB);   // [8 waves][32] column partials
   const int tid = threadIdx.x, lane = tid & 63;
@@ -47,36 +51,43 @@ __global__ __launch_bounds__(512) void cq_score_kernel(CqArgs a) {
   const int vi = min(v0 + (lane & 15), a.Ll - 1);
   const bf16_t* lrow = Lg + (int64_t)vi * D + (lane >> 4) * 8;
   f32x4 st[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-  const int nks = D / 32;
-  // 16 fragments (16 x 1 KiB per wave) in flight: each is re-requested right after it is consumed
-  bf16x8 fr[16];
+  // the lane's eight (t) scalars of the short stream, requested before the operand stream (index-clamped, unconditional)
+  float stv[2][4], msv[2][4];
 #pragma unroll
-  for (int u = 0; u < 16; ++u)
-    if (u < nks) fr[u] = *reinterpret_cast<const bf16x8*>(lrow + u * 32);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the DMA blocks and the first fragments have landed
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tc = min(j * 16 + (lane >> 4) * 4 + r, a.Ls - 1);
+      stv[j][r] = a.shortterm[(int64_t)b * a.Ls + tc];
+      msv[j][r] = a.mask_short[(int64_t)b * a.Ls + tc];
+    }
+  const float mlv = a.mask_long[(int64_t)b * a.Ll + vi];
+  // up to 32 fragments (32 KiB per wave) in flight: at D <= 1024 the whole row block is requested at once
+  constexpr int RG = NKS < 32 ? NKS : 32;
+  bf16x8 fr[RG];
+#pragma unroll
+  for (int u = 0; u < RG; ++u) fr[u] = *reinterpret_cast<const bf16x8*>(lrow + u * 32);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RG) : "memory");   // the DMA blocks and the scalars (issued first) have landed
   __builtin_amdgcn_s_barrier();
-  for (int k0 = 0; k0 < nks; k0 += 16) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+  for (int k0 = 0; k0 < NKS; k0 += RG) {
+#pragma unroll
+    for (int u = 0; u < RG; ++u) {
       const int ks = k0 + u;
-      if (ks < nks) {
-        if (act) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int row = j * 16 + (lane & 15);
-            const int c = ks * 4 + (lane >> 4);
-            const bf16x8 sf = *reinterpret_cast<const bf16x8*>(Ss + row * RB + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
-            st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, fr[u], st[j], 0, 0, 0);   // C[t][v]
-          }
-        }
-        if (ks + 16 < nks) fr[u] = *reinterpret_cast<const bf16x8*>(lrow + (ks + 16) * 32);
+      for (int j = 0; j < 2; ++j) {
+        const int row = j * 16 + (lane & 15);
+        const int c = ks * 4 + (lane >> 4);
+        const bf16x8 sf = *reinterpret_cast<const bf16x8*>(Ss + row * RB + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
+        st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, fr[u], st[j], 0, 0, 0);   // C[t][v]
       }
+      if (ks + RG < NKS) fr[u] = *reinterpret_cast<const bf16x8*>(lrow + (ks + RG) * 32);
     }
   }
   // lane owns v = v0 + (lane&15) and t = j*16 + (lane>>4)*4 + r
   const int v = v0 + (lane & 15);
   const bool vok = act && v < a.Ll;
-  const float ml = vok ? a.mask_long[(int64_t)b * a.Ll + v] : 0.f;
+  const float ml = vok ? mlv : 0.f;
   float xt[2][4], xv[2][4];
   float mxt = -INFINITY;
 #pragma unroll
@@ -86,8 +97,8 @@ __global__ __launch_bounds__(512) void cq_score_kernel(CqArgs a) {
       const int t = j * 16 + (lane >> 4) * 4 + r;
       float m = -INFINITY, mv = -INFINITY;
       if (t < a.Ls && vok) {
-        const float s = st[j][r] + a.shortterm[(int64_t)b * a.Ls + t];
-        m = s + (1.0f - a.mask_short[(int64_t)b * a.Ls + t]) * VMR_NEG_INF_MASK;   // softmax over t
+        const float s = st[j][r] + stv[j][r];
+        m = s + (1.0f - msv[j][r]) * VMR_NEG_INF_MASK;   // softmax over t
         mv = s + (1.0f - ml) * VMR_NEG_INF_MASK;                                    // softmax over v
       }
       xt[j][r] = m; xv[j][r] = mv;
@@ -218,12 +229,20 @@ extern "C" int vmr_cq_score_fwd(const void* lng, const void* sht, const float* s
   if (smem > 64 * 1024) {
     static thread_local bool done = false;
     if (!done) {
-      hipError_t e = hipFuncSetAttribute((const void*)cq_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return vmr_fail(-5, "vmr_cq_score_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      for (const void* f : {(const void*)cq_score_kernel<32>, (const void*)cq_score_kernel<40>, (const void*)cq_score_kernel<48>, (const void*)cq_score_kernel<56>,
+                            (const void*)cq_score_kernel<64>}) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vmr_fail(-5, "vmr_cq_score_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      }
       done = true;
     }
   }
-  hipLaunchKernelGGL(cq_score_kernel, dim3(B), dim3(512), smem, (hipStream_t)stream, a);
+  switch (D / 256) {
+#define VMR_CQ_CASE(n) case n: hipLaunchKernelGGL(cq_score_kernel<n * 8>, dim3(B), dim3(512), smem, (hipStream_t)stream, a); break
+    VMR_CQ_CASE(1); VMR_CQ_CASE(2); VMR_CQ_CASE(3); VMR_CQ_CASE(4); VMR_CQ_CASE(5); VMR_CQ_CASE(6); VMR_CQ_CASE(7); VMR_CQ_CASE(8);
+#undef VMR_CQ_CASE
+    default: return vmr_fail(-2, "vmr_cq_score_fwd: unsupported D %d", D);
+  }
   VMR_LAUNCH_CHECK();
   if (Srow && orient == 1 && ldP > Ll) {
     const int64_t rows = (int64_t)B * Ls;
