@@ -63,6 +63,10 @@ int vmr_debug_set_gemm_p8(int mode);
 #define VMR_EPI_SLAB 256     /* split-K without atomics: split ks writes fp32 C + ks*M*ldc (then vmr_splitk_reduce) */
 #define VMR_EPI_RES_PRE 512  /* with VMR_EPI_RESIDUAL: the residual joins the PRE-activation, act(x.W^T + b + residual),
                                * instead of being added after activation / dropout (BAN map2d_proj on a concatenation) */
+#define VMR_EPI_AUX_BITS 1024 /* with VMR_EPI_AUX: aux is a BIT matrix, uint8 [M][N/8] (bit c%8 of byte [m][c/8] = the
+                               * pre-residual value is non-zero) -- all the ReLU / dropout backward needs, 1/16 of the bytes.
+                               * Only on the register-direct epilogue of the row-major-weight LDS-DMA kernels:
+                               * ask vmr_gemm_aux_bits_supported() first; vmr_gemm refuses otherwise. */
 
 typedef struct {
   const void* A;
@@ -103,6 +107,9 @@ typedef struct {
 } vmr_gemm_t;
 
 int vmr_gemm(const vmr_gemm_t* g, void* stream);
+/* 1 if vmr_gemm would run g on a kernel whose epilogue can write VMR_EPI_AUX_BITS (g.aux / that flag need not be set
+ * yet: the answer depends on shapes, layouts, alignment and the other flags only). */
+int vmr_gemm_aux_bits_supported(const vmr_gemm_t* g);
 /* Two INDEPENDENT products in one launch when both qualify for the single-round LDS-DMA tiles -- g1: row-major
  * operands without split-K (the input gradient dX = dY.W on the K-major weight copy), g2: both operands transposed,
  * split-K slabs (the weight gradient dW = dY^T.x) -- so that one problem's fill overlaps the other's store drain;
@@ -280,7 +287,8 @@ int vmr_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t r
  *          post-dropout ReLU output, scale = 1/(1-p))
  *  mode 2: dz = dy*scale*keep(seed, r*D+c), db += colsum(dz) (dropout without ReLU; the mask
  *          is regenerated from the seed the forward GEMM epilogue used)
- * db may be NULL in modes 1/2.  The column sums are ACCUMULATED: db += db_scale*colsum and, when
+ *  mode 3: as mode 1 with h the BIT matrix VMR_EPI_AUX_BITS wrote (uint8 [rows][D/8])
+ * db may be NULL in modes 1/2/3.  The column sums are ACCUMULATED: db += db_scale*colsum and, when
  * db2 is given, db2 += colsum (the two bias terms of vmr_gemm_t.bias/bias2; db_scale 0 reads as 1). */
 int vmr_relu_bwd_bias(int mode, const void* dy, const void* h, void* dz, float* db, int64_t rows,
                       int D, int64_t ld, float scale, int dtype, float drop_p, uint32_t drop_seed,

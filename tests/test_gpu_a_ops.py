@@ -1,5 +1,6 @@
 """GPU: each HIP operator (through the C ABI) against a plain PyTorch fp32
 reference of the same op, forward and backward."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -85,6 +86,30 @@ def test_gemm_lds_dma_kernels_exact(dev, shape):
         h = torch.relu(A.float() @ B.float().t() + bias) * mask
         assert torch.equal(aux, h.to(dt)), (shape, tb)
         assert torch.equal(out, (h + res.float()).to(dt)), (shape, tb)
+    # the same epilogue with the mask kept as a bit matrix (VMR_EPI_AUX_BITS), and the backward kernel that reads it
+    d = L.GemmDesc()
+    d.A, d.B, d.C, d.bias, d.residual = A.data_ptr(), B.data_ptr(), out.data_ptr(), bias.data_ptr(), res.data_ptr()
+    d.lda, d.ldb, d.ldc, d.ldr, d.M, d.N, d.K, d.dtype = K, K, N, N, M, N, K, L.BF16
+    d.flags = L.EPI_BIAS | L.EPI_RELU | L.EPI_DROPOUT | L.EPI_RESIDUAL
+    d.Z1 = d.Z2 = d.splitk = 1
+    assert L.lib().vmr_gemm_aux_bits_supported(C.byref(d)) == 1
+    bits = torch.zeros(M, N // 8, device=dev, dtype=torch.uint8)
+    out2 = torch.empty(M, N, device=dev, dtype=dt)
+    ops.gemm(A, B, out2, M, N, K, 0, 0, K, K, N, dtype=L.BF16, bias=bias, residual=res, aux=bits, ldr=N,
+             flags=L.EPI_BIAS | L.EPI_RELU | L.EPI_DROPOUT | L.EPI_RESIDUAL | L.EPI_AUX | L.EPI_AUX_BITS, drop=(0.25, 9, None))
+    assert torch.equal(out2, (h + res.float()).to(dt))
+    want = (h.to(dt) != 0).view(M, N // 8, 8).to(torch.int32)
+    want = (want << torch.arange(8, device=dev, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(bits, want)
+    dy = _ints(M, N, dt, dev)
+    dz1, dz3 = torch.empty_like(dy), torch.empty_like(dy)
+    db1, db3 = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    st = L.stream_ptr()
+    L.check(L.lib().vmr_relu_bwd_bias(1, dy.data_ptr(), aux.data_ptr(), dz1.data_ptr(), db1.data_ptr(), M, N, N, 2.0, L.BF16,
+                                      0.0, 0, None, None, 1.0, st), "mode 1")
+    L.check(L.lib().vmr_relu_bwd_bias(3, dy.data_ptr(), bits.data_ptr(), dz3.data_ptr(), db3.data_ptr(), M, N, N, 2.0, L.BF16,
+                                      0.0, 0, None, None, 1.0, st), "mode 3")
+    assert torch.equal(dz1, dz3) and torch.allclose(db1, db3, rtol=1e-6, atol=1e-3)
 
 
 def test_gemm_8phase_kernel_exact(dev):

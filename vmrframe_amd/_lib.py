@@ -31,6 +31,7 @@ def ln_bwd_ws_floats(rows: int, D: int) -> int:
 
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_AUX, EPI_OUT_F32, EPI_ACCUM, EPI_ROWSCALE, EPI_SLAB, EPI_RES_PRE = \
     1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+EPI_AUX_BITS = 1024
 
 
 class ColReduceItem(C.Structure):
@@ -128,6 +129,7 @@ SIGNATURES = {
     "vmr_sumsq": [_P, _P, _L, _P],
     "vmr_debug_poison_lds": [_U, _P, _P],
     "vmr_debug_set_gemm_p8": [_I],
+    "vmr_gemm_aux_bits_supported": [_P],
     "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P, _F, _F, _L, _P],
 }
 

@@ -552,7 +552,14 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
         if (flags & VMR_EPI_AUX) {
           const float a8[8] = {ax[2 * k][0], ax[2 * k][1], ax[2 * k][2], ax[2 * k][3],
                                ax[2 * k + 1][0], ax[2 * k + 1][1], ax[2 * k + 1][2], ax[2 * k + 1][3]};
-          Vec8<bf16_t>::store(Aux + (int64_t)gm * g.ldr + gn, a8);
+          if (flags & VMR_EPI_AUX_BITS) {   // the lane's 8 consecutive columns = one byte of the [M][N/8] bit matrix
+            uint32_t bits = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bits |= (a8[e] != 0.f ? 1u : 0u) << e;
+            reinterpret_cast<unsigned char*>(g.aux)[((int64_t)zb * g.M + gm) * (g.N >> 3) + (gn >> 3)] = (unsigned char)bits;
+          } else {
+            Vec8<bf16_t>::store(Aux + (int64_t)gm * g.ldr + gn, a8);
+          }
         }
       }
     } else {
@@ -1307,6 +1314,15 @@ bool p8_ok(const vmr_gemm_t& g, int64_t Z) {
 // Measured (scratch/p8_bench.py, same box, us): [9472,3072,1024] 69 vs 84 (320x128 tiles), 4096^3 113 vs 158, 8192^3 827
 // vs 1092 -- but [9472,1024,1024] 33 vs 31, [9472,2048,1024] 60 vs 58, [8192,1024,4096] 87 vs 79: 256 x 256 tiles pay only
 // when they fill at least 85 % of the CUs of every round (148 tiles of 256 CUs do not).
+// true when vmr_gemm will take a row-major-weight LDS-DMA kernel with the register-direct 16-byte epilogue (the only
+// one that can write VMR_EPI_AUX_BITS): mirrors the dispatch below
+bool gemm_perm_direct(const vmr_gemm_t& g) {
+  const int dma = g_gemm_dma < 0 ? 2 : g_gemm_dma;
+  const int64_t Z = (int64_t)(g.Z1 > 0 ? g.Z1 : 1) * (g.Z2 > 0 ? g.Z2 : 1);
+  return dma >= 2 && g.dtype == VMR_BF16 && !g.transB && Z == 1 && g.splitk <= 1 && gemm_aligned(g) && g.M % BM == 0 &&
+         g.N % BN == 0 && g.K % 64 == 0 && g.K >= 128 && !(g.flags & (VMR_EPI_ACCUM | VMR_EPI_OUT_F32 | VMR_EPI_SLAB)) &&
+         (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));
+}
 bool p8_wins(const vmr_gemm_t& g, int64_t tiles) {
   (void)g;
   const int64_t rounds = (tiles + 255) / 256;
@@ -1336,6 +1352,12 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   VMR_CHECK(!(g.flags & VMR_EPI_AUX) || g.aux, "vmr_gemm: aux flag without pointer");
   VMR_CHECK(!(g.flags & VMR_EPI_ROWSCALE) || g.rowscale, "vmr_gemm: rowscale flag without pointer");
   VMR_CHECK(!(g.flags & VMR_EPI_DROPOUT) || (g.drop_p >= 0.f && g.drop_p < 1.f), "vmr_gemm: bad drop_p");
+  if (g_gemm_dma < 0) {
+    const char* e = getenv("VMR_GEMM_DMA");
+    g_gemm_dma = e ? atoi(e) : 2;
+  }
+  VMR_CHECK(!(g.flags & VMR_EPI_AUX_BITS) || ((g.flags & VMR_EPI_AUX) && gemm_perm_direct(g)),
+            "vmr_gemm: VMR_EPI_AUX_BITS on a product without the register-direct epilogue (ask vmr_gemm_aux_bits_supported)");
   const int64_t Z = (int64_t)g.Z1 * g.Z2 * g.splitk;
   VMR_CHECK(Z <= 65535, "vmr_gemm: too many batches (%lld)", (long long)Z);
   if (g.M == 0 || g.N == 0) return 0;
@@ -1573,6 +1595,15 @@ extern "C" int vmr_gemm2_reduce(const vmr_gemm_t* p1, const vmr_gemm_t* p2, cons
   }
   VMR_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int vmr_gemm_aux_bits_supported(const vmr_gemm_t* gp) {
+  if (!gp) return 0;
+  if (g_gemm_dma < 0) {
+    const char* e = getenv("VMR_GEMM_DMA");
+    g_gemm_dma = e ? atoi(e) : 2;
+  }
+  return gemm_perm_direct(*gp) ? 1 : 0;
 }
 
 extern "C" int vmr_debug_set_gemm_p8(int mode) {

@@ -209,6 +209,7 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
 
 
 MERGE_DX_DW = os.environ.get("VMR_MERGE_DX_DW", "1") != "0"
+AUX_BITS = os.environ.get("VMR_AUX_BITS", "1") != "0"      # ReLU / dropout masks of the conv-block products as bit matrices
 GROUP_DW = os.environ.get("VMR_GROUP_DW", "1") != "0"      # one weight-gradient product per grouped projection
 DEFER_SPLITK_REDUCE = os.environ.get("VMR_DEFER_SPLITK_REDUCE", "1") != "0"
 
@@ -458,9 +459,25 @@ class _Linear(torch.autograd.Function):
             assert residual.is_contiguous() and residual.shape[1] == N and residual.shape[0] * res_div == M
             flags |= L.EPI_RESIDUAL | (L.EPI_RES_PRE if res_pre else 0)
         res_pre = bool(res_pre and residual is not None)
+        aux_bits = False
         if relu and (residual is not None) and not res_pre and any(t.requires_grad for t in (x, *weights)):
-            aux = torch.empty_like(y)   # post-dropout ReLU output: the backward's mask
-            flags |= L.EPI_AUX
+            # the backward's ReLU / dropout mask: one BIT per element where the GEMM runs on a register-direct
+            # epilogue (the conv-block products: 1.2 MB instead of a 19 MB bf16 copy of the activation at cfg2),
+            # otherwise the post-dropout ReLU output itself
+            probe = L.GemmDesc()
+            probe.A, probe.B, probe.C = x.data_ptr(), W.data_ptr(), ybuf.data_ptr()
+            probe.bias, probe.bias2, probe.residual = _ptr(bias), _ptr(bias2), _ptr(residual)
+            probe.lda, probe.ldb, probe.ldc, probe.ldr = x.stride(0), W.stride(0), Np, N
+            probe.M, probe.N, probe.K, probe.transA, probe.transB = M, N, Kp, 0, 0
+            probe.dtype, probe.flags, probe.Z1, probe.Z2, probe.splitk = dt, flags, 1, 1, 1
+            aux_bits = AUX_BITS and Np == N and rowscale is None and res_div == 1 and \
+                bool(L.lib().vmr_gemm_aux_bits_supported(C.byref(probe)))
+            if aux_bits:
+                aux = torch.empty(M, N // 8, device=x.device, dtype=torch.uint8)
+                flags |= L.EPI_AUX | L.EPI_AUX_BITS
+            else:
+                aux = torch.empty_like(y)
+                flags |= L.EPI_AUX
         if rowscale is not None:
             flags |= L.EPI_ROWSCALE
         few = None
@@ -479,6 +496,7 @@ class _Linear(torch.autograd.Function):
         ctx.bias_param = bias
         ctx.bias2_param, ctx.bias_scale = bias2, bias_scale
         ctx.kslice, ctx.res_div, ctx.res_pre = kslice, res_div, res_pre
+        ctx.aux_bits = aux_bits
         assert res_div == 1 or aux is None
         assert not (res_pre and rowscale is not None)
         assert bias2 is None or (bias is not None and Np == N)
@@ -519,7 +537,7 @@ class _Linear(torch.autograd.Function):
         dbs = ctx.bias_scale if bgrad is not None else 1.0   # (autograd path: scaled below)
         if relu:
             dzb = torch.empty_like(dyb)
-            L.check(lib.vmr_relu_bwd_bias(1, dyb.data_ptr(), h.data_ptr(), dzb.data_ptr(), _ptr(db), M, Np, Np, scale,
+            L.check(lib.vmr_relu_bwd_bias(3 if ctx.aux_bits else 1, dyb.data_ptr(), h.data_ptr(), dzb.data_ptr(), _ptr(db), M, Np, Np, scale,
                                           dt, 0.0, 0, None, _ptr(db2), dbs, st), "vmr_relu_bwd_bias")
         elif drop[0] > 0:
             dzb = torch.empty_like(dyb)
