@@ -585,7 +585,12 @@ extern "C" int vmr_layernorm_bwd_deferred(const void* dy, const void* x, const f
 // -> 4 workgroups / CU, 13 tiles per 128-frame clip; the extra halo re-reads are L2 hits, the
 // parallelism hides the row latency
 static void dwconv_tiling(int S, int D, size_t esz, int& R, int& tiles) {
-  const int nrows = (int)min((size_t)16, (size_t)(128 * 1024) / ((size_t)D * esz));
+  static int cap = -1;
+  if (cap < 0) {
+    const char* e = getenv("VMR_DWCONV_ROWS");   // LDS tile rows (output rows + 6 halo rows); measured best: see DESIGN
+    cap = e ? atoi(e) : 16;
+  }
+  const int nrows = (int)min((size_t)cap, (size_t)(128 * 1024) / ((size_t)D * esz));
   if (S <= 0 || nrows < 7) { R = 0; tiles = 0; return; }
   R = min(nrows - 6, S);
   tiles = cdiv(S, R);
