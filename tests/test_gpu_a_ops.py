@@ -576,6 +576,11 @@ def test_gumbel_softmax_and_match_loss(dev):
     # in-kernel noise: Gumbel(0,1) has mean 0.5772 and variance pi^2/6; draws differ per seed / step
     z = torch.zeros(200000, 1, device=dev)
     tau = 1.0
+    # the in-kernel uniform must stay strictly inside (0, 1): over 2^26 draws a 24-bit construction hits U = 1.0
+    # (g = +inf, NaN probabilities) about four times -- a 200-step BaseFast run did at its replay 32
+    big, _ = ops.gumbel_softmax(torch.zeros(1 << 24, 4, device=dev), None, tau, 12345, None, 8, torch.bfloat16)
+    assert bool(torch.isfinite(big).all())
+    del big
     p1, _ = ops.gumbel_softmax(torch.zeros(50000, 4, device=dev), None, tau, 7, None, 8, torch.bfloat16)
     p2, _ = ops.gumbel_softmax(torch.zeros(50000, 4, device=dev), None, tau, 8, None, 8, torch.bfloat16)
     assert not torch.equal(p1, p2)

@@ -25,9 +25,11 @@ __global__ __launch_bounds__(256) void gumbel_softmax_fwd_kernel(const float* __
       if (c < C) {
         float g;
         if (noise) g = noise[r * C + c];
-        else {   // g = -log(E), E ~ Exp(1) = -log(U): one 32-bit hash per element, U in (0,1)
+        else {   // g = -log(E), E ~ Exp(1) = -log(U): one 32-bit hash per element, U strictly inside (0,1).
+          // 23 bits + 0.5 is exact in fp32 (U <= 1 - 2^-24); with 24 bits the top value rounded to U = 1.0, g = +inf,
+          // and one element in 2^24 turned the whole step into NaNs (seen at replay 32 of a 200-step BaseFast run).
           const uint2 h = vmr_hash4(seed, (uint64_t)r * C + c);
-          const float u = ((float)(h.x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+          const float u = ((float)(h.x >> 9) + 0.5f) * (1.0f / 8388608.0f);
           g = -__logf(-__logf(u));
         }
         v[c] = (logits[r * C + c] + g) * inv_tau;

@@ -279,10 +279,22 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   float s = 0.f;
   const int64_t n4 = n >> 2;
   const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+  // four independent 16-byte loads in flight per thread (a single dependent load per iteration ran at 3.8 TB/s)
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const f32x4 v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];
+    s += v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] + v0[3] * v0[3];
+    s1 += v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2] + v1[3] * v1[3];
+    s2 += v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2] + v2[3] * v2[3];
+    s3 += v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2] + v3[3] * v3[3];
+  }
+  for (; i < n4; i += stride) {
     const f32x4 v = g4[i];
     s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
   }
+  s += s1 + s2 + s3;
   if (blockIdx.x == 0)
     for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
   s = wave_sum(s);
