@@ -293,6 +293,10 @@ int vmr_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t r
 int vmr_relu_bwd_bias(int mode, const void* dy, const void* h, void* dz, float* db, int64_t rows,
                       int D, int64_t ld, float scale, int dtype, float drop_p, uint32_t drop_seed,
                       const uint32_t* drop_step, float* db2, float db_scale, void* stream);
+/* The positional add of FeatureEncoderPredict (layers.py:626-631): y[r,:] = x[r,:] + pos[r % S,:], pos = the fp32
+ * table (rows >= S); bwd: dpos[s,:] += sum_b dy[b*S+s,:] (ACCUMULATED; dx = dy needs no kernel). */
+int vmr_add_pos_fwd(const void* x, const float* pos, void* y, int64_t rows, int S, int D, int dtype, void* stream);
+int vmr_add_pos_bwd(const void* dy, float* dpos, int64_t rows, int S, int D, int dtype, void* stream);
 /* WordEmbedding.forward (layers.py:28-48) without the per-call table concat: out[i, 0:wd] = drop(row(ids[i])) in
  * `dtype`, row(0) = pad_vec, row(1) = unk_vec, row(k>=2) = glove_vec[k-2] (fp32 [1,wd], [1,wd], [nglove,wd]); out is
  * the [n, ldo] matrix that feeds query_conv1d; columns [zero_from, zero_to) are zero-filled (K padding), the columns

@@ -934,3 +934,23 @@ def test_embedding_gather_scatter(dev):
     (b,) = torch.autograd.grad(ref, table, g)
     _close(a, b, 1e-5, "embedding grad")
     assert float(a[0].abs().max()) == 0.0       # padding_idx row gets no gradient
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_add_pos_matches_torch(dev, dt):
+    """ops.add_pos (FeatureEncoderPredict's positional add, reference layers.py:626-631): forward against torch on the
+    fp32 table, backward = the incoming gradient for x and its per-position batch sum for the table."""
+    ops = _ops()
+    B, S, D = 5, 12, 64
+    torch.manual_seed(3)
+    x = torch.randn(B * S, D, device=dev).to(dt).requires_grad_(True)
+    pos = torch.randn(16, D, device=dev, requires_grad=True)
+    y = ops.add_pos(x, pos, S)
+    ref = (x.detach().float().view(B, S, D) + pos.detach()[:S].view(1, S, D)).reshape(B * S, D)
+    assert torch.equal(y, ref.to(dt))
+    g = torch.randn(B * S, D, device=dev).to(dt)
+    y.backward(g)
+    assert torch.equal(x.grad, g)
+    want = torch.zeros_like(pos)
+    want[:S] = g.float().view(B, S, D).sum(0)
+    assert torch.allclose(pos.grad, want, rtol=1e-5, atol=1e-5)

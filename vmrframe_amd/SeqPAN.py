@@ -427,8 +427,7 @@ class SeqPAN(nn.Module):
         """FeatureEncoderPredict.forward (reference layers.py:626-639)."""
         fe = "predictor.feature_encoder"
         D, c = self.dim, self._cache
-        pos = ops.to_dtype(self.P(fe + ".pos_embedding.position_embeddings.weight")[:T], x.dtype)
-        feat = (x.view(B, T, D) + pos[:T].view(1, T, D)).reshape(B * T, D)
+        feat = ops.add_pos(x, self.P(fe + ".pos_embedding.position_embeddings.weight"), T)
         feat = self._conv_block(feat, fe + ".conv_block", [(B, T)], dc)
         o, feat = self._ln(feat, fe + ".layer_norm_1", 1e-5, drop=dc.next(tag + ".ln1"), tee=True)
         att = fe + ".top_self_attention.selfattn"

@@ -127,6 +127,8 @@ SIGNATURES = {
     "vmr_map2d_pool_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "vmr_map2d_scatter": [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     "vmr_sumsq": [_P, _P, _L, _P],
+    "vmr_add_pos_fwd": [_P, _P, _P, _L, _I, _I, _I, _P],
+    "vmr_add_pos_bwd": [_P, _P, _L, _I, _I, _I, _P],
     "vmr_debug_poison_lds": [_U, _P, _P],
     "vmr_debug_set_gemm_p8": [_I],
     "vmr_gemm_aux_bits_supported": [_P],

@@ -259,6 +259,25 @@ __global__ __launch_bounds__(256) void dpos_kernel(const T* __restrict__ dy, flo
   }
 }
 
+// y[r, :] = x[r, :] + pos[r % S, :]  (the positional add of FeatureEncoderPredict, reference layers.py:626-631): pos is the
+// fp32 table itself -- no compute-dtype copy of it, no broadcast add in the framework
+template <typename T>
+__global__ __launch_bounds__(256) void add_pos_kernel(const T* __restrict__ x, const float* __restrict__ pos, T* __restrict__ y,
+                                                      int64_t rows, int S, int D) {
+  const int cpr = D / 8;
+  const int64_t total = rows * cpr;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / cpr;
+    const int c = (int)(idx - r * cpr) * 8;
+    float v[8], p[8];
+    Vec8<T>::load(x + r * D + c, v);
+    Vec8<float>::load(pos + (int64_t)(r % S) * D + c, p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += p[e];
+    Vec8<T>::store(y + r * D + c, v);
+  }
+}
+
 // out[j] += sum_b part[b][j]   (j < n): second stage of the column reductions.  blockIdx.y takes
 // 16 partial rows (16 independent loads in flight per thread), so only nblocks/16 adders meet on
 // an address.
@@ -737,4 +756,32 @@ extern "C" int vmr_dwconv_bwd(const void* du, const void* x, const float* gamma,
                               const float* mean, const float* rstd, const float* w, void* dn, float* dw,
                               float* workspace, int B, int S, int D, int dtype, void* stream) {
   return vmr_dwconv_bwd2(du, x, gamma, beta, mean, rstd, w, dn, dw, workspace, B, S, 0, 0, D, dtype, stream);
+}
+
+
+extern "C" int vmr_add_pos_fwd(const void* x, const float* pos, void* y, int64_t rows, int S, int D, int dtype, void* stream) {
+  VMR_CHECK(x && pos && y, "vmr_add_pos_fwd: null pointer");
+  VMR_CHECK(S > 0 && D % 8 == 0 && rows >= 0, "vmr_add_pos_fwd: need S > 0 and D %% 8 == 0");
+  if (rows == 0) return 0;
+  const unsigned grid = (unsigned)min((int64_t)4096, (rows * (D / 8) + 255) / 256);
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(add_pos_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, pos, (bf16_t*)y, rows, S, D);
+  else
+    hipLaunchKernelGGL(add_pos_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, pos, (float*)y, rows, S, D);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+// dpos[s, :] += sum_b dy[b*S + s, :]  (ACCUMULATES: dpos may be the table's slot in the gradient arena)
+extern "C" int vmr_add_pos_bwd(const void* dy, float* dpos, int64_t rows, int S, int D, int dtype, void* stream) {
+  VMR_CHECK(dy && dpos, "vmr_add_pos_bwd: null pointer");
+  VMR_CHECK(S > 0 && D % 8 == 0 && rows >= 0, "vmr_add_pos_bwd: need S > 0 and D %% 8 == 0");
+  if (rows == 0) return 0;
+  const dim3 gp((unsigned)min((int64_t)1024, ((int64_t)S * (D / 8) + 255) / 256));
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(dpos_kernel<bf16_t>, gp, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dpos, rows, S, D, 0.f, 0u, nullptr);
+  else
+    hipLaunchKernelGGL(dpos_kernel<float>, gp, dim3(256), 0, (hipStream_t)stream, (const float*)dy, dpos, rows, S, D, 0.f, 0u, nullptr);
+  VMR_LAUNCH_CHECK();
+  return 0;
 }

@@ -1055,6 +1055,7 @@ class _LayerNorm(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.meta = (drop, S, None if pos is None else tuple(pos.shape))
         ctx.params = (gamma, beta)
+        ctx.pos_param = pos
         ctx.state = cache.state
         if tee:
             return y, x.view_as(x)
@@ -1072,7 +1073,11 @@ class _LayerNorm(torch.autograd.Function):
         direct = mg is not None and mb is not None
         dg = mg if direct else torch.zeros(D, device=x.device, dtype=torch.float32)
         db = mb if direct else torch.zeros_like(dg)
-        dpos = torch.zeros(pshape, device=x.device, dtype=torch.float32) if pshape else None
+        # (the positional-table gradient accumulates in place in the arena when there is one: no zero-fill, no add pass)
+        mp = main_grad(ctx.pos_param) if pshape else None
+        pos_direct = mp is not None and mp.is_contiguous() and tuple(mp.shape) == tuple(pshape)
+        dpos = (mp if pos_direct else torch.zeros(pshape, device=x.device, dtype=torch.float32)) if pshape else None
+        dpos_ret = None if pos_direct else dpos
         ws = torch.empty(L.ln_bwd_ws_floats(rows, D), device=x.device, dtype=torch.float32)
         if direct and DEFER_COLREDUCE:
             # gradients accumulate into the arena: leave the partial rows in ws, reduce them with every other
@@ -1083,13 +1088,46 @@ class _LayerNorm(torch.autograd.Function):
                                                        S, rows, D, L.dtype_code(x), drop[0], drop[1], _ptr(drop[2]),
                                                        C.byref(nb), L.stream_ptr()), "vmr_layernorm_bwd_deferred")
             ctx.state.defer_colreduce(ws, dg, db, nb.value, D, D, 512 if D <= 512 else (1024 if D <= 1024 else 2048))
-            return dx, None, None, None, dpos, None, None, None, None
+            return dx, None, None, None, dpos_ret, None, None, None, None
         L.check(L.lib().vmr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                           rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                           _ptr(dpos), ws.data_ptr(), S, rows, D, L.dtype_code(x), drop[0], drop[1],
                                           _ptr(drop[2]),
                                           L.stream_ptr()), "vmr_layernorm_bwd")
-        return dx, (None if direct else dg), (None if direct else db), None, dpos, None, None, None, None
+        return dx, (None if direct else dg), (None if direct else db), None, dpos_ret, None, None, None, None
+
+
+class _AddPos(torch.autograd.Function):
+    """y = x + pos[row % S] (FeatureEncoderPredict's positional add, reference layers.py:626-631) on the fp32 table
+    itself; backward: dx = dy unchanged, the table gradient accumulates in place in the arena when there is one."""
+
+    @staticmethod
+    def forward(ctx, x, pos, S):
+        L.require_gpu(x, pos)
+        x = x.contiguous()
+        rows, D = x.shape
+        assert pos.dim() == 2 and pos.shape[1] == D and pos.shape[0] >= S and pos.is_contiguous() and pos.dtype == torch.float32
+        y = torch.empty_like(x)
+        L.check(L.lib().vmr_add_pos_fwd(x.data_ptr(), pos.data_ptr(), y.data_ptr(), rows, S, D, L.dtype_code(x), L.stream_ptr()),
+                "vmr_add_pos_fwd")
+        ctx.pos_param, ctx.S = pos, S
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        pos, S = ctx.pos_param, ctx.S
+        dy = dy.contiguous()
+        rows, D = dy.shape
+        mp = main_grad(pos)
+        direct = mp is not None and mp.is_contiguous() and tuple(mp.shape) == tuple(pos.shape)
+        dpos = mp if direct else torch.zeros(pos.shape, device=dy.device, dtype=torch.float32)
+        L.check(L.lib().vmr_add_pos_bwd(dy.data_ptr(), dpos.data_ptr(), rows, S, D, L.dtype_code(dy), L.stream_ptr()),
+                "vmr_add_pos_bwd")
+        return dy, (None if direct else dpos), None
+
+
+def add_pos(x, pos, S):
+    return _AddPos.apply(x, pos, S)
 
 
 def layer_norm(x, gamma, beta, eps, cache, *, pos=None, S=0, drop=NO_DROP, tee=False):
