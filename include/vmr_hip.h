@@ -406,7 +406,7 @@ int vmr_iou_metrics(const float* props, const float* gts, float* ious, double* a
  *      are ACCUMULATED (two-stage through `workspace`, VMR_NARROW_WS_FLOATS(M,N,K) fp32, caller-owned
  *      scratch).  K %% 8 == 0, K <= 2048. */
 #define VMR_NARROW_WS_FLOATS(M, N, K) \
-  ((((int64_t)(M) + 127) / 128) * ((K) >= 2048 ? 1 : 256 / ((K) / 8)) * ((int64_t)(N) * (K) + (N)))
+  ((((int64_t)(M) + 31) / 32) * ((K) >= 2048 ? 1 : 256 / ((K) / 8)) * ((int64_t)(N) * (K) + (N)))
 int vmr_narrow_linear_fwd(const void* x, const float* W, const float* bias, float* y, int64_t M, int N,
                           int K, int64_t ldx, int dtype, void* stream);
 int vmr_narrow_linear_bwd(const float* dy, const void* x, const float* W, void* dx, float* dW, float* db,

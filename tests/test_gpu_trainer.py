@@ -158,8 +158,12 @@ def test_graph_replay_equals_eager_steps(dev):
             dB = (optB.arena.flat_p[o:o + k] - before[o:o + k]).double()[keep]
             e2, d2 = float((dA - dB).pow(2).sum()), float(dB.pow(2).sum())
             num, den = num + e2, den + d2
-            worst = max(worst, (e2 / d2) ** 0.5)
-            assert (e2 / d2) ** 0.5 < 0.10, (it, n, (e2 / d2) ** 0.5)
+            # per tensor: relative to its update, but never to less than a fifth of a full Adam step (lr per element):
+            # a tensor whose first moment is crossing zero moves by ~0 and any summation noise is "50 %" of that
+            lr_now = 1e-3 * (10 - (2 + it)) / 10
+            d2f = max(d2, (0.2 * lr_now) ** 2 * int(keep.sum()))
+            worst = max(worst, (e2 / d2f) ** 0.5)
+            assert (e2 / d2f) ** 0.5 < 0.10, (it, n, (e2 / d2f) ** 0.5, (e2 / d2) ** 0.5)
         total = max(total, (num / den) ** 0.5)
         # the forward's few-tile split-K products add fp32 partials with float atomics: their order flips last bits of
         # bf16 activations, which reaches single small tensors at the 1e-2 level (measured: worst 3.6e-2); the update
@@ -280,7 +284,10 @@ def test_load_state_dict_after_arena_build_refreshes_bf16_mirrors(dev):
     gm = arena_grads(opt, m)
     for n, p in fresh.named_parameters():
         if p.grad is not None and float(p.grad.norm()) > 1e-3 * float(opt.arena.flat_g.norm()):
-            assert rel(gm[n].cpu(), p.grad.cpu()) < 5e-2, n
+            # (arena path -- K-major copies, merged launches, direct accumulation -- against the plain autograd path of a
+            #  fresh model: other summation orders on bf16 activations, measured up to 7e-2 on [D,1] tensors; two fresh
+            #  models differ by up to 2e-2; stale copies of weights that moved 20x their norm give O(1))
+            assert rel(gm[n].cpu(), p.grad.cpu()) < 0.15, n
     # in-place edits under no_grad are noticed too (version counters; raw `p.data` edits need opt.sync_mirrors()):
     # with start_hidden's weight zeroed both of its K-slices vanish, so every start logit is the same constant
     with torch.no_grad():

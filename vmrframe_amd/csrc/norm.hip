@@ -225,17 +225,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 // this replaced one float atomic PER ELEMENT inside ln_bwd (8.4 M atomics, 64 per address: 242 us at cfg2).
 template <typename T>
 __global__ __launch_bounds__(256) void dpos_kernel(const T* __restrict__ dy, float* __restrict__ dpos, int64_t rows, int S, int D,
-                                                   float drop_p, uint32_t seed0, const uint32_t* __restrict__ step) {
+                                                   float drop_p, uint32_t seed0, const uint32_t* __restrict__ step, int nsplit) {
   const uint32_t seed = vmr_seed(seed0, step);
   const uint32_t thresh = vmr_drop_thresh(drop_p);
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int cpr = D / 8;
   const int64_t total = (int64_t)S * cpr;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+  // nsplit threads share one (s, 8 channels) column: thread sp walks batch-row groups sp, sp + nsplit, ... of 8 rows each
+  // and the partial sums meet through float atomics (nsplit per address).  One thread per column was a chain of
+  // batch/8 dependent HBM round trips: 16 us for a 17 MB operand at B = 64.
+  for (int64_t idx2 = (int64_t)blockIdx.x * 256 + threadIdx.x; idx2 < total * nsplit; idx2 += (int64_t)gridDim.x * 256) {
+    const int sp = (int)(idx2 / total);
+    const int64_t idx = idx2 - (int64_t)sp * total;
     const int s = (int)(idx / cpr), c = (int)(idx - (int64_t)s * cpr) * 8;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     typedef __attribute__((ext_vector_type(8))) T TV8;
-    for (int64_t row0 = s; row0 < rows; row0 += (int64_t)8 * S) {   // 8 batch rows in flight (the walk is latency-bound)
+    for (int64_t row0 = s + (int64_t)sp * 8 * S; row0 < rows; row0 += (int64_t)nsplit * 8 * S) {   // 8 batch rows in flight
       TV8 g8[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) g8[u] = *reinterpret_cast<const TV8*>(dy + min(row0 + (int64_t)u * S, rows - 1) * D + c);
@@ -251,12 +256,21 @@ __global__ __launch_bounds__(256) void dpos_kernel(const T* __restrict__ dy, flo
         }
       }
     }
-    float old[8];
-    Vec8<float>::load(dpos + (int64_t)s * D + c, old);
+    if (nsplit > 1) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) old[e] += acc[e];
-    Vec8<float>::store(dpos + (int64_t)s * D + c, old);
+      for (int e = 0; e < 8; ++e) atomicAdd(dpos + (int64_t)s * D + c + e, acc[e]);
+    } else {
+      float old[8];
+      Vec8<float>::load(dpos + (int64_t)s * D + c, old);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) old[e] += acc[e];
+      Vec8<float>::store(dpos + (int64_t)s * D + c, old);
+    }
   }
+}
+static inline int dpos_split(int64_t rows, int S) {   // one round of 8 rows per thread where the batch allows, at most 8 ways
+  const int64_t groups = (rows / S + 7) / 8;
+  return (int)(groups < 1 ? 1 : (groups > 8 ? 8 : groups));
 }
 
 // y[r, :] = x[r, :] + pos[r % S, :]  (the positional add of FeatureEncoderPredict, reference layers.py:626-631): pos is the
@@ -566,13 +580,14 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
   VMR_LAUNCH_CHECK();
   if (dpos) {
     VMR_CHECK(S > 0 && D % 8 == 0, "vmr_layernorm_bwd: dpos needs S > 0");
-    const dim3 gp((unsigned)min((int64_t)4096, ((int64_t)S * (D / 8) + 255) / 256));
+    const int nsp = dpos_split(rows, S);
+    const dim3 gp((unsigned)min((int64_t)4096, ((int64_t)S * (D / 8) * nsp + 255) / 256));
     if (dtype == VMR_BF16)
       hipLaunchKernelGGL(dpos_kernel<bf16_t>, gp, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dpos, rows, S, D, drop_p,
-                         drop_seed, drop_step);
+                         drop_seed, drop_step, nsp);
     else
       hipLaunchKernelGGL(dpos_kernel<float>, gp, dim3(256), 0, (hipStream_t)stream, (const float*)dy, dpos, rows, S, D, drop_p,
-                         drop_seed, drop_step);
+                         drop_seed, drop_step, nsp);
     VMR_LAUNCH_CHECK();
   }
   if (part && !defer) {
@@ -777,11 +792,12 @@ extern "C" int vmr_add_pos_bwd(const void* dy, float* dpos, int64_t rows, int S,
   VMR_CHECK(dy && dpos, "vmr_add_pos_bwd: null pointer");
   VMR_CHECK(S > 0 && D % 8 == 0 && rows >= 0, "vmr_add_pos_bwd: need S > 0 and D %% 8 == 0");
   if (rows == 0) return 0;
-  const dim3 gp((unsigned)min((int64_t)1024, ((int64_t)S * (D / 8) + 255) / 256));
+  const int nsp = dpos_split(rows, S);
+  const dim3 gp((unsigned)min((int64_t)4096, ((int64_t)S * (D / 8) * nsp + 255) / 256));
   if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(dpos_kernel<bf16_t>, gp, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dpos, rows, S, D, 0.f, 0u, nullptr);
+    hipLaunchKernelGGL(dpos_kernel<bf16_t>, gp, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dpos, rows, S, D, 0.f, 0u, nullptr, nsp);
   else
-    hipLaunchKernelGGL(dpos_kernel<float>, gp, dim3(256), 0, (hipStream_t)stream, (const float*)dy, dpos, rows, S, D, 0.f, 0u, nullptr);
+    hipLaunchKernelGGL(dpos_kernel<float>, gp, dim3(256), 0, (hipStream_t)stream, (const float*)dy, dpos, rows, S, D, 0.f, 0u, nullptr, nsp);
   VMR_LAUNCH_CHECK();
   return 0;
 }

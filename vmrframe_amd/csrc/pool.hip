@@ -422,7 +422,7 @@ int launch_narrow_fwd(int N, dim3 grid, size_t lds, hipStream_t st, const void* 
   return 0;
 }
 
-constexpr int NL_RPB = 128;   // rows per workgroup of the dW reduction
+constexpr int NL_RPB = 32;    // rows per workgroup of the dW reduction (128 left 64-74 workgroups on 256 CUs, each thread a chain of 8 dependent row fetches: 15 us)
 template <typename T>
 int launch_narrow_bwd(int N, hipStream_t st, const float* dy, const void* x, const float* W, void* dx, float* dW, float* db,
                       float* ws, int64_t M, int K, int64_t ldx) {

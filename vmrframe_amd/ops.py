@@ -744,7 +744,7 @@ class _NarrowLinear(torch.autograd.Function):
         if bias is not None:
             db = gb if gb is not None else torch.zeros(N, device=x.device, dtype=torch.float32)
         groups = max(1, 256 // (K // 8))
-        ws = torch.empty(_cdiv(M, 128) * groups * (N * K + N), device=x.device, dtype=torch.float32)
+        ws = torch.empty(_cdiv(M, 32) * groups * (N * K + N), device=x.device, dtype=torch.float32)   # VMR_NARROW_WS_FLOATS
         L.check(L.lib().vmr_narrow_linear_bwd(dy.data_ptr(), x.data_ptr(), W.detach().reshape(N, -1).data_ptr(), _ptr(dx),
                                               dW.data_ptr(), _ptr(db), ws.data_ptr(), M, N, K, x.stride(0),
                                               L.dtype_code(x), L.stream_ptr()), "vmr_narrow_linear_bwd")
