@@ -411,6 +411,14 @@ int vmr_narrow_linear_fwd(const void* x, const float* W, const float* bias, floa
                           int K, int64_t ldx, int dtype, void* stream);
 int vmr_narrow_linear_bwd(const float* dy, const void* x, const float* W, void* dx, float* dW, float* db,
                           float* workspace, int64_t M, int N, int K, int64_t ldx, int dtype, void* stream);
+/* The label-embedding fuse of the match head (models/SeqPAN.py:80-82): y = (res + p . E^T) * rowscale with p fp32 [M,N]
+ * (the Gumbel-softmax probabilities, N = 4), E = label_embs fp32 [K,N], res / y [M,K] dtype, rowscale fp32 [M] or NULL.
+ * bwd: dres = dy * rowscale (dtype [M,K]), dp[m,n] = dres[m,:] . E[:,n] (fp32 [M,N]), dE[k,n] += sum_m p[m,n] dres[m,k]
+ * (ACCUMULATED, fp32 [K,N]); workspace: VMR_NARROW_WS_FLOATS(M, N, K) floats. */
+int vmr_label_fuse_fwd(const float* p, const float* E, const void* res, const float* rowscale, void* y, int64_t M, int N,
+                       int K, int dtype, void* stream);
+int vmr_label_fuse_bwd(const void* dy, const float* p, const float* E, const float* rowscale, void* dres, float* dp,
+                       float* dE, float* workspace, int64_t M, int N, int K, int dtype, void* stream);
 
 /* ------------------------------------------------- match head + its loss
  * vmr_gumbel_softmax_fwd/bwd: F.gumbel_softmax(logits, tau) of models/SeqPAN.py:79 over C <= 8 classes:

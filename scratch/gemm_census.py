@@ -26,7 +26,6 @@ def main():
     model = V.SeqPAN(cfg, glove).to(dev)
     model.sync_timing = False
     opt = FlatAdamW(model, lr=1e-4, weight_decay=0.01, max_norm=1.0, warmup_steps=0.0, total_steps=100)
-    reducer = dp.GradReducer(model, opt, use_hooks=True)
     batch = {k: v.to(dev) for k, v in Bn.synth(a, 1234).items()}
     model.train()
 
@@ -34,7 +33,6 @@ def main():
         loss, out = V.train_engine_SeqPAN(model, batch, cfg, "train")
         opt.zero_grad()
         loss.backward()
-        reducer.finish()
         opt.step()
 
     for _ in range(3):

@@ -954,3 +954,27 @@ def test_add_pos_matches_torch(dev, dt):
     want = torch.zeros_like(pos)
     want[:S] = g.float().view(B, S, D).sum(0)
     assert torch.allclose(pos.grad, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_label_fuse_matches_torch(dev, dt):
+    """ops.label_fuse: (fuse + match_score . label_embs^T) * vmask (reference models/SeqPAN.py:80-82), forward and the
+    three gradients (residual, probabilities, label embeddings) against torch fp32."""
+    ops = _ops()
+    M, K, N = 200, 256, 4
+    torch.manual_seed(11)
+    res = torch.randn(M, K, device=dev).to(dt).requires_grad_(True)
+    p = torch.softmax(torch.randn(M, N, device=dev), -1).requires_grad_(True)
+    E = torch.randn(K, N, device=dev, requires_grad=True)
+    rs = (torch.rand(M, device=dev) > 0.3).float()
+    y = ops.label_fuse(res, p, E, rs)
+    r32, p32, E32 = res.detach().float().requires_grad_(True), p.detach().clone().requires_grad_(True), E.detach().clone().requires_grad_(True)
+    ref = (r32 + p32 @ E32.t()) * rs[:, None]
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    _close(y.float(), ref, tol, "label_fuse fwd")
+    g = torch.randn(M, K, device=dev).to(dt)
+    y.backward(g)
+    ref.backward(g.float())
+    _close(res.grad.float(), r32.grad, tol, "dres")
+    _close(p.grad, p32.grad, tol, "dprobs")
+    _close(E.grad, E32.grad, tol, "dlabel_embs")

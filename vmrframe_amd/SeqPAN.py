@@ -492,9 +492,8 @@ class SeqPAN(nn.Module):
         # Gumbel-softmax (tau 0.3) + the K-padded compute-dtype copy in one kernel
         ms_probs, ms = ops.gumbel_softmax(mlogits, noise, 0.3, gseed, gstep, 8, cdt)
         match_score = self._cut(ms_probs.view(B, T, 4), 3)     # (read by lossfun_match only)
-        # fuse2 = (fuse + match_score . label_embs^T) * vmask : one GEMM epilogue
-        fuse2 = ops.linear(ms, self.P("label_embs"), None, self._cache, residual=fuse,
-                           rowscale=vmask.reshape(-1))
+        # fuse2 = (fuse + match_score . label_embs^T) * vmask : a rank-4 update of the streamed matrix (ops.label_fuse)
+        fuse2 = ops.label_fuse(fuse, ms_probs, self.P("label_embs"), vmask.reshape(-1))
         # predictor (reference layers.py:659-671)
         # start/end_hidden(cat[features, fuse2]) as two K=D GEMMs on column slices of the weight (the second
         # accumulates through the residual input): no [Nv, 2D] concat copies.  The fuse2 halves come first so that

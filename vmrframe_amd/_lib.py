@@ -128,6 +128,8 @@ SIGNATURES = {
     "vmr_map2d_scatter": [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     "vmr_sumsq": [_P, _P, _L, _P],
     "vmr_add_pos_fwd": [_P, _P, _P, _L, _I, _I, _I, _P],
+    "vmr_label_fuse_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "vmr_label_fuse_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "vmr_add_pos_bwd": [_P, _P, _L, _I, _I, _I, _P],
     "vmr_debug_poison_lds": [_U, _P, _P],
     "vmr_debug_set_gemm_p8": [_I],

@@ -283,6 +283,7 @@ extern "C" int vmr_weighted_pool_bwd(const void* dpooled, const void* x, const f
 namespace {
 
 constexpr int NL_MAXN = 8;
+template <typename T> __device__ __forceinline__ float round_through_t(float v) { return to_f<T>(from_f<T>(v)); }
 
 template <typename T, int N>
 __global__ __launch_bounds__(256) void narrow_fwd_kernel(const T* __restrict__ x, const float* __restrict__ W,
@@ -445,7 +446,141 @@ int launch_narrow_bwd(int N, hipStream_t st, const float* dy, const void* x, con
   return 0;
 }
 
+// ---- the label-embedding fuse of the match head (reference models/SeqPAN.py:80-82):
+//      y[m, :] = (res[m, :] + sum_n p[m, n] * E[:, n]) * rs[m],  E = label_embs fp32 [K][N] (N = 4 classes).
+// As a GEMM it was a K = 8 (zero-padded) product forward and N = 8 / K = 8 products backward on 128-wide MFMA tiles
+// (26 + 42 + 23 us); it is a rank-N update of a streamed matrix.
+template <typename T, int N>
+__global__ __launch_bounds__(256) void label_fuse_fwd_kernel(const float* __restrict__ p, const float* __restrict__ E,
+                                                             const T* __restrict__ res, const float* __restrict__ rs,
+                                                             T* __restrict__ y, int64_t M, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Ws = reinterpret_cast<float*>(smem);   // [N][K], transposed while staging
+  for (int i = threadIdx.x; i < N * K; i += 256) Ws[(i % N) * K + i / N] = E[i];
+  __syncthreads();
+  const int cpr = K / 8;
+  const int64_t total = M * cpr;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t m = idx / cpr;
+    const int c = (int)(idx - m * cpr) * 8;
+    float o[8];
+    Vec8<T>::load(res + m * K + c, o);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const float g = p[m * N + n];
+      float wv[8];
+      Vec8<float>::load(Ws + n * K + c, wv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += g * wv[e];
+    }
+    const float r = rs ? rs[m] : 1.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= r;
+    Vec8<T>::store(y + m * K + c, o);
+  }
+}
+
+// backward, first pass (one wave per row): dres[m, :] = dy[m, :] * rs[m]  and  dp[m, n] = dres[m, :] . E[:, n]
+template <typename T, int N>
+__global__ __launch_bounds__(256) void label_fuse_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ E,
+                                                             const float* __restrict__ rs, T* __restrict__ dres,
+                                                             float* __restrict__ dp, int64_t M, int K, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Ws = reinterpret_cast<float*>(smem);
+  for (int i = threadIdx.x; i < N * K; i += 256) Ws[(i % N) * K + i / N] = E[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  for (int64_t m = r0 + wid; m < min(M, r0 + rows_per_block); m += 4) {
+    float acc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = 0.f;
+    const float r = rs ? rs[m] : 1.f;
+    for (int i = lane * 8; i < K; i += 512) {
+      float xv[8];
+      Vec8<T>::load(dy + m * K + i, xv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] *= r;
+      Vec8<T>::store(dres + m * K + i, xv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = round_through_t<T>(xv[e]);   // (the second pass reads dres as stored)
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        float wv[8];
+        Vec8<float>::load(Ws + n * K + i, wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[n] += xv[e] * wv[e];
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = wave_sum(acc[n]);
+    if (lane == 0) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) dp[m * N + n] = acc[n];
+    }
+  }
+}
+
+// second stage of narrow_dw_kernel's partial rows into a K-major gradient: dE[k][n] += sum_r part[r][n*K + k]
+__global__ __launch_bounds__(256) void narrow_reduce_t_kernel(const float* __restrict__ part, float* __restrict__ dE, int nrows,
+                                                              int N, int K) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N * K) return;
+  const int r0 = blockIdx.y * 16;
+  float v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = (r0 + k < nrows) ? part[(int64_t)(r0 + k) * (N * K + N) + j] : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += v[k];
+  atomicAdd(&dE[(j % K) * N + j / K], s);
+}
+
 }  // namespace
+
+extern "C" int vmr_label_fuse_fwd(const float* p, const float* E, const void* res, const float* rowscale, void* y, int64_t M,
+                                  int N, int K, int dtype, void* stream) {
+  VMR_CHECK(p && E && res && y, "vmr_label_fuse_fwd: null pointer");
+  VMR_CHECK(N == 4 && K % 8 == 0 && K <= 2048, "vmr_label_fuse_fwd: N must be 4, K %% 8 == 0, K <= 2048 (N=%d K=%d)", N, K);
+  if (M == 0) return 0;
+  const dim3 grid((unsigned)min((int64_t)4096, (M * (K / 8) + 255) / 256));
+  const size_t lds = (size_t)N * K * 4;
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL((label_fuse_fwd_kernel<bf16_t, 4>), grid, dim3(256), lds, (hipStream_t)stream, p, E, (const bf16_t*)res,
+                       rowscale, (bf16_t*)y, M, K);
+  else
+    hipLaunchKernelGGL((label_fuse_fwd_kernel<float, 4>), grid, dim3(256), lds, (hipStream_t)stream, p, E, (const float*)res,
+                       rowscale, (float*)y, M, K);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_label_fuse_bwd(const void* dy, const float* p, const float* E, const float* rowscale, void* dres, float* dp,
+                                  float* dE, float* workspace, int64_t M, int N, int K, int dtype, void* stream) {
+  VMR_CHECK(dy && p && E && dres && dp && dE && workspace, "vmr_label_fuse_bwd: null pointer");
+  VMR_CHECK(N == 4 && K % 8 == 0 && K <= 2048, "vmr_label_fuse_bwd: N must be 4, K %% 8 == 0, K <= 2048 (N=%d K=%d)", N, K);
+  if (M == 0) return 0;
+  const int rpb = 32;
+  const dim3 g1((unsigned)((M + rpb - 1) / rpb));
+  const size_t lds = (size_t)N * K * 4;
+  const dim3 gw((unsigned)((M + NL_RPB - 1) / NL_RPB));
+  const int groups = max(1, 256 / (K / 8));
+  if (dtype == VMR_BF16) {
+    hipLaunchKernelGGL((label_fuse_bwd_kernel<bf16_t, 4>), g1, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, E, rowscale,
+                       (bf16_t*)dres, dp, M, K, rpb);
+    hipLaunchKernelGGL((narrow_dw_kernel<bf16_t, 4>), gw, dim3(256), 0, (hipStream_t)stream, p, (const bf16_t*)dres, workspace, M, K,
+                       (int64_t)K, NL_RPB);
+  } else {
+    hipLaunchKernelGGL((label_fuse_bwd_kernel<float, 4>), g1, dim3(256), lds, (hipStream_t)stream, (const float*)dy, E, rowscale,
+                       (float*)dres, dp, M, K, rpb);
+    hipLaunchKernelGGL((narrow_dw_kernel<float, 4>), gw, dim3(256), 0, (hipStream_t)stream, p, (const float*)dres, workspace, M, K,
+                       (int64_t)K, NL_RPB);
+  }
+  hipLaunchKernelGGL(narrow_reduce_t_kernel, dim3(cdiv(N * K, 256), cdiv((int)gw.x * groups, 16)), dim3(256), 0, (hipStream_t)stream,
+                     workspace, dE, (int)gw.x * groups, N, K);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int vmr_narrow_linear_fwd(const void* x, const float* W, const float* bias, float* y, int64_t M, int N, int K,
                                      int64_t ldx, int dtype, void* stream) {

@@ -235,9 +235,11 @@ def mm_few_tiles(a: torch.Tensor, b: torch.Tensor, ta: int, tb: int) -> Optional
     M, K = (a.shape[1], a.shape[0]) if ta else a.shape
     N = b.shape[1] if tb else b.shape[0]
     tiles = _cdiv(M, 128) * _cdiv(N, 128)
-    if a.dtype == torch.float32 or tiles >= 32 or K < 512:
+    if a.dtype == torch.float32 or tiles >= FEW_TILES or K < 512:
         return None
-    sk = max(2, min(8, K // 128))
+    # enough splits for ~320 workgroups, at least two 128-deep K-steps each (the text-side products: [1280,1024,4096]
+    # is 80 tiles x 64 K-steps as a plain launch -- 63 us on a third of the CUs)
+    sk = max(2, min(8, K // 256 if tiles >= 32 else K // 128, _cdiv(320, tiles)))
     acc = torch.zeros(M, N, device=a.device, dtype=torch.float32)
     gemm(a, b, acc, M, N, K, ta, tb, a.stride(0), b.stride(0), N, dtype=L.dtype_code(a), flags=L.EPI_ACCUM, splitk=sk)
     return acc
@@ -262,6 +264,7 @@ def bmm4(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, ta: int, tb: int, *,
 # gradient: two workgroups per CU); 384 when it shares its launch with the layer's single-round dX product (4 splits:
 # half the slab traffic, the dX workgroups fill the other slots: 9.35 -> 9.27 ms/step at cfg2, but 8.7 -> 9.5 ms for
 # BaseFast at T = 256, whose dX grids are multi-round and never merge)
+FEW_TILES = int(os.environ.get("VMR_FEW_TILES", "128"))     # products below this many 128x128 tiles split K over the idle CUs
 SPLITK_TARGET = int(os.environ.get("VMR_SPLITK_TARGET", "512"))
 SPLITK_TARGET_MERGED = int(os.environ.get("VMR_SPLITK_TARGET_MERGED", "384"))
 USE_SLABS = os.environ.get("VMR_SPLITK_SLABS", "1") != "0"
@@ -750,6 +753,47 @@ class _NarrowLinear(torch.autograd.Function):
                                               L.dtype_code(x), L.stream_ptr()), "vmr_narrow_linear_bwd")
         return (dx, None if gW is not None else dW.reshape(W.shape),
                 None if (bias is None or gb is not None) else db, None)
+
+
+class _LabelFuse(torch.autograd.Function):
+    """fuse2 = (fuse + match_score . label_embs^T) * vmask (reference models/SeqPAN.py:80-82) as a rank-4 update of the
+    streamed [tokens, D] matrix instead of K = 8 / N = 8 products on 128-wide MFMA tiles.  probs fp32 [M,4], E fp32 [D,4]."""
+
+    @staticmethod
+    def forward(ctx, res, probs, E, rowscale):
+        L.require_gpu(res, probs, E)
+        res, probs = res.contiguous(), probs.contiguous().float()
+        M, K = res.shape
+        N = probs.shape[1]
+        assert tuple(E.shape) == (K, N) and E.is_contiguous() and E.dtype == torch.float32
+        y = torch.empty_like(res)
+        L.check(L.lib().vmr_label_fuse_fwd(probs.data_ptr(), E.data_ptr(), res.data_ptr(), _ptr(rowscale), y.data_ptr(), M, N, K,
+                                           L.dtype_code(res), L.stream_ptr()), "vmr_label_fuse_fwd")
+        ctx.save_for_backward(probs, E, rowscale)
+        ctx.E_param = E
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        probs, E, rowscale = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = dy.shape
+        N = probs.shape[1]
+        dres = torch.empty_like(dy)
+        dp = torch.empty(M, N, device=dy.device, dtype=torch.float32)
+        gE = main_grad(ctx.E_param)
+        direct = gE is not None and gE.is_contiguous() and tuple(gE.shape) == (K, N)
+        dE = gE if direct else torch.zeros(K, N, device=dy.device, dtype=torch.float32)
+        groups = max(1, 256 // (K // 8))
+        ws = torch.empty(_cdiv(M, 32) * groups * (N * K + N), device=dy.device, dtype=torch.float32)   # VMR_NARROW_WS_FLOATS
+        L.check(L.lib().vmr_label_fuse_bwd(dy.data_ptr(), probs.data_ptr(), E.data_ptr(), _ptr(rowscale), dres.data_ptr(),
+                                           dp.data_ptr(), dE.data_ptr(), ws.data_ptr(), M, N, K, L.dtype_code(dy), L.stream_ptr()),
+                "vmr_label_fuse_bwd")
+        return dres, dp, (None if direct else dE), None
+
+
+def label_fuse(res, probs, E, rowscale=None):
+    return _LabelFuse.apply(res, probs, E, rowscale)
 
 
 def narrow_linear(x, W, bias, N=None):
