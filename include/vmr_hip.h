@@ -288,6 +288,8 @@ int vmr_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t r
  *  mode 2: dz = dy*scale*keep(seed, r*D+c), db += colsum(dz) (dropout without ReLU; the mask
  *          is regenerated from the seed the forward GEMM epilogue used)
  *  mode 3: as mode 1 with h the BIT matrix VMR_EPI_AUX_BITS wrote (uint8 [rows][D/8])
+ *  mode 4: dz = dy*scale*keep(seed, r*D+c) + h   (stand-alone dropout whose input has a second consumer: h = that
+ *          consumer's gradient, dtype [rows, ld]; the db sums are of the dropout term + h and normally unused)
  * db may be NULL in modes 1/2/3.  The column sums are ACCUMULATED: db += db_scale*colsum and, when
  * db2 is given, db2 += colsum (the two bias terms of vmr_gemm_t.bias/bias2; db_scale 0 reads as 1). */
 int vmr_relu_bwd_bias(int mode, const void* dy, const void* h, void* dz, float* db, int64_t rows,

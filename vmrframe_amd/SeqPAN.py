@@ -391,8 +391,14 @@ class SeqPAN(nn.Module):
         Lq = qry.shape[1]
         cdt = ctx.dtype
         w4C, w4Q, w4mlu = self.P(prefix + ".w4C"), self.P(prefix + ".w4Q"), self.P(prefix + ".w4mlu")
-        cd = ops.dropout(ctx, dc.next(prefix + ".c"))
-        qd = ops.dropout(qry, dc.next(prefix + ".q"))
+        # (tee: the apply stage reads the aliases, so the gradients of ctx / qry from the apply stage join the dropout
+        #  backward inside its kernel instead of through separate add passes)
+        if ops.CQ_TEE:
+            cd, ctx = ops.dropout(ctx, dc.next(prefix + ".c"), tee=True)
+            qd, qry = ops.dropout(qry, dc.next(prefix + ".q"), tee=True)
+        else:
+            cd = ops.dropout(ctx, dc.next(prefix + ".c"))
+            qd = ops.dropout(qry, dc.next(prefix + ".q"))
         whole = ops.cq_block_supported(Lc, Lq, D, cdt)   # score + softmaxes + apply stage as fused kernels each way
         if Lq <= Lc:      # (rank-1 terms: one scale-shift kernel + one matrix-vector kernel on the short stream)
             bop = ops.scale_shift(qd, w4mlu, w4C)
@@ -474,7 +480,8 @@ class SeqPAN(nn.Module):
             X = self._cut(X, blk - 1)
             X = self._dual_block(X, f"dual_attention_block_{blk}", vmask, tmask, rowmask, B, T, Lq, dc)
         X = self._cut(X, 2 if self.USE_DUAL_BLOCKS else 0)
-        V3, T3 = X[:Nv].view(B, T, D), X[Nv:].view(B, Lq, D)
+        V3, T3 = ops.split_rows(X, Nv) if ops.CQ_TEE else (X[:Nv], X[Nv:])
+        V3, T3 = V3.view(B, T, D), T3.view(B, Lq, D)
         t2v = self._cq_attention("q2v_attn", V3, T3, vmask, tmask, dc)            # [Nv, D]
         v2t = self._cq_attention("v2q_attn", T3, V3, tmask, vmask, dc)            # [Nt, D]
         # CQConcatenate (reference layers.py:462-468)

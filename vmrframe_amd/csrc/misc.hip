@@ -102,10 +102,16 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = ((hb >> e) & 1) ? g[e] * scale : 0.f;
         Vec8<T>::store(dz + r * ld + c0, g);
-      } else if (MODE == 2) {
+      } else if (MODE == 2 || MODE == 4) {
         const uint32_t keep = vmr_keep8(seed, (uint64_t)r * D + c0, thresh);
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = ((keep >> e) & 1) ? g[e] * scale : 0.f;
+        if (MODE == 4) {   // + the gradient of the tensor's other consumer (h), one pass instead of a separate add
+          float hv[8];
+          Vec8<T>::load(h + r * ld + c0, hv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] += hv[e];
+        }
         Vec8<T>::store(dz + r * ld + c0, g);
       }
 #pragma unroll
@@ -466,6 +472,9 @@ static void launch_rbb(int mode, dim3 grid, hipStream_t st, const void* dy, cons
   else if (mode == 3)
     hipLaunchKernelGGL((relu_bwd_bias_kernel<T, 3>), grid, dim3(256), 0, st, (const T*)dy, (const T*)h, (T*)dz, db, rows,
                        D, ld, scale, rpb, drop_p, seed, step, db2, db_scale);
+  else if (mode == 4)
+    hipLaunchKernelGGL((relu_bwd_bias_kernel<T, 4>), grid, dim3(256), 0, st, (const T*)dy, (const T*)h, (T*)dz, db, rows,
+                       D, ld, scale, rpb, drop_p, seed, step, db2, db_scale);
   else
     hipLaunchKernelGGL((relu_bwd_bias_kernel<T, 2>), grid, dim3(256), 0, st, (const T*)dy, (const T*)h, (T*)dz, db, rows,
                        D, ld, scale, rpb, drop_p, seed, step, db2, db_scale);
@@ -474,12 +483,12 @@ static void launch_rbb(int mode, dim3 grid, hipStream_t st, const void* dy, cons
 extern "C" int vmr_relu_bwd_bias(int mode, const void* dy, const void* h, void* dz, float* db, int64_t rows, int D,
                                  int64_t ld, float scale, int dtype, float drop_p, uint32_t drop_seed,
                                  const uint32_t* drop_step, float* db2, float db_scale, void* stream) {
-  VMR_CHECK(mode >= 0 && mode <= 3, "vmr_relu_bwd_bias: bad mode %d", mode);
+  VMR_CHECK(mode >= 0 && mode <= 4, "vmr_relu_bwd_bias: bad mode %d", mode);
   VMR_CHECK(!db2 || db, "vmr_relu_bwd_bias: db2 without db");
   if (db_scale == 0.f) db_scale = 1.f;
   VMR_CHECK(dy && (db || mode != 0), "vmr_relu_bwd_bias: null pointer");
   VMR_CHECK(D % 8 == 0 && ld % 8 == 0, "vmr_relu_bwd_bias: D and ld must be multiples of 8 (D=%d)", D);
-  VMR_CHECK((mode != 1 && mode != 3) || h, "vmr_relu_bwd_bias: modes 1/3 need h");
+  VMR_CHECK((mode != 1 && mode != 3 && mode != 4) || h, "vmr_relu_bwd_bias: modes 1/3/4 need h");
   VMR_CHECK(mode == 0 || dz, "vmr_relu_bwd_bias: modes 1/2 need dz");
   if (rows == 0) return 0;
   const int gx = cdiv(D, 256);

@@ -209,6 +209,7 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
 
 
 MERGE_DX_DW = os.environ.get("VMR_MERGE_DX_DW", "1") != "0"
+CQ_TEE = os.environ.get("VMR_CQ_TEE", "1") != "0"          # dropout backward + other-consumer gradient in one kernel; one-concat row split
 AUX_BITS = os.environ.get("VMR_AUX_BITS", "1") != "0"      # ReLU / dropout masks of the conv-block products as bit matrices
 GROUP_DW = os.environ.get("VMR_GROUP_DW", "1") != "0"      # one weight-gradient product per grouped projection
 DEFER_SPLITK_REDUCE = os.environ.get("VMR_DEFER_SPLITK_REDUCE", "1") != "0"
@@ -1512,10 +1513,11 @@ def bmm(a, b, ta, tb, out_f32=False):
 
 class _Dropout(torch.autograd.Function):
     """Stand-alone inverted dropout (the score-path dropout of CQAttention,
-    reference models/layers.py:431-432); mask regenerated in the backward."""
+    reference models/layers.py:431-432); mask regenerated in the backward.  tee=True also returns an alias of x: hand
+    it to x's OTHER consumer, whose gradient is then added inside this backward's kernel (no separate add pass)."""
 
     @staticmethod
-    def forward(ctx, x, drop):
+    def forward(ctx, x, drop, tee=False):
         L.require_gpu(x)
         x = x.contiguous()
         D = x.shape[-1]
@@ -1524,23 +1526,57 @@ class _Dropout(torch.autograd.Function):
         L.check(L.lib().vmr_cast(x.data_ptr(), L.dtype_code(x), y.data_ptr(), L.dtype_code(y), rows, D, D, D,
                                  drop[0], drop[1], _ptr(drop[2]), L.stream_ptr()), "vmr_cast")
         ctx.drop = drop
+        if tee:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxtra=None):
         drop = ctx.drop
+        if dy is None:
+            return dxtra, None, None
         dy = dy.contiguous()
         D = dy.shape[-1]
         rows = dy.numel() // D
         dx = torch.empty_like(dy)
-        L.check(L.lib().vmr_relu_bwd_bias(2, dy.data_ptr(), None, dx.data_ptr(), None, rows, D, D,
-                                          1.0 / (1.0 - drop[0]), L.dtype_code(dy), drop[0], drop[1], _ptr(drop[2]),
+        if dxtra is not None:
+            dxtra = dxtra.contiguous()
+            assert dxtra.shape == dy.shape and dxtra.dtype == dy.dtype
+        L.check(L.lib().vmr_relu_bwd_bias(4 if dxtra is not None else 2, dy.data_ptr(), _ptr(dxtra), dx.data_ptr(), None, rows, D,
+                                          D, 1.0 / (1.0 - drop[0]), L.dtype_code(dy), drop[0], drop[1], _ptr(drop[2]),
                                           None, 1.0, L.stream_ptr()), "vmr_relu_bwd_bias")
-        return dx, None
+        return dx, None, None
 
 
-def dropout(x, drop):
-    return x if drop[0] <= 0.0 else _Dropout.apply(x, drop)
+class _SplitRows(torch.autograd.Function):
+    """(X[:n0], X[n0:]) of a packed token matrix; backward = ONE concat of the two gradients (autograd's slice backward
+    zero-fills the full matrix twice, copies each slice in and adds the two)."""
+
+    @staticmethod
+    def forward(ctx, X, n0):
+        ctx.n0, ctx.shape = n0, tuple(X.shape)
+        ctx.meta = (X.dtype, X.device)
+        return X[:n0], X[n0:]
+
+    @staticmethod
+    def backward(ctx, da, db):
+        n0, shape = ctx.n0, ctx.shape
+        if da is None:
+            da = torch.zeros((n0,) + shape[1:], dtype=ctx.meta[0], device=ctx.meta[1])
+        if db is None:
+            db = torch.zeros((shape[0] - n0,) + shape[1:], dtype=ctx.meta[0], device=ctx.meta[1])
+        return torch.cat([da.reshape((n0,) + shape[1:]), db.reshape((shape[0] - n0,) + shape[1:])], 0), None
+
+
+def split_rows(X, n0):
+    return _SplitRows.apply(X, n0)
+
+
+def dropout(x, drop, tee=False):
+    """tee=True: returns (dropout(x), alias of x) -- see _Dropout."""
+    if drop[0] <= 0.0:
+        return (x, x) if tee else x
+    return _Dropout.apply(x, drop, tee)
 
 
 # ---------------------------------------------------------------------------
