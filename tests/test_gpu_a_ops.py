@@ -978,3 +978,18 @@ def test_label_fuse_matches_torch(dev, dt):
     _close(res.grad.float(), r32.grad, tol, "dres")
     _close(p.grad, p32.grad, tol, "dprobs")
     _close(E.grad, E32.grad, tol, "dlabel_embs")
+
+
+def test_transpose_batched_exact(dev):
+    """vmr_transpose_batched (the K-major weight copies of the arena): the 16-byte tile path (whole 64 x 64 tiles) and the
+    4-byte / element fallback, several items in one launch."""
+    from vmrframe_amd import _lib as L
+    shapes = [(128, 192), (64, 64), (100, 50), (1024, 3072), (70, 64), (256, 8)]
+    srcs = [torch.randn(r, c, device=dev).to(torch.bfloat16) for r, c in shapes]
+    dsts = [torch.zeros(c, r, device=dev, dtype=torch.bfloat16) for r, c in shapes]
+    items = (L.TransposeItem * len(shapes))()
+    for it, a, b, (r, c) in zip(items, srcs, dsts, shapes):
+        it.src, it.dst, it.rows, it.cols = a.data_ptr(), b.data_ptr(), r, c
+    L.check(L.lib().vmr_transpose_batched(items, len(shapes), L.stream_ptr()), "vmr_transpose_batched")
+    for a, b, shp in zip(srcs, dsts, shapes):
+        assert torch.equal(b, a.t().contiguous()), shp
