@@ -21,7 +21,11 @@ from tests.helpers import load_golden
 pytestmark = pytest.mark.gpu
 
 BF16_LOGIT_REL = 8e-2          # measured: 3.5e-2 (logits), 6.3e-2 (match scores) at B = 64
-BF16_GNORM_TENSOR = 0.15       # measured worst: 7.7e-2 .. 9.7e-2 (v2q_attn.w4C) at cfg2 shapes, B = 8
+BF16_GNORM_TENSOR = 0.15       # measured worst outside the rank-1 score terms: 5e-2 at cfg2 shapes, B = 8
+# The rank-1 terms of the trilinear score (w4C / w4Q) add a constant to every score of a softmax ROW (or column): that part
+# of their gradient is analytically zero, computed as a sum of cancelling bf16-rounded terms, and its noise floor adds
+# in quadrature to the norm -- measured 8e-2 .. 1.6e-1 depending on summation order and batch (B = 8 here)
+BF16_GNORM_RANK1 = 0.30
 BF16_GNORM_TOTAL = 0.05        # measured: 1.2e-2
 BF16_GRAD_TENSOR_REL = 0.20    # measured worst: 0.109 (text_encoder.query_conv1d.conv1d.bias) at B = 64
 BF16_GRAD_TOTAL_REL = 0.12     # measured: 6.6e-2
@@ -93,9 +97,14 @@ def test_graphed_bf16_step_at_cfg2_shapes_vs_golden(dev):
     tot = float(z["gnorm"])
     mine_tot = float(torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values())))
     assert abs(mine_tot - tot) < BF16_GNORM_TOTAL * tot, (mine_tot, tot)
-    worst = max((abs(float(grads[k].double().norm()) - v) / v, k) for k, v in zip(keys, vals) if v >= 1e-3 * tot)
-    print(f"[cfg2_small_B bf16 graph] total gnorm {mine_tot:.4f} vs {tot:.4f}; worst per-tensor norm error {worst}")
+    errs = [(abs(float(grads[k].double().norm()) - v) / v, k) for k, v in zip(keys, vals) if v >= 1e-3 * tot]
+    rank1 = lambda k: k.endswith(".w4C") or k.endswith(".w4Q")
+    worst = max(e for e in errs if not rank1(e[1]))
+    worst1 = max(e for e in errs if rank1(e[1]))
+    print(f"[cfg2_small_B bf16 graph] total gnorm {mine_tot:.4f} vs {tot:.4f}; worst per-tensor norm error {worst}, "
+          f"rank-1 score terms {worst1}")
     assert worst[0] < BF16_GNORM_TENSOR, worst
+    assert worst1[0] < BF16_GNORM_RANK1, worst1
     for k in [f[2:] for f in z.files if f.startswith("g.")]:       # the few small tensors stored in full
         if float(np.linalg.norm(z["g." + k])) >= 1e-3 * tot:
             assert rel(grads[k].cpu(), z["g." + k]) < BF16_GRAD_TENSOR_REL, k

@@ -231,12 +231,15 @@ __global__ __launch_bounds__(256) void dpos_kernel(const T* __restrict__ dy, flo
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int cpr = D / 8;
   const int64_t total = (int64_t)S * cpr;
-  // nsplit threads share one (s, 8 channels) column: thread sp walks batch-row groups sp, sp + nsplit, ... of 8 rows each
-  // and the partial sums meet through float atomics (nsplit per address).  One thread per column was a chain of
-  // batch/8 dependent HBM round trips: 16 us for a 17 MB operand at B = 64.
-  for (int64_t idx2 = (int64_t)blockIdx.x * 256 + threadIdx.x; idx2 < total * nsplit; idx2 += (int64_t)gridDim.x * 256) {
-    const int sp = (int)(idx2 / total);
-    const int64_t idx = idx2 - (int64_t)sp * total;
+  // nsplit (1, 2, 4 or 8) ADJACENT lanes share one (s, 8 channels) column: lane sp walks batch-row groups sp, sp + nsplit,
+  // ... of 8 rows each, the partial sums meet through lane shuffles and lane 0 of the group does the read-modify-write.
+  // (One thread per column was a chain of batch/8 dependent HBM round trips: 16 us for a 17 MB operand at B = 64;
+  // meeting through float atomics instead -- 8 per address, 32-byte lane stride -- took 28 us.)
+  const int64_t total2 = (total * nsplit + 255) / 256 * 256;     // whole workgroups: every lane reaches the shuffles
+  for (int64_t idx2 = (int64_t)blockIdx.x * 256 + threadIdx.x; idx2 < total2; idx2 += (int64_t)gridDim.x * 256) {
+    const int sp = (int)(idx2 % nsplit);
+    const int64_t idx = min(idx2 / nsplit, total - 1);
+    const bool live = idx2 / nsplit < total;
     const int s = (int)(idx / cpr), c = (int)(idx - (int64_t)s * cpr) * 8;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     typedef __attribute__((ext_vector_type(8))) T TV8;
@@ -256,10 +259,11 @@ __global__ __launch_bounds__(256) void dpos_kernel(const T* __restrict__ dy, flo
         }
       }
     }
-    if (nsplit > 1) {
+    for (int d = 1; d < nsplit; d <<= 1) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) atomicAdd(dpos + (int64_t)s * D + c + e, acc[e]);
-    } else {
+      for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], d, 64);
+    }
+    if (sp == 0 && live) {
       float old[8];
       Vec8<float>::load(dpos + (int64_t)s * D + c, old);
 #pragma unroll
@@ -268,9 +272,9 @@ __global__ __launch_bounds__(256) void dpos_kernel(const T* __restrict__ dy, flo
     }
   }
 }
-static inline int dpos_split(int64_t rows, int S) {   // one round of 8 rows per thread where the batch allows, at most 8 ways
+static inline int dpos_split(int64_t rows, int S) {   // one round of 8 rows per lane where the batch allows: 1, 2, 4 or 8 ways
   const int64_t groups = (rows / S + 7) / 8;
-  return (int)(groups < 1 ? 1 : (groups > 8 ? 8 : groups));
+  return groups >= 8 ? 8 : (groups >= 4 ? 4 : (groups >= 2 ? 2 : 1));
 }
 
 // y[r, :] = x[r, :] + pos[r % S, :]  (the positional add of FeatureEncoderPredict, reference layers.py:626-631): pos is the
