@@ -649,7 +649,16 @@ extern "C" int vmr_ln_dwconv_fwd2(const void* x, const float* gamma, const float
   dwconv_tiling(S1, D, esz, R1, tiles1);
   dwconv_tiling(S2, D, esz, R2, tiles2);
   VMR_CHECK(R1 > 0 && R2 > 0, "vmr_ln_dwconv_fwd: D too large for the LDS tile");
-  const size_t lds = (size_t)(max(R1, R2) + 6) * D * esz;
+  size_t lds = (size_t)(max(R1, R2) + 6) * D * esz;
+  {   // (A/B switch: a larger LDS request lowers the resident workgroups per CU, so the grid runs in rounds whose load
+      //  and store bursts overlap)
+    static int pad = -1;
+    if (pad < 0) {
+      const char* e = getenv("VMR_DWCONV_LDS_KB");
+      pad = e ? atoi(e) : 0;
+    }
+    if ((size_t)pad * 1024 > lds) lds = (size_t)pad * 1024;
+  }
   const void* fn = nullptr;
   if (dtype == VMR_BF16) LN_DISPATCH(D, fn = (const void*)ln_dwconv_fwd_kernel<bf16_t, MC>);
   else LN_DISPATCH(D, fn = (const void*)ln_dwconv_fwd_kernel<float, MC>);
