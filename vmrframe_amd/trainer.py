@@ -84,7 +84,10 @@ class GraphedTrainStep:
                 self.opt.step()
             self.pieces = [(g0, [])]
             return self
-        with torch.cuda.graph(g0, stream=s):
+        # With a process group alive its watchdog thread polls events while we capture: only THIS thread's calls are
+        # policed ("thread_local"); the default global mode would fail the capture on the watchdog's queries.
+        mode = dict(capture_error_mode="thread_local")
+        with torch.cuda.graph(g0, stream=s, **mode):
             self.loss, self.out = self._forward()
             plan = self.model.backward_plan(self.loss) if hasattr(self.model, "backward_plan") else \
                 [(self.loss.backward, list(range(len(self.reducer.ranges()) - 1, -1, -1)))]
@@ -92,11 +95,11 @@ class GraphedTrainStep:
         self.pieces = [(g0, plan[0][1])]
         for run, done in plan[1:]:                  # the tape of the earlier stages lives in g0's memory pool
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s, pool=g0.pool()):
+            with torch.cuda.graph(g, stream=s, pool=g0.pool(), **mode):
                 run()
             self.pieces.append((g, done))
         self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt, stream=s, pool=g0.pool()):
+        with torch.cuda.graph(self.g_opt, stream=s, pool=g0.pool(), **mode):
             self.opt.step()
         return self
 
