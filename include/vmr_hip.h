@@ -336,6 +336,10 @@ int vmr_eltwise(int op, const void* a, const void* b, const void* c, const void*
  * gradient of a column slice of a weight matrix inside the arena). */
 int vmr_splitk_reduce(const float* slab, float* dst, int nsplit, int64_t n, int cols, int64_t ld_dst,
                       void* stream);
+/* out[m,n] = dtype(sum_k slab[k][m,n] + bias[n] + addend[m,n]) (bias fp32 [cols], addend dtype [rows,cols], both
+ * nullable): second stage of a few-tile split-K product together with its epilogue and the cast. */
+int vmr_splitk_reduce_cast(const float* slab, int nsplit, int64_t rows, int cols, const float* bias, const void* addend,
+                           void* out, int dtype, void* stream);
 
 /* ------------------------------------------------- CQAttention score kernel
  * The trilinear similarity of CQAttention (models/layers.py:417-421,427-437; rank-1 terms folded onto the short

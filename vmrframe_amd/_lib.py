@@ -122,6 +122,7 @@ SIGNATURES = {
     "vmr_embedding_bwd": [_P, _P, _P, _L, _I, _L, _L, _P],
     "vmr_eltwise": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "vmr_splitk_reduce": [_P, _P, _I, _L, _I, _L, _P],
+    "vmr_splitk_reduce_cast": [_P, _I, _L, _I, _P, _P, _P, _I, _P],
     "vmr_map2d_cells": [_P, _I, _I],
     "vmr_map2d_pool_fwd": [_P, _P, _P, _L, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "vmr_map2d_pool_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _I, _I, _P],

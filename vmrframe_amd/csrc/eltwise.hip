@@ -101,6 +101,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// out[m, n] = T(sum_k slab[k][m, n] + bias[n] + addend[m, n]): the second stage of a few-tile split-K product WITH its
+// epilogue (bias of the layer, or the gradient of the input's other consumer) and the cast to the compute dtype --
+// one launch instead of {zero-fill, atomics, add, cast}, and a fixed summation order
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_cast_kernel(const float* __restrict__ slab, int nsplit, int64_t n4,
+                                                                 int cols4, const float* __restrict__ bias,
+                                                                 const T* __restrict__ addend, T* __restrict__ out) {
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 acc = s4[i];
+    for (int k = 1; k < nsplit; ++k) {
+      const f32x4 v = s4[k * n4 + i];
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    if (bias) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (i % cols4) * 4);
+      acc[0] += bv[0]; acc[1] += bv[1]; acc[2] += bv[2]; acc[3] += bv[3];
+    }
+    float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (addend) {
+      float av[4];
+      Vec4<T>::load(addend + i * 4, av);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += av[e];
+    }
+    Vec4<T>::store(out + i * 4, o);
+  }
+}
+
 template <typename T>
 void launch_elt(int op, dim3 grid, hipStream_t st, const void* a, const void* b, const void* c, const void* d,
                 const void* e5, const float* rowmask, void* o0, void* o1, void* o2, void* o3, int64_t rows, int D) {
@@ -147,6 +176,27 @@ extern "C" int vmr_splitk_reduce(const float* slab, float* dst, int nsplit, int6
   if (n == 0) return 0;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((int64_t)4096, (n / 4 + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, slab, dst, nsplit, n / 4, n / 4, cols / 4, ld_dst / 4);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_splitk_reduce_cast(const float* slab, int nsplit, int64_t rows, int cols, const float* bias, const void* addend,
+                                      void* out, int dtype, void* stream) {
+  VMR_CHECK(slab && out && nsplit >= 1 && rows >= 0 && cols > 0, "vmr_splitk_reduce_cast: bad arguments");
+  VMR_CHECK(cols % 4 == 0 && ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) |
+                               reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(addend)) & 7) == 0 &&
+                (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0,
+            "vmr_splitk_reduce_cast: cols %% 4 == 0, 16-byte aligned slabs / bias, 8-byte aligned out / addend");
+  VMR_CHECK(dtype == VMR_BF16 || dtype == VMR_F32, "vmr_splitk_reduce_cast: bad dtype");
+  const int64_t n4 = rows * cols / 4;
+  if (n4 == 0) return 0;
+  const dim3 grid((unsigned)min((int64_t)4096, (n4 + 255) / 256));
+  if (dtype == VMR_BF16)
+    hipLaunchKernelGGL(splitk_reduce_cast_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, slab, nsplit, n4, cols / 4, bias,
+                       (const bf16_t*)addend, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(splitk_reduce_cast_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, slab, nsplit, n4, cols / 4, bias,
+                       (const float*)addend, (float*)out);
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -229,21 +229,28 @@ def mm(a: torch.Tensor, b: torch.Tensor, ta: int, tb: int, *, out=None, out_f32=
     return (out, h) if kw.get("hold") else out
 
 
-def mm_few_tiles(a: torch.Tensor, b: torch.Tensor, ta: int, tb: int) -> Optional[torch.Tensor]:
-    """a . b for products with a handful of output tiles and a long K (a [64, D] pooled vector through a [D, D]
-    weight): split K over the idle CUs, fp32 partials through atomics, one cast.  None if the shape does not
-    qualify (the caller uses the plain path)."""
+def mm_few_tiles(a: torch.Tensor, b: torch.Tensor, ta: int, tb: int, bias=None, addend=None) -> Optional[torch.Tensor]:
+    """a . b (+ bias[n] + addend[m,n]) in the compute dtype for products with few output tiles and a long K (a [64, D]
+    pooled vector through a [D, D] weight; the text-side [1280, 1024, 4096] product): K is split over the idle CUs into
+    plain fp32 slabs and ONE second-stage launch sums them, applies the epilogue and casts (no zero-fill, no atomics:
+    the summation order is fixed).  None if the shape does not qualify (the caller uses the plain path)."""
     M, K = (a.shape[1], a.shape[0]) if ta else a.shape
     N = b.shape[1] if tb else b.shape[0]
     tiles = _cdiv(M, 128) * _cdiv(N, 128)
-    if a.dtype == torch.float32 or tiles >= FEW_TILES or K < 512:
+    if a.dtype == torch.float32 or tiles >= FEW_TILES or K < 512 or N % 4 != 0:
         return None
     # enough splits for ~320 workgroups, at least two 128-deep K-steps each (the text-side products: [1280,1024,4096]
     # is 80 tiles x 64 K-steps as a plain launch -- 63 us on a third of the CUs)
     sk = max(2, min(8, K // 256 if tiles >= 32 else K // 128, _cdiv(320, tiles)))
-    acc = torch.zeros(M, N, device=a.device, dtype=torch.float32)
-    gemm(a, b, acc, M, N, K, ta, tb, a.stride(0), b.stride(0), N, dtype=L.dtype_code(a), flags=L.EPI_ACCUM, splitk=sk)
-    return acc
+    ws = torch.empty(sk, M, N, device=a.device, dtype=torch.float32)
+    gemm(a, b, ws, M, N, K, ta, tb, a.stride(0), b.stride(0), N, dtype=L.dtype_code(a), flags=L.EPI_SLAB, splitk=sk)
+    out = torch.empty(M, N, device=a.device, dtype=a.dtype)
+    if addend is not None:
+        addend = addend.contiguous()
+        assert tuple(addend.shape) == (M, N) and addend.dtype == a.dtype
+    L.check(L.lib().vmr_splitk_reduce_cast(ws.data_ptr(), sk, M, N, _ptr(bias), _ptr(addend), out.data_ptr(), L.dtype_code(out),
+                                           L.stream_ptr()), "vmr_splitk_reduce_cast")
+    return out
 
 
 def bmm4(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, ta: int, tb: int, *, flags=0, **kw):
@@ -486,9 +493,9 @@ class _Linear(torch.autograd.Function):
             flags |= L.EPI_ROWSCALE
         few = None
         if (Np == N and not relu and drop[0] == 0 and residual is None and rowscale is None and bias2 is None):
-            few = mm_few_tiles(x, W, 0, 0)         # e.g. the pooled-query projection of CQConcatenate: M = B
+            few = mm_few_tiles(x, W, 0, 0, bias=bias)   # e.g. the pooled-query projection of CQConcatenate: M = B
         if few is not None:
-            ybuf = y = (few + bias if bias is not None else few).to(x.dtype)
+            ybuf = y = few
         else:
             gemm(x, W, ybuf, M, N, Kp, 0, 0, x.stride(0), W.stride(0), Np, dtype=dt, flags=flags, bias=bias,
                  residual=residual, aux=aux, ldr=N, rowscale=rowscale, drop=drop, bias2=bias2, bias_scale=bias_scale,
@@ -566,9 +573,9 @@ class _Linear(torch.autograd.Function):
         held = None       # the dX product, held back until the first weight-gradient slab product takes it along
         state = ctx.state
         if ctx.needs_input_grad[0]:
-            few = mm_few_tiles(dz, W, 0, 1)
+            few = mm_few_tiles(dz, W, 0, 1, addend=dxtra)
             if few is not None:
-                dx = (few if dxtra is None else few + dxtra).to(dz.dtype)
+                dx = few
             else:
                 # K-major weight copy from the optimizer arena: dX = dz . Wt^T runs on the row-major-weight kernel
                 Wt = WeightCache.get_t(ctx.weights, dz.dtype) if Np == N else None
