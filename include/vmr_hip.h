@@ -417,6 +417,9 @@ int vmr_narrow_linear_fwd(const void* x, const float* W, const float* bias, floa
                           int K, int64_t ldx, int dtype, void* stream);
 int vmr_narrow_linear_bwd(const float* dy, const void* x, const float* W, void* dx, float* dW, float* db,
                           float* workspace, int64_t M, int N, int K, int64_t ldx, int dtype, void* stream);
+/* Same with dx = dx_add + sum_n dy[m,n] W[n,:] (dx_add: dtype, dense [M,K]: the gradient of x's other consumer). */
+int vmr_narrow_linear_bwd_add(const float* dy, const void* x, const float* W, void* dx, const void* dx_add, float* dW,
+                              float* db, float* workspace, int64_t M, int N, int K, int64_t ldx, int dtype, void* stream);
 /* The label-embedding fuse of the match head (models/SeqPAN.py:80-82): y = (res + p . E^T) * rowscale with p fp32 [M,N]
  * (the Gumbel-softmax probabilities, N = 4), E = label_embs fp32 [K,N], res / y [M,K] dtype, rowscale fp32 [M] or NULL.
  * bwd: dres = dy * rowscale (dtype [M,K]), dp[m,n] = dres[m,:] . E[:,n] (fp32 [M,N]), dE[k,n] += sum_m p[m,n] dres[m,k]

@@ -62,7 +62,7 @@ json.dump(tj, open(os.path.join(P, "gemm_traffic.json"), "w"), indent=1)
 with open(os.path.join(P, f"{tag}_summary.md"), "w") as o:
     o.write(f"# Round 2, {tag} -- rocprofv3 of the default bench\n\n")
     o.write("Commands (scratch/profile_round2.sh, 1x MI355X, cfg2, bf16, dropout 0.2): `rocprofv3 --kernel-trace --stats --output-format csv -- "
-            "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline` (hipGraph replay); then three PMC-only passes over "
+            "python3 bench.py --steps 100 --warmup 2 --no-cpu-baseline` (hipGraph replay; 100 timed steps so that the one-time set-up kernels -- parameter init, arena build -- stay below 1 % of the totals); then three PMC-only passes over "
             "`python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline`: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, "
             "`--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_WAVE_CYCLES GRBM_GUI_ACTIVE`.\n\n")
     if bench:

@@ -308,9 +308,9 @@ class SeqPAN(nn.Module):
     def _lin(self, x, prefix, **kw):
         return ops.linear(x, self.P(prefix + ".conv1d.weight"), self.P(prefix + ".conv1d.bias"), self._cache, **kw)
 
-    def _head(self, x, prefix):
+    def _head(self, x, prefix, tee=False):
         """Conv1D with <= 8 output channels -> fp32 logits (matrix-vector kernels, ops.narrow_linear)."""
-        return ops.narrow_linear(x, self.P(prefix + ".conv1d.weight"), self.P(prefix + ".conv1d.bias"))
+        return ops.narrow_linear(x, self.P(prefix + ".conv1d.weight"), self.P(prefix + ".conv1d.bias"), tee=tee)
 
     def _ln(self, x, prefix, eps, **kw):
         return ops.layer_norm(x, self.P(prefix + ".weight"), self.P(prefix + ".bias"), eps, self._cache, **kw)
@@ -493,7 +493,7 @@ class SeqPAN(nn.Module):
         pq = ops.linear(pooled, Wc, bc, self._cache, kslice=(D, 2 * D))           # [B, D]
         fuse = ops.linear(t2v, Wc, None, self._cache, kslice=(0, D), residual=pq, res_div=T)
         # match head (reference models/SeqPAN.py:78-82)
-        mlogits = self._head(fuse, "match_conv1d")                                 # [Nv, 4] fp32
+        mlogits, fuse = self._head(fuse, "match_conv1d", tee=True)                 # [Nv, 4] fp32 (+ alias: label_fuse below)
         gseed, gstep = dc.noise_seed("match.gumbel")
         noise = None if self.gumbel_override is None else self.gumbel_override.to(mlogits.device).reshape(Nv, 4)
         # Gumbel-softmax (tau 0.3) + the K-padded compute-dtype copy in one kernel

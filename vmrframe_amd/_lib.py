@@ -92,6 +92,7 @@ SIGNATURES = {
     "vmr_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _F, _U, _P, _P],
     "vmr_narrow_linear_fwd": [_P, _P, _P, _P, _L, _I, _I, _L, _I, _P],
     "vmr_narrow_linear_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P],
+    "vmr_narrow_linear_bwd_add": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _I, _P],
     "vmr_gumbel_softmax_fwd": [_P, _P, _F, _U, _P, _P, _P, _L, _I, _I, _I, _P],
     "vmr_gumbel_softmax_bwd": [_P, _P, _P, _F, _P, _L, _I, _I, _I, _P],
     "vmr_match_loss_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],

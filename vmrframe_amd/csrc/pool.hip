@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void narrow_fwd_kernel(const T* __restrict__ x
 // dx[m, chunk] = sum_n dy[m,n] * W[n, chunk]: pure streaming, one thread per (row, 8-column chunk), W in LDS
 template <typename T, int N>
 __global__ __launch_bounds__(256) void narrow_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W,
-                                                        T* __restrict__ dx, int64_t M, int K) {
+                                                        T* __restrict__ dx, int64_t M, int K, const T* __restrict__ add) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Ws = reinterpret_cast<float*>(smem);   // [N][K]
   for (int i = threadIdx.x * 4; i < N * K; i += 1024) *reinterpret_cast<f32x4*>(Ws + i) = *reinterpret_cast<const f32x4*>(W + i);
@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256) void narrow_dx_kernel(const float* __restrict_
     const int64_t m = idx / cpr;
     const int c = (int)(idx - m * cpr) * 8;
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (add) Vec8<T>::load(add + m * K + c, o);   // the gradient of x's other consumer joins here (no separate add pass)
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       const float g = dy[m * N + n];
@@ -426,14 +427,14 @@ int launch_narrow_fwd(int N, dim3 grid, size_t lds, hipStream_t st, const void* 
 constexpr int NL_RPB = 32;    // rows per workgroup of the dW reduction (128 left 64-74 workgroups on 256 CUs, each thread a chain of 8 dependent row fetches: 15 us)
 template <typename T>
 int launch_narrow_bwd(int N, hipStream_t st, const float* dy, const void* x, const float* W, void* dx, float* dW, float* db,
-                      float* ws, int64_t M, int K, int64_t ldx) {
+                      float* ws, int64_t M, int K, int64_t ldx, const void* dx_add) {
   const dim3 gw((unsigned)((M + NL_RPB - 1) / NL_RPB));
   const dim3 gx((unsigned)min((int64_t)4096, (M * (K / 8) + 255) / 256));
   const size_t lds = (size_t)N * K * 4;
   const int groups = max(1, 256 / (K / 8));
 #define VMR_NB(NN)                                                                                                    \
   do {                                                                                                                \
-    if (dx) hipLaunchKernelGGL((narrow_dx_kernel<T, NN>), gx, dim3(256), lds, st, dy, W, (T*)dx, M, K);                \
+    if (dx) hipLaunchKernelGGL((narrow_dx_kernel<T, NN>), gx, dim3(256), lds, st, dy, W, (T*)dx, M, K, (const T*)dx_add); \
     hipLaunchKernelGGL((narrow_dw_kernel<T, NN>), gw, dim3(256), 0, st, dy, (const T*)x, ws, M, K, ldx, NL_RPB);       \
   } while (0)
   switch (N) {
@@ -597,15 +598,25 @@ extern "C" int vmr_narrow_linear_fwd(const void* x, const float* W, const float*
   return 0;
 }
 
+extern "C" int vmr_narrow_linear_bwd_add(const float* dy, const void* x, const float* W, void* dx /*nullable*/, const void* dx_add,
+                                         float* dW, float* db /*nullable*/, float* workspace, int64_t M, int N, int K,
+                                         int64_t ldx, int dtype, void* stream);
 extern "C" int vmr_narrow_linear_bwd(const float* dy, const void* x, const float* W, void* dx /*nullable*/, float* dW,
                                      float* db /*nullable*/, float* workspace, int64_t M, int N, int K, int64_t ldx,
                                      int dtype, void* stream) {
+  return vmr_narrow_linear_bwd_add(dy, x, W, dx, nullptr, dW, db, workspace, M, N, K, ldx, dtype, stream);
+}
+
+extern "C" int vmr_narrow_linear_bwd_add(const float* dy, const void* x, const float* W, void* dx /*nullable*/, const void* dx_add,
+                                         float* dW, float* db /*nullable*/, float* workspace, int64_t M, int N, int K,
+                                         int64_t ldx, int dtype, void* stream) {
   VMR_CHECK(dy && x && W && dW && workspace, "vmr_narrow_linear_bwd: null pointer");
+  VMR_CHECK(!dx_add || dx, "vmr_narrow_linear_bwd_add: dx_add without dx");
   VMR_CHECK(N >= 1 && N <= NL_MAXN && K % 8 == 0 && K <= 2048 && ldx % 8 == 0 && ldx >= K && (size_t)N * K * 4 <= 64 * 1024,
             "vmr_narrow_linear_bwd: need 1 <= N <= 8, K %% 8 == 0, K <= 2048, N*K*4 <= 64 KiB (N=%d K=%d)", N, K);
   if (M == 0) return 0;
-  if (dtype == VMR_BF16) launch_narrow_bwd<bf16_t>(N, (hipStream_t)stream, dy, x, W, dx, dW, db, workspace, M, K, ldx);
-  else launch_narrow_bwd<float>(N, (hipStream_t)stream, dy, x, W, dx, dW, db, workspace, M, K, ldx);
+  if (dtype == VMR_BF16) launch_narrow_bwd<bf16_t>(N, (hipStream_t)stream, dy, x, W, dx, dW, db, workspace, M, K, ldx, dx_add);
+  else launch_narrow_bwd<float>(N, (hipStream_t)stream, dy, x, W, dx, dW, db, workspace, M, K, ldx, dx_add);
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -729,7 +729,7 @@ class _NarrowLinear(torch.autograd.Function):
     fp32 logits [M, N] straight from the compute-dtype features, one backward pass for dx, dW, db."""
 
     @staticmethod
-    def forward(ctx, x, W, bias, N):
+    def forward(ctx, x, W, bias, N, tee=False):
         L.require_gpu(x, W)
         assert x.dim() == 2 and x.stride(1) == 1
         M, K = x.shape
@@ -740,15 +740,20 @@ class _NarrowLinear(torch.autograd.Function):
                                               L.dtype_code(x), L.stream_ptr()), "vmr_narrow_linear_fwd")
         ctx.save_for_backward(x, W, bias)
         ctx.N = N
+        if tee:   # second output = x itself: its other consumer's gradient then joins dx inside the dx kernel
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxtra=None):
         x, W, bias = ctx.saved_tensors
         M, K = x.shape
         N = ctx.N
         dy = dy.contiguous().float()
         dx = torch.empty(M, K, device=x.device, dtype=x.dtype) if ctx.needs_input_grad[0] else None
+        if dxtra is not None:
+            dxtra = dxtra.contiguous()
+            assert dx is not None and dxtra.shape == x.shape and dxtra.dtype == x.dtype and x.is_contiguous()
         gW, gb = main_grad(W), (main_grad(bias) if bias is not None else None)
         dW = gW if gW is not None else torch.zeros(N, K, device=x.device, dtype=torch.float32)
         db = None
@@ -756,11 +761,11 @@ class _NarrowLinear(torch.autograd.Function):
             db = gb if gb is not None else torch.zeros(N, device=x.device, dtype=torch.float32)
         groups = max(1, 256 // (K // 8))
         ws = torch.empty(_cdiv(M, 32) * groups * (N * K + N), device=x.device, dtype=torch.float32)   # VMR_NARROW_WS_FLOATS
-        L.check(L.lib().vmr_narrow_linear_bwd(dy.data_ptr(), x.data_ptr(), W.detach().reshape(N, -1).data_ptr(), _ptr(dx),
-                                              dW.data_ptr(), _ptr(db), ws.data_ptr(), M, N, K, x.stride(0),
-                                              L.dtype_code(x), L.stream_ptr()), "vmr_narrow_linear_bwd")
+        L.check(L.lib().vmr_narrow_linear_bwd_add(dy.data_ptr(), x.data_ptr(), W.detach().reshape(N, -1).data_ptr(), _ptr(dx),
+                                                  _ptr(dxtra), dW.data_ptr(), _ptr(db), ws.data_ptr(), M, N, K, x.stride(0),
+                                                  L.dtype_code(x), L.stream_ptr()), "vmr_narrow_linear_bwd_add")
         return (dx, None if gW is not None else dW.reshape(W.shape),
-                None if (bias is None or gb is not None) else db, None)
+                None if (bias is None or gb is not None) else db, None, None)
 
 
 class _LabelFuse(torch.autograd.Function):
@@ -804,10 +809,10 @@ def label_fuse(res, probs, E, rowscale=None):
     return _LabelFuse.apply(res, probs, E, rowscale)
 
 
-def narrow_linear(x, W, bias, N=None):
+def narrow_linear(x, W, bias, N=None, tee=False):
     """x [M,K] (compute dtype) . W^T + bias -> fp32 [M,N], N <= 8; W holds N*K values as N contiguous rows
-    ([N,K,1] conv weights; a [K,1] column vector with N=1)."""
-    return _NarrowLinear.apply(x, W, bias, W.shape[0] if N is None else N)
+    ([N,K,1] conv weights; a [K,1] column vector with N=1).  tee=True: returns (y, alias of x) -- see _Linear."""
+    return _NarrowLinear.apply(x, W, bias, W.shape[0] if N is None else N, tee)
 
 
 class _GumbelSoftmax(torch.autograd.Function):
@@ -826,6 +831,7 @@ class _GumbelSoftmax(torch.autograd.Function):
                 "vmr_gumbel_softmax_fwd")
         ctx.save_for_backward(probs)
         ctx.meta = (tau, pad_to, dtype)
+        ctx.set_materialize_grads(False)     # an unused output must not cost a zero-filled gradient
         return probs, padded
 
     @staticmethod
@@ -833,6 +839,8 @@ class _GumbelSoftmax(torch.autograd.Function):
         (probs,) = ctx.saved_tensors
         tau, pad_to, dtype = ctx.meta
         R, Cc = probs.shape
+        if dprobs is None and dpadded is None:
+            return None, None, None, None, None, None, None
         dprobs = None if dprobs is None else dprobs.contiguous().float()
         dpadded = None if dpadded is None else dpadded.contiguous()
         dl = torch.empty_like(probs)

@@ -44,7 +44,8 @@ class GraphedTrainStep:
         self.stream: Optional[torch.cuda.Stream] = None
 
     def _forward(self):
-        self.model.drop_step.add_(1)
+        if self.model.drop_step is not self.opt.step_t:     # (once the arena exists the dropout streams are keyed by the
+            self.model.drop_step.add_(1)                    #  optimizer's own device step counter: one increment per step)
         self.opt.zero_grad()
         return self.engine(self.model, self.static_batch, self.cfg, "train")
 
@@ -75,6 +76,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         assert self.opt.arena is not None
+        self.model.drop_step = self.opt.step_t      # int32[1] on the device, advanced inside the optimizer graph
         self.model._cache.clear()                   # every weight cast must be recorded in the graph
         g0 = torch.cuda.CUDAGraph()
         if not self.split:
