@@ -470,9 +470,11 @@ class SeqPAN(nn.Module):
         # (V is zero-padded to a multiple of 64 columns, e.g. 500 -> 512: the projection stays on the LDS-DMA GEMM)
         vx = ops.cast_pad(vfeat_in.reshape(Nv, -1).float(), cdt, dc.next("video.in"), mult=64 if cdt != torch.float32 else 8)
         vq = self._lin(vx, "video_affine.video_conv1d")
-        xv = self._ln(vq, "video_affine.v_layer_norm", 1e-6, pos=pos_p, S=T)
-        xt = self._ln(tq, "text_encoder.q_layer_norm", 1e-6, pos=pos_p, S=Lq)
-        X = torch.cat([xv, xt], 0)
+        # (the two LayerNorms write their rows of the packed token matrix directly: no concat pass)
+        X = torch.empty(Nv + tq.shape[0], D, device=vq.device, dtype=vq.dtype)
+        xv = self._ln(vq, "video_affine.v_layer_norm", 1e-6, pos=pos_p, S=T, out=X[:Nv])
+        xt = self._ln(tq, "text_encoder.q_layer_norm", 1e-6, pos=pos_p, S=Lq, out=X[Nv:])
+        X = ops.pack_rows(X, xv, xt)
         # the SAME encoder on both streams (reference models/SeqPAN.py:59-60)
         X = self._conv_block(X, "vfeat_encoder.conv_block", segs, dc, self.ENC_LAYERS)
         rowmask = torch.cat([vmask.reshape(-1), tmask.reshape(-1)])

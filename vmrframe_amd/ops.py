@@ -1098,11 +1098,13 @@ class _LayerNorm(torch.autograd.Function):
     separate elementwise pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, pos, S, drop, cache, tee=False):
+    def forward(ctx, x, gamma, beta, eps, pos, S, drop, cache, tee=False, out=None):
         L.require_gpu(x)
         x = x.contiguous()
         rows, D = x.shape
-        y = torch.empty_like(x)
+        if out is not None:      # (rows of a caller-owned packed matrix: see pack_rows)
+            assert tuple(out.shape) == tuple(x.shape) and out.dtype == x.dtype and out.is_contiguous() and not tee
+        y = out if out is not None else torch.empty_like(x)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         posc = None
@@ -1148,13 +1150,34 @@ class _LayerNorm(torch.autograd.Function):
                                                        S, rows, D, L.dtype_code(x), drop[0], drop[1], _ptr(drop[2]),
                                                        C.byref(nb), L.stream_ptr()), "vmr_layernorm_bwd_deferred")
             ctx.state.defer_colreduce(ws, dg, db, nb.value, D, D, 512 if D <= 512 else (1024 if D <= 1024 else 2048))
-            return dx, None, None, None, dpos_ret, None, None, None, None
+            return dx, None, None, None, dpos_ret, None, None, None, None, None
         L.check(L.lib().vmr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                           rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                           _ptr(dpos), ws.data_ptr(), S, rows, D, L.dtype_code(x), drop[0], drop[1],
                                           _ptr(drop[2]),
                                           L.stream_ptr()), "vmr_layernorm_bwd")
-        return dx, (None if direct else dg), (None if direct else db), None, dpos_ret, None, None, None, None
+        return dx, (None if direct else dg), (None if direct else db), None, dpos_ret, None, None, None, None, None
+
+
+class _PackRows(torch.autograd.Function):
+    """X = [a; b] where a and b were WRITTEN INTO the two row ranges of X by their producers (layer_norm(out=...)):
+    the packed token matrix without a concat pass; backward hands the two row ranges of dX back as views."""
+
+    @staticmethod
+    def forward(ctx, X, a, b):
+        n0 = a.shape[0]
+        assert X.shape[0] == n0 + b.shape[0] and a.data_ptr() == X.data_ptr() and \
+            b.data_ptr() == X.data_ptr() + n0 * X.stride(0) * X.element_size()
+        ctx.n0 = n0
+        return X.view_as(X)
+
+    @staticmethod
+    def backward(ctx, dX):
+        return None, dX[:ctx.n0], dX[ctx.n0:]
+
+
+def pack_rows(X, a, b):
+    return _PackRows.apply(X, a, b)
 
 
 class _AddPos(torch.autograd.Function):
@@ -1190,8 +1213,8 @@ def add_pos(x, pos, S):
     return _AddPos.apply(x, pos, S)
 
 
-def layer_norm(x, gamma, beta, eps, cache, *, pos=None, S=0, drop=NO_DROP, tee=False):
-    return _LayerNorm.apply(x, gamma, beta, eps, pos, S, drop, cache, tee)
+def layer_norm(x, gamma, beta, eps, cache, *, pos=None, S=0, drop=NO_DROP, tee=False, out=None):
+    return _LayerNorm.apply(x, gamma, beta, eps, pos, S, drop, cache, tee, out)
 
 
 # ---------------------------------------------------------------------------
