@@ -263,10 +263,21 @@ int fill_args(CharCnnArgs& a, const int64_t* ids, const float* table, const floa
 
 }  // namespace
 
+// words per workgroup: 8 (bf16) covers 1280 words with 160 workgroups -- fewer than CUs; VMR_CC_WPB=4 doubles them
+static int cc_wpb(int dtype) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VMR_CC_WPB");
+    v = e ? atoi(e) : 8;
+    if (v != 4 && v != 8) v = 8;
+  }
+  return dtype == VMR_BF16 ? v : 4;
+}
+
 extern "C" int vmr_char_cnn_ws_floats(int W, int CD, const int* oc, int dtype) {
   int wtot = 0, ot = 0;
   for (int kk = 0; kk < CC_NK; ++kk) { wtot += oc[kk] * CD * (kk + 1); ot += oc[kk]; }
-  const int wpb = dtype == VMR_BF16 ? 8 : 4;   // words per workgroup of the backward kernel
+  const int wpb = cc_wpb(dtype);   // words per workgroup of the backward kernel
   return ((W + wpb - 1) / wpb) * (wtot + ot);
 }
 
@@ -278,7 +289,7 @@ extern "C" int vmr_char_cnn_fwd(const int64_t* char_ids, const float* table, con
   if (W == 0) return 0;
   CharCnnArgs a;
   fill_args(a, char_ids, table, w, b, oc, W, C, CD, drop_p, drop_seed, drop_step);
-  const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = dtype == VMR_BF16 ? 8 : 4;
+  const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = cc_wpb(dtype);
   const int cp = C <= 8 ? 8 : 16;
   const size_t lds = ((size_t)a.wtot * esz + 15) / 16 * 16 + (size_t)wpb * cp * CD * 4;
   VMR_CHECK(lds <= 160 * 1024, "vmr_char_cnn_fwd: operands do not fit LDS (%zu B)", lds);
@@ -291,7 +302,8 @@ extern "C" int vmr_char_cnn_fwd(const int64_t* char_ids, const float* table, con
     hipLaunchKernelGGL((char_cnn_fwd_kernel<TT, WPBV, CMV>), grid, dim3(1024), lds, (hipStream_t)stream, a, (TT*)out, ldo,  \
                        amax);                                                                                              \
   } while (0)
-  if (dtype == VMR_BF16) { if (C <= 8) VMR_CC_FWD(bf16_t, 8, 8); else VMR_CC_FWD(bf16_t, 8, 16); }
+  if (dtype == VMR_BF16 && wpb == 8) { if (C <= 8) VMR_CC_FWD(bf16_t, 8, 8); else VMR_CC_FWD(bf16_t, 8, 16); }
+  else if (dtype == VMR_BF16) { if (C <= 8) VMR_CC_FWD(bf16_t, 4, 8); else VMR_CC_FWD(bf16_t, 4, 16); }
   else { if (C <= 8) VMR_CC_FWD(float, 4, 8); else VMR_CC_FWD(float, 4, 16); }
 #undef VMR_CC_FWD
   VMR_LAUNCH_CHECK();
@@ -307,7 +319,7 @@ extern "C" int vmr_char_cnn_bwd(const void* dout, const void* out, int64_t ldo, 
   if (W == 0) return 0;
   CharCnnArgs a;
   fill_args(a, char_ids, table, w, b, oc, W, C, CD, drop_p, drop_seed, drop_step);
-  const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = dtype == VMR_BF16 ? 8 : 4, cp = C <= 8 ? 8 : 16;
+  const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = cc_wpb(dtype), cp = C <= 8 ? 8 : 16;
   const size_t lds = ((size_t)a.wtot * esz + 15) / 16 * 16 + (size_t)wpb * cp * CD * 4 + (size_t)wpb * a.OT * 8;
   VMR_CHECK(lds <= 160 * 1024, "vmr_char_cnn_bwd: operands do not fit LDS (%zu B)", lds);
   const int nblk = (W + wpb - 1) / wpb;
@@ -319,7 +331,8 @@ extern "C" int vmr_char_cnn_bwd(const void* dout, const void* out, int64_t ldo, 
     hipLaunchKernelGGL((char_cnn_bwd_kernel<TT, WPBV, CPV>), dim3(nblk), dim3(1024), lds, (hipStream_t)stream, a,          \
                        (const TT*)dout, (const TT*)out, ldo, amax, workspace, dtable);                                    \
   } while (0)
-  if (dtype == VMR_BF16) { if (cp == 8) VMR_CC_BWD(bf16_t, 8, 8); else VMR_CC_BWD(bf16_t, 8, 16); }
+  if (dtype == VMR_BF16 && wpb == 8) { if (cp == 8) VMR_CC_BWD(bf16_t, 8, 8); else VMR_CC_BWD(bf16_t, 8, 16); }
+  else if (dtype == VMR_BF16) { if (cp == 8) VMR_CC_BWD(bf16_t, 4, 8); else VMR_CC_BWD(bf16_t, 4, 16); }
   else { if (cp == 8) VMR_CC_BWD(float, 4, 8); else VMR_CC_BWD(float, 4, 16); }
 #undef VMR_CC_BWD
   VMR_LAUNCH_CHECK();
