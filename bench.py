@@ -314,9 +314,15 @@ def main():
     ops.GEMM2_HOOK = timer2
     cq_rec = []
 
+    CQ_REPS = 4     # the score kernel is a pure function of its inputs: launched 4x back to back between the two events so
+                    # that the ~8 us an event pair adds around ONE short launch in eager mode does not pass for kernel time
+
     def cq_hook(launch, B_, Ll, Ls, D_):
         s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s_.record(); launch(); e_.record()
+        s_.record()
+        for _ in range(CQ_REPS):
+            launch()
+        e_.record()
         cq_rec.append((s_, e_, B_, Ll, Ls, D_))
     ops.CQ_HOOK = cq_hook
     cqa_rec = []
@@ -401,7 +407,7 @@ def main():
         if cq_rec:
             # the CQAttention score kernel (north-star "attention score/softmax/context-gather"): algorithmic
             # bytes = read long + short operand, write both probability matrices (bf16); flops = the QK^T contraction
-            us = [s_.elapsed_time(e_) * 1e3 for (s_, e_, *_r) in cq_rec]
+            us = [s_.elapsed_time(e_) * 1e3 / CQ_REPS for (s_, e_, *_r) in cq_rec]
             _, _, B_, Ll, Ls, D_ = cq_rec[0]
             by = B_ * ((Ll + Ls) * D_ * 2 + 2 * Ll * ((Ls + 7) // 8 * 8) * 4)     # (fp32 probability pair)
             fl = 2.0 * B_ * Ll * Ls * D_
@@ -420,7 +426,7 @@ def main():
             # bytes: read C, Q once + write the [T, D] output once (the concat stays on chip in the ideal schedule).
             _, _, _, B_, Lc_, Lq_, D_ = fw[0]
             t_apply = sum(r[0].elapsed_time(r[1]) for r in fw) / len(fw) * 1e-3
-            t_score = sum(r[0].elapsed_time(r[1]) for r in cq_rec if r[3] == Lc_) / max(1, sum(1 for r in cq_rec if r[3] == Lc_)) * 1e-3
+            t_score = sum(r[0].elapsed_time(r[1]) / CQ_REPS for r in cq_rec if r[3] == Lc_) / max(1, sum(1 for r in cq_rec if r[3] == Lc_)) * 1e-3
             cqa = [r for r in timer.records if abs(r[2] - 2.0 * B_ * Lc_ * 4 * D_ * D_) < 1.0]        # [B*T, D, 4D] products
             t_lin = sum(r[0].elapsed_time(r[1]) for r in cqa) / max(1, len(cqa)) * 1e-3 if cqa else float("nan")
             flops = B_ * (2.0 * Lc_ * 4 * D_ * D_ + 3 * 2.0 * Lc_ * Lq_ * D_ + 2.0 * Lc_ * Lq_ * D_)
