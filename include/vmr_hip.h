@@ -379,7 +379,7 @@ int vmr_cq_apply_fwd(const void* ctx, const void* qry, const float* S_lm, const 
                      int Lq, int D, int dtype, void* stream);
 int vmr_cq_apply_bwd(const void* dcat4, const void* ctx, const void* qry, const float* S_lm, const float* St_lm,
                      void* dctx, void* dqry, float* parts, int B, int Lc, int Lq, int D, int dtype, void* stream);
-int vmr_cq_softmax_bwd_parts(const float* parts, const float* S_lm, const float* St_lm, float* dS_lm, float* dterm,
+int vmr_cq_softmax_bwd_parts(float* parts /* scratch: summed in place */, const float* S_lm, const float* St_lm, float* dS_lm, float* dterm,
                              int B, int Lc, int Lq, int D, void* stream);
 int vmr_cq_score_bwd(const void* lng, const void* sht, const float* dS_lm, void* dlng, void* dsht, int B, int Ll, int Ls,
                      int D, int dtype, void* stream);

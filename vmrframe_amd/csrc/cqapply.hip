@@ -471,7 +471,31 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
 //   context short (c = s, q = l): dS = S_ (dS_ - coldot_s(dS_ S_)) + S_t (dS_t - rowdot_l(dS_t S_t))
 //   dterm[s] = sum_l dS[l][s]   (the gradient of the rank-1 term that rides on the short stream)
 // =====================================================================================================================
-__global__ __launch_bounds__(1024) void cq_softmax_bwd_parts_kernel(const float* __restrict__ parts, int nparts,
+// parts[b][0][...] += sum_{p >= 1} parts[b][p][...] over ALL CUs: with one workgroup per clip the softmax-backward kernel
+// below pulled the 8 per-slice partial tiles (262 KB per clip, 16.8 MB) through 64 CUs at the per-CU HBM fetch rate
+// (~25 GB/s): 22 us of which ~10 were this sum
+__global__ __launch_bounds__(256) void cq_parts_presum_kernel(float* __restrict__ parts, int nparts, int64_t per_part4,
+                                                              int64_t total4) {
+  f32x4* p4 = reinterpret_cast<f32x4*>(parts);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / per_part4, j = i - b * per_part4;
+    f32x4* base = p4 + b * nparts * per_part4 + j;
+    f32x4 v[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v[p] = base[(int64_t)min(p, nparts - 1) * per_part4];
+    f32x4 acc = v[0];
+#pragma unroll
+    for (int p = 1; p < 8; ++p)
+      if (p < nparts) { acc[0] += v[p][0]; acc[1] += v[p][1]; acc[2] += v[p][2]; acc[3] += v[p][3]; }
+    for (int p = 8; p < nparts; ++p) {
+      const f32x4 w = base[(int64_t)p * per_part4];
+      acc[0] += w[0]; acc[1] += w[1]; acc[2] += w[2]; acc[3] += w[3];
+    }
+    base[0] = acc;
+  }
+}
+
+__global__ __launch_bounds__(1024) void cq_softmax_bwd_parts_kernel(const float* __restrict__ parts, int nparts, int nsum,
                                                                    const float* __restrict__ A1, const float* __restrict__ A2,
                                                                    float* __restrict__ dS, float* __restrict__ dterm, int Ll,
                                                                    int Ls, int SP, int LcP, int LqP, int ctx_long) {
@@ -494,7 +518,7 @@ __global__ __launch_bounds__(1024) void cq_softmax_bwd_parts_kernel(const float*
     if (s < Ls) {
       const float* pp = pb + (ctx_long ? (int64_t)l * LqP + s : (int64_t)s * LqP + l);
 #pragma unroll 8
-      for (int p = 0; p < nparts; ++p) { s1 += pp[(int64_t)p * 2 * tile]; s2 += pp[(int64_t)p * 2 * tile + tile]; }
+      for (int p = 0; p < nsum; ++p) { s1 += pp[(int64_t)p * 2 * tile]; s2 += pp[(int64_t)p * 2 * tile + tile]; }
     }
     g1[i] = s1; g2[i] = s2;
     p1[i] = A1[(int64_t)b * n + i];
@@ -678,7 +702,7 @@ extern "C" int vmr_cq_apply_bwd(const void* dcat4, const void* ctx, const void* 
   return 0;
 }
 
-extern "C" int vmr_cq_softmax_bwd_parts(const float* parts, const float* S_lm, const float* St_lm, float* dS_lm, float* dterm,
+extern "C" int vmr_cq_softmax_bwd_parts(float* parts, const float* S_lm, const float* St_lm, float* dS_lm, float* dterm,
                                         int B, int Lc, int Lq, int D, void* stream) {
   VMR_CHECK(parts && S_lm && St_lm && dS_lm && dterm, "vmr_cq_softmax_bwd_parts: null pointer");
   VMR_CHECK(D % DS == 0 && Lc >= 1 && Lq >= 1 && (Lc <= 32 || Lq <= 32), "vmr_cq_softmax_bwd_parts: bad dims");
@@ -688,8 +712,16 @@ extern "C" int vmr_cq_softmax_bwd_parts(const float* parts, const float* S_lm, c
   const size_t lds = ((size_t)4 * Ll * SP + SP + 1024) * 4;
   VMR_CHECK(lds <= 160 * 1024, "vmr_cq_softmax_bwd_parts: score tile %dx%d does not fit LDS", Ll, SP);
   if (int rc = set_lds((const void*)cq_softmax_bwd_parts_kernel, lds, "vmr_cq_softmax_bwd_parts")) return rc;
-  hipLaunchKernelGGL(cq_softmax_bwd_parts_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, parts, D / DS, S_lm, St_lm, dS_lm,
-                     dterm, Ll, Ls, SP, (Lc + 15) / 16 * 16, (Lq + 15) / 16 * 16, ctx_long);
+  const int LcP = (Lc + 15) / 16 * 16, LqP = (Lq + 15) / 16 * 16, nparts = D / DS;
+  int nsum = nparts;
+  if (nparts > 1 && ((uintptr_t)parts & 15) == 0) {   // (parts is scratch: the slice sum is left in slice 0)
+    const int64_t per4 = (int64_t)2 * LcP * LqP / 4, tot4 = per4 * B;
+    hipLaunchKernelGGL(cq_parts_presum_kernel, dim3((unsigned)min((int64_t)2048, (tot4 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, parts, nparts, per4, tot4);
+    nsum = 1;
+  }
+  hipLaunchKernelGGL(cq_softmax_bwd_parts_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, parts, nparts, nsum, S_lm, St_lm,
+                     dS_lm, dterm, Ll, Ls, SP, LcP, LqP, ctx_long);
   VMR_LAUNCH_CHECK();
   return 0;
 }
