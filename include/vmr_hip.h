@@ -358,6 +358,14 @@ int vmr_cq_score_supported(int Ll, int Ls, int D, int dtype);
 int vmr_cq_score_fwd(const void* lng, const void* short_op, const float* shortterm, const float* mask_long,
                      const float* mask_short, void* Srow, void* Scol, float* Pt_lm, float* Pv_lm, int B, int Ll,
                      int Ls, int D, int ldP, int orient, int dtype, void* stream);
+/* Same, with a workspace of vmr_cq_score_ws_floats(B) floats: when only the fp32 pair is requested, a clip's long
+ * rows are split over 4 workgroups (256 instead of 64 at cfg2: one workgroup per clip pulls its operands through ONE
+ * CU at the per-CU HBM fetch rate) and a second small launch normalises the softmax over the long index from the
+ * per-workgroup (max, sum) pairs. */
+int vmr_cq_score_ws_floats(int B);
+int vmr_cq_score_fwd_ws(const void* lng, const void* short_op, const float* shortterm, const float* mask_long,
+                        const float* mask_short, void* Srow, void* Scol, float* Pt_lm, float* Pv_lm, float* colstats, int B,
+                        int Ll, int Ls, int D, int ldP, int orient, int dtype, void* stream);
 
 /* ------------------------------------------------- CQAttention apply stage (fused) and the block's backward
  * reference models/layers.py:422-424: c2q = S_.Q, q2c = (S_.S_t^T).C [re-associated as S_.(S_t^T.C)],

@@ -105,6 +105,8 @@ SIGNATURES = {
     "vmr_resample_pad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     "vmr_cq_score_supported": [_I, _I, _I, _I],
     "vmr_cq_score_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vmr_cq_score_ws_floats": [_I],
+    "vmr_cq_score_fwd_ws": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vmr_cq_apply_supported": [_I, _I, _I, _I],
     "vmr_cq_apply_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vmr_cq_apply_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

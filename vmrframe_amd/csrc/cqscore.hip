@@ -20,18 +20,23 @@ struct CqArgs {
   const bf16_t* lng; const bf16_t* sht; const float* shortterm; const float* mask_long; const float* mask_short;
   bf16_t* Srow; bf16_t* Scol;      // nullable: the composed path's bf16 [B, rows, ldP] pair
   float* Pt32; float* Pv32;        // nullable: fp32 long-major [B, Ll, SP32] (softmax over t / over v) for cqapply.hip
+  float* cstat;                    // row-split launches: [B, gridDim.y, 32, 2] local column (max, sum of exp) per workgroup
   int Ll, Ls, D, ldP, orient, SP32;
 };
 
 // NKS = D / 32 k-steps, compile-time: the fragment pipeline below must be straight-line code.  (With a run-time trip
 // count and guarded re-requests hipcc put "s_waitcnt vmcnt(0)" in front of every MFMA pair -- 16 of the 32 k-steps each
 // paid a full HBM round trip, and the eight guarded shortterm / mask loads another eight: 18 us for 20 MB.)
-template <int NKS>
-__global__ __launch_bounds__(512) void cq_score_kernel(CqArgs a) {
+// NW waves = NW * 16 long rows per workgroup.  gridDim.y > 1 splits a clip's rows over workgroups (one workgroup per clip
+// pulls its 320 KB through ONE CU at the per-CU HBM fetch rate, ~25 GB/s: 64 active CUs = 15 us for 21 MB): the softmax
+// over the long index then leaves exp(s - local max) in Pv32 and the local (max, sum) pairs in cstat; cq_colnorm_kernel
+// rescales.
+template <int NKS, int NW>
+__global__ __launch_bounds__(NW * 64) void cq_score_kernel(CqArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int D = NKS * 32, RB = D * 2, CPRW = RB / 16;  // bytes / 16-B chunks per short-operand row
   unsigned char* Ss = smem;                                // [32][RB]
-  float* red = reinterpret_cast<float*>(smem + 32 * RB);   // [8 waves][32] column partials
+  float* red = reinterpret_cast<float*>(smem + 32 * RB);   // [NW waves][32] column partials
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
@@ -39,14 +44,14 @@ __global__ __launch_bounds__(512) void cq_score_kernel(CqArgs a) {
   const bf16_t* Sg = a.sht + (int64_t)b * a.Ls * D;
   // ---- short operand -> LDS (DMA, 1 KiB per wave-instruction; rows >= Ls re-read row Ls-1: masked out below)
   const int nblk = 32 * RB / 1024;
-  for (int j = wid; j < nblk; j += 8) {
+  for (int j = wid; j < nblk; j += NW) {
     const int flat = j * 64 + lane, row = flat / CPRW, sl = flat - row * CPRW;
     const int c = (sl & ~15) | ((sl & 15) ^ (row & 15));
     const bf16_t* src = Sg + (int64_t)min(row, a.Ls - 1) * D + c * 8;
     __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)(Ss + j * 1024), 16, 0, 0);
   }
   // ---- this wave's 16 long rows: fragments straight from HBM, 8 k-steps in flight
-  const int v0 = wid * 16;
+  const int v0 = ((int)blockIdx.y * NW + wid) * 16;
   const bool act = v0 < a.Ll;
   const int vi = min(v0 + (lane & 15), a.Ll - 1);
   const bf16_t* lrow = Lg + (int64_t)vi * D + (lane >> 4) * 8;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(512) void cq_score_kernel(CqArgs a) {
       const int t = j * 16 + (lane >> 4) * 4 + r;
       float m = red[t];
 #pragma unroll
-      for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w * 32 + t]);
+      for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w * 32 + t]);
       cm[j][r] = m;
     }
   __syncthreads();
@@ -158,8 +163,17 @@ __global__ __launch_bounds__(512) void cq_score_kernel(CqArgs a) {
       const int t = j * 16 + (lane >> 4) * 4 + r;
       float s = red[t];
 #pragma unroll
-      for (int w = 1; w < 8; ++w) s += red[w * 32 + t];
-      cs[j][r] = s > 0.f ? 1.f / s : 0.f;
+      for (int w = 1; w < NW; ++w) s += red[w * 32 + t];
+      if (gridDim.y > 1) {
+        if (wid == 0 && (lane & 15) == 0) {
+          float* q = a.cstat + (((int64_t)b * gridDim.y + blockIdx.y) * 32 + t) * 2;
+          q[0] = cm[j][r];
+          q[1] = s;
+        }
+        cs[j][r] = 1.f;           // (rescaled by cq_colnorm_kernel)
+      } else {
+        cs[j][r] = s > 0.f ? 1.f / s : 0.f;
+      }
     }
   if (!vok) return;
   // ---- outputs.  orient 0 (context = long): Srow = P_t, Scol = P_v, both [b, v, ldP] (8-byte stores);
@@ -191,6 +205,26 @@ __global__ __launch_bounds__(512) void cq_score_kernel(CqArgs a) {
   }
 }
 
+// second pass of a row-split launch: Pv32[b, v, t] *= exp(m_q[t] - M[t]) / sum_q' s_q'[t] exp(m_q'[t] - M[t]), q = the
+// workgroup that owned row v.  One workgroup per (clip, row block).
+__global__ __launch_bounds__(256) void cq_colnorm_kernel(float* __restrict__ Pv32, const float* __restrict__ cstat, int Ll,
+                                                         int SP32, int rows_per) {
+  __shared__ float fac[32];
+  const int b = blockIdx.x, q = blockIdx.y, nsplit = gridDim.y, tid = threadIdx.x;
+  if (tid < 32) {
+    const float* st = cstat + (int64_t)b * nsplit * 64 + tid * 2;
+    float M = -INFINITY;
+    for (int i = 0; i < nsplit; ++i) M = fmaxf(M, st[i * 64]);
+    float S = 0.f;
+    for (int i = 0; i < nsplit; ++i) S += (st[i * 64] > -INFINITY) ? st[i * 64 + 1] * __expf(st[i * 64] - M) : 0.f;
+    fac[tid] = (S > 0.f && st[q * 64] > -INFINITY) ? __expf(st[q * 64] - M) / S : 0.f;
+  }
+  __syncthreads();
+  const int r0 = q * rows_per, nr = min(rows_per, Ll - r0);
+  float* P = Pv32 + ((int64_t)b * Ll + r0) * SP32;
+  for (int i = tid; i < nr * SP32; i += 256) P[i] *= fac[i % SP32];
+}
+
 // orient 1 pads: columns Ll..ldP of every [t] row must be zero (the following GEMMs read ldP columns)
 __global__ __launch_bounds__(256) void cq_pad_zero_kernel(bf16_t* __restrict__ A, bf16_t* __restrict__ Bm, int64_t rows, int L,
                                                           int ldP) {
@@ -209,9 +243,13 @@ extern "C" int vmr_cq_score_supported(int Ll, int Ls, int D, int dtype) {
   return dtype == VMR_BF16 && Ll >= 1 && Ll <= 128 && Ls >= 1 && Ls <= 32 && D % 256 == 0 && D >= 256 && D <= 2048;
 }
 
-extern "C" int vmr_cq_score_fwd(const void* lng, const void* sht, const float* shortterm, const float* mask_long,
-                                const float* mask_short, void* Srow, void* Scol, float* Pt_lm, float* Pv_lm, int B, int Ll,
-                                int Ls, int D, int ldP, int orient, int dtype, void* stream) {
+extern "C" int vmr_cq_score_ws_floats(int B) { return B * 8 * 64; }
+
+// colstats != nullptr (vmr_cq_score_ws_floats(B) floats) and only the fp32 pair requested: a clip's rows are split over
+// workgroups of 2 waves (256 instead of 64 workgroups at cfg2) + the column-normalisation pass
+extern "C" int vmr_cq_score_fwd_ws(const void* lng, const void* sht, const float* shortterm, const float* mask_long,
+                                   const float* mask_short, void* Srow, void* Scol, float* Pt_lm, float* Pv_lm, float* colstats,
+                                   int B, int Ll, int Ls, int D, int ldP, int orient, int dtype, void* stream) {
   VMR_CHECK(lng && sht && shortterm && mask_long && mask_short, "vmr_cq_score_fwd: null pointer");
   VMR_CHECK((Srow && Scol) || (Pt_lm && Pv_lm), "vmr_cq_score_fwd: no output requested");
   VMR_CHECK((!Srow) == (!Scol) && (!Pt_lm) == (!Pv_lm), "vmr_cq_score_fwd: outputs come in pairs");
@@ -224,21 +262,42 @@ extern "C" int vmr_cq_score_fwd(const void* lng, const void* sht, const float* s
   a.lng = (const bf16_t*)lng; a.sht = (const bf16_t*)sht; a.shortterm = shortterm; a.mask_long = mask_long;
   a.mask_short = mask_short; a.Srow = (bf16_t*)Srow; a.Scol = (bf16_t*)Scol;
   a.Pt32 = Pt_lm; a.Pv32 = Pv_lm; a.SP32 = (Ls + 7) / 8 * 8;
-  a.Ll = Ll; a.Ls = Ls; a.D = D; a.ldP = ldP; a.orient = orient;
+  a.Ll = Ll; a.Ls = Ls; a.D = D; a.ldP = ldP; a.orient = orient; a.cstat = colstats;
   const int smem = 32 * D * 2 + 8 * 32 * 4;
+  static int g_split = -1;
+  if (g_split < 0) {
+    const char* e = getenv("VMR_CQ_SPLIT");
+    g_split = e ? atoi(e) : 0;   // measured at cfg2: 10.5 us + 5.1 us (column normalisation) against 15.0 us in one launch
+  }
+  const bool split = g_split && colstats && !Srow && Pt_lm && Ll > 32;
   if (smem > 64 * 1024) {
     static thread_local bool done = false;
     if (!done) {
-      for (const void* f : {(const void*)cq_score_kernel<32>, (const void*)cq_score_kernel<40>, (const void*)cq_score_kernel<48>, (const void*)cq_score_kernel<56>,
-                            (const void*)cq_score_kernel<64>}) {
+      for (const void* f : {(const void*)cq_score_kernel<32, 8>, (const void*)cq_score_kernel<40, 8>, (const void*)cq_score_kernel<48, 8>,
+                            (const void*)cq_score_kernel<56, 8>, (const void*)cq_score_kernel<64, 8>, (const void*)cq_score_kernel<32, 2>,
+                            (const void*)cq_score_kernel<40, 2>, (const void*)cq_score_kernel<48, 2>, (const void*)cq_score_kernel<56, 2>,
+                            (const void*)cq_score_kernel<64, 2>}) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return vmr_fail(-5, "vmr_cq_score_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
       }
       done = true;
     }
   }
+  if (split) {
+    const int nsplit = (Ll + 31) / 32;
+    switch (D / 256) {
+#define VMR_CQ_CASE(n) case n: hipLaunchKernelGGL((cq_score_kernel<n * 8, 2>), dim3(B, nsplit), dim3(128), smem, (hipStream_t)stream, a); break
+      VMR_CQ_CASE(1); VMR_CQ_CASE(2); VMR_CQ_CASE(3); VMR_CQ_CASE(4); VMR_CQ_CASE(5); VMR_CQ_CASE(6); VMR_CQ_CASE(7); VMR_CQ_CASE(8);
+#undef VMR_CQ_CASE
+      default: return vmr_fail(-2, "vmr_cq_score_fwd: unsupported D %d", D);
+    }
+    VMR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cq_colnorm_kernel, dim3(B, nsplit), dim3(256), 0, (hipStream_t)stream, Pv_lm, colstats, Ll, a.SP32, 32);
+    VMR_LAUNCH_CHECK();
+    return 0;
+  }
   switch (D / 256) {
-#define VMR_CQ_CASE(n) case n: hipLaunchKernelGGL(cq_score_kernel<n * 8>, dim3(B), dim3(512), smem, (hipStream_t)stream, a); break
+#define VMR_CQ_CASE(n) case n: hipLaunchKernelGGL((cq_score_kernel<n * 8, 8>), dim3(B), dim3(512), smem, (hipStream_t)stream, a); break
     VMR_CQ_CASE(1); VMR_CQ_CASE(2); VMR_CQ_CASE(3); VMR_CQ_CASE(4); VMR_CQ_CASE(5); VMR_CQ_CASE(6); VMR_CQ_CASE(7); VMR_CQ_CASE(8);
 #undef VMR_CQ_CASE
     default: return vmr_fail(-2, "vmr_cq_score_fwd: unsupported D %d", D);
@@ -251,4 +310,11 @@ extern "C" int vmr_cq_score_fwd(const void* lng, const void* sht, const float* s
     VMR_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int vmr_cq_score_fwd(const void* lng, const void* sht, const float* shortterm, const float* mask_long,
+                                const float* mask_short, void* Srow, void* Scol, float* Pt_lm, float* Pv_lm, int B, int Ll,
+                                int Ls, int D, int ldP, int orient, int dtype, void* stream) {
+  return vmr_cq_score_fwd_ws(lng, sht, shortterm, mask_long, mask_short, Srow, Scol, Pt_lm, Pv_lm, nullptr, B, Ll, Ls, D, ldP,
+                             orient, dtype, stream);
 }

@@ -1745,10 +1745,12 @@ class _CQBlock(torch.autograd.Function):
         st = shortterm.contiguous().float()
         lib, stream = L.lib(), L.stream_ptr()
 
+        cstat = torch.empty(lib.vmr_cq_score_ws_floats(B), device=ctx.device, dtype=torch.float32)
+
         def launch():
-            L.check(lib.vmr_cq_score_fwd(lng.data_ptr(), short_op.data_ptr(), st.data_ptr(), mask_long.data_ptr(),
-                                         mask_short.data_ptr(), None, None, Pt.data_ptr(), Pv.data_ptr(), B, Ll, Ls, D, 0,
-                                         orient, L.dtype_code(lng), stream), "vmr_cq_score_fwd")
+            L.check(lib.vmr_cq_score_fwd_ws(lng.data_ptr(), short_op.data_ptr(), st.data_ptr(), mask_long.data_ptr(),
+                                            mask_short.data_ptr(), None, None, Pt.data_ptr(), Pv.data_ptr(), cstat.data_ptr(),
+                                            B, Ll, Ls, D, 0, orient, L.dtype_code(lng), stream), "vmr_cq_score_fwd_ws")
         if CQ_HOOK is not None:
             CQ_HOOK(launch, B, Ll, Ls, D)
         else:
