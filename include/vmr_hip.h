@@ -363,6 +363,7 @@ int vmr_cq_score_fwd(const void* lng, const void* short_op, const float* shortte
  * CU at the per-CU HBM fetch rate) and a second small launch normalises the softmax over the long index from the
  * per-workgroup (max, sum) pairs. */
 int vmr_cq_score_ws_floats(int B);
+int vmr_debug_set_cq_split(int mode); /* test / A-B utility: 1 = row-split form where possible, 0 = single launch (default), -1 = re-read VMR_CQ_SPLIT */
 int vmr_cq_score_fwd_ws(const void* lng, const void* short_op, const float* shortterm, const float* mask_long,
                         const float* mask_short, void* Srow, void* Scol, float* Pt_lm, float* Pv_lm, float* colstats, int B,
                         int Ll, int Ls, int D, int ldP, int orient, int dtype, void* stream);

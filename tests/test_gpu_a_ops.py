@@ -993,3 +993,35 @@ def test_transpose_batched_exact(dev):
     L.check(L.lib().vmr_transpose_batched(items, len(shapes), L.stream_ptr()), "vmr_transpose_batched")
     for a, b, shp in zip(srcs, dsts, shapes):
         assert torch.equal(b, a.t().contiguous()), shp
+
+
+def test_cq_score_row_split_equals_single_launch(dev):
+    """vmr_cq_score_fwd_ws: a clip's long rows over 4 workgroups + the column-normalisation pass against the one-launch
+    form -- the softmax over the short index bit-equal, the softmax over the long index to fp32 rounding; ragged
+    lengths and fully masked row blocks (padded frames at the end of a clip) included."""
+    from vmrframe_amd import _lib as L
+    lib = L.lib()
+    B, Ll, Ls, D = 6, 128, 20, 256
+    torch.manual_seed(5)
+    lng = (torch.randn(B, Ll, D, device=dev) / 4).to(torch.bfloat16)
+    sht = (torch.randn(B, Ls, D, device=dev) / 4).to(torch.bfloat16)
+    st = torch.randn(B, Ls, device=dev)
+    ml = torch.ones(B, Ll, device=dev)
+    ms = torch.ones(B, Ls, device=dev)
+    ml[1, 70:] = 0; ml[2, 20:] = 0; ms[3, 11:] = 0; ml[4, 96:] = 0
+    SP = (Ls + 7) // 8 * 8
+    outs = []
+    try:
+        for mode in (0, 1):
+            lib.vmr_debug_set_cq_split(mode)
+            Pt = torch.empty(B, Ll, SP, device=dev); Pv = torch.empty_like(Pt)
+            ws = torch.empty(lib.vmr_cq_score_ws_floats(B), device=dev)
+            L.check(lib.vmr_cq_score_fwd_ws(lng.data_ptr(), sht.data_ptr(), st.data_ptr(), ml.data_ptr(), ms.data_ptr(), None, None,
+                                            Pt.data_ptr(), Pv.data_ptr(), ws.data_ptr(), B, Ll, Ls, D, 0, 0, L.BF16, L.stream_ptr()),
+                    "vmr_cq_score_fwd_ws")
+            outs.append((Pt, Pv))
+    finally:
+        lib.vmr_debug_set_cq_split(-1)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=2e-6, atol=1e-9)
+    assert float(outs[1][1][:, :, :Ls].sum(1).sub(1).abs().max()) < 1e-5      # columns still sum to one over the long index

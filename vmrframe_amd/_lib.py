@@ -106,6 +106,7 @@ SIGNATURES = {
     "vmr_cq_score_supported": [_I, _I, _I, _I],
     "vmr_cq_score_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vmr_cq_score_ws_floats": [_I],
+    "vmr_debug_set_cq_split": [_I],
     "vmr_cq_score_fwd_ws": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vmr_cq_apply_supported": [_I, _I, _I, _I],
     "vmr_cq_apply_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -243,6 +243,11 @@ extern "C" int vmr_cq_score_supported(int Ll, int Ls, int D, int dtype) {
   return dtype == VMR_BF16 && Ll >= 1 && Ll <= 128 && Ls >= 1 && Ls <= 32 && D % 256 == 0 && D >= 256 && D <= 2048;
 }
 
+static int g_split = -1;   // VMR_CQ_SPLIT / vmr_debug_set_cq_split
+extern "C" int vmr_debug_set_cq_split(int mode) {
+  g_split = mode;
+  return 0;
+}
 extern "C" int vmr_cq_score_ws_floats(int B) { return B * 8 * 64; }
 
 // colstats != nullptr (vmr_cq_score_ws_floats(B) floats) and only the fp32 pair requested: a clip's rows are split over
@@ -264,7 +269,6 @@ extern "C" int vmr_cq_score_fwd_ws(const void* lng, const void* sht, const float
   a.Pt32 = Pt_lm; a.Pv32 = Pv_lm; a.SP32 = (Ls + 7) / 8 * 8;
   a.Ll = Ll; a.Ls = Ls; a.D = D; a.ldP = ldP; a.orient = orient; a.cstat = colstats;
   const int smem = 32 * D * 2 + 8 * 32 * 4;
-  static int g_split = -1;
   if (g_split < 0) {
     const char* e = getenv("VMR_CQ_SPLIT");
     g_split = e ? atoi(e) : 0;   // measured at cfg2: 10.5 us + 5.1 us (column normalisation) against 15.0 us in one launch
