@@ -414,7 +414,13 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict_
 // register footprint -> many short waves resident: this kernel is latency-, not bandwidth-bound).
 // dn[s] = sum_k w[k]*du[s-k+3];  dw[k] += sum_s du[s]*n[s+k-3].  The 4 waves' dw partials are
 // combined in LDS and stored as one partial row per workgroup (colreduce_kernel sums them).
-constexpr int DWB_CH = 2, DWB_SLICE = 64 * DWB_CH;
+#ifndef VMR_DWB_CH
+#define VMR_DWB_CH 2
+#endif
+constexpr int DWB_CH = VMR_DWB_CH, DWB_SLICE = 64 * DWB_CH;
+template <typename T, int N> struct VecN;
+template <typename T> struct VecN<T, 2> : Vec2<T> {};
+template <typename T> struct VecN<T, 4> : Vec4<T> {};
 
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ du, const T* __restrict__ x,
@@ -460,8 +466,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
     const int64_t off = ((int64_t)b * S + sc) * D + c0c;
     const float mean = mean_i[(int64_t)b * S + sc], rstd = rstd_i[(int64_t)b * S + sc];
     float xv[CHN], dv[CHN];
-    Vec2<T>::load(du + off, dv);
-    Vec2<T>::load(x + off, xv);
+    VecN<T, CHN>::load(du + off, dv);
+    VecN<T, CHN>::load(x + off, xv);
     // multiply by a 0/1 mask (NOT a select): the compiler must keep the loads unconditional, so all
     // loads of a chunk are in flight together; a select lets it sink each load into its own branch
     const float m = valid ? 1.f : 0.f;
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
 #pragma unroll
           for (int k = 0; k < 7; ++k) aw[ch][k] += wdu[3][ch] * wn[k][ch];  // du[s] * n[s+k-3]
         }
-        if (act) Vec2<T>::store(dn + ((int64_t)b * S + s) * D + c0, o);
+        if (act) VecN<T, CHN>::store(dn + ((int64_t)b * S + s) * D + c0, o);
       }
     }
   }
