@@ -88,34 +88,51 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const T* __restrict_
   const int64_t rend = min(rows, rbeg + rows_per_block);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c0 < D) {
-    for (int64_t r = rbeg + rl; r < rend; r += 8) {
-      float g[8];
-      Vec8<T>::load(dy + r * ld + c0, g);
-      if (MODE == 1) {
-        float hv[8];
-        Vec8<T>::load(h + r * ld + c0, hv);
+    // RB rows per iteration: their loads (index-clamped, unconditional) are issued together -- one row per iteration was a
+    // chain of dependent HBM round trips (3.2 TB/s)
+#ifndef VMR_RBB_RB
+#define VMR_RBB_RB 4
+#endif
+    constexpr int RB = VMR_RBB_RB;
+    typedef __attribute__((ext_vector_type(8))) T TV8;
+    for (int64_t r0 = rbeg + rl; r0 < rend; r0 += 8 * RB) {
+      TV8 gv[RB], hv8[RB];
+      uint32_t hb[RB];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = hv[e] > 0.f ? g[e] * scale : 0.f;
-        Vec8<T>::store(dz + r * ld + c0, g);
-      } else if (MODE == 3) {   // h = bit matrix uint8 [rows][D/8]: this thread's 8 columns are one byte
-        const uint32_t hb = reinterpret_cast<const unsigned char*>(h)[r * (D >> 3) + (c0 >> 3)];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = ((hb >> e) & 1) ? g[e] * scale : 0.f;
-        Vec8<T>::store(dz + r * ld + c0, g);
-      } else if (MODE == 2 || MODE == 4) {
-        const uint32_t keep = vmr_keep8(seed, (uint64_t)r * D + c0, thresh);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = ((keep >> e) & 1) ? g[e] * scale : 0.f;
-        if (MODE == 4) {   // + the gradient of the tensor's other consumer (h), one pass instead of a separate add
-          float hv[8];
-          Vec8<T>::load(h + r * ld + c0, hv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) g[e] += hv[e];
-        }
-        Vec8<T>::store(dz + r * ld + c0, g);
+      for (int u = 0; u < RB; ++u) {
+        const int64_t r = min(r0 + 8 * u, rows - 1);
+        gv[u] = *reinterpret_cast<const TV8*>(dy + r * ld + c0);
+        if (MODE == 1 || MODE == 4) hv8[u] = *reinterpret_cast<const TV8*>(h + r * ld + c0);
+        if (MODE == 3) hb[u] = reinterpret_cast<const unsigned char*>(h)[r * (D >> 3) + (c0 >> 3)];
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += g[e];
+      for (int u = 0; u < RB; ++u) {
+        const int64_t r = r0 + 8 * u;
+        if (r >= rend) continue;
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = (float)gv[u][e];
+        if (MODE == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = (float)hv8[u][e] > 0.f ? g[e] * scale : 0.f;
+          Vec8<T>::store(dz + r * ld + c0, g);
+        } else if (MODE == 3) {   // h = bit matrix uint8 [rows][D/8]: this thread's 8 columns are one byte
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = ((hb[u] >> e) & 1) ? g[e] * scale : 0.f;
+          Vec8<T>::store(dz + r * ld + c0, g);
+        } else if (MODE == 2 || MODE == 4) {
+          const uint32_t keep = vmr_keep8(seed, (uint64_t)r * D + c0, thresh);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = ((keep >> e) & 1) ? g[e] * scale : 0.f;
+          if (MODE == 4) {   // + the gradient of the tensor's other consumer (h), one pass instead of a separate add
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] += (float)hv8[u][e];
+          }
+          Vec8<T>::store(dz + r * ld + c0, g);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += g[e];
+      }
     }
   }
   if (!db) return;
