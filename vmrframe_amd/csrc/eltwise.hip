@@ -87,10 +87,11 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const T* __restrict__ a, c
 // quads with leading dimension ld4 (quads)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dst,
                                                             int nsplit, int64_t n4, int64_t stride4, int cols4,
-                                                            int64_t ld4) {
+                                                            int64_t ld4, int valid4) {
   const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
   f32x4* d4 = reinterpret_cast<f32x4*>(dst);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    if (valid4 && (int)(i % cols4) >= valid4) continue;   // zero-padded K columns of the slab: no destination
     const int64_t o = cols4 ? (i / cols4) * ld4 + (i % cols4) : i;
     f32x4 acc = d4[o];
     for (int k = 0; k < nsplit; ++k) {
@@ -171,11 +172,14 @@ extern "C" int vmr_splitk_reduce(const float* slab, float* dst, int nsplit, int6
   VMR_CHECK(n % 4 == 0 && ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0,
             "vmr_splitk_reduce: needs 16-byte aligned buffers and n %% 4 == 0");
   if (cols == ld_dst) cols = 0;
-  VMR_CHECK(cols == 0 || (cols % 4 == 0 && ld_dst % 4 == 0 && ld_dst >= cols && n % cols == 0),
+  VMR_CHECK(cols == 0 || (cols % 4 == 0 && ld_dst % 4 == 0 && ld_dst > 0 && n % cols == 0),
             "vmr_splitk_reduce: cols / ld_dst must be multiples of 4");
   if (n == 0) return 0;
+  // ld_dst < cols: the slab rows carry zero-padded K columns (a [N, 500] weight whose product ran at K = 512): the
+  // destination is dense [rows, ld_dst] and only the first ld_dst columns of each slab row are reduced
+  const int valid4 = (cols && ld_dst < cols) ? (int)(ld_dst / 4) : 0;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((int64_t)4096, (n / 4 + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, slab, dst, nsplit, n / 4, n / 4, cols / 4, ld_dst / 4);
+                     (hipStream_t)stream, slab, dst, nsplit, n / 4, n / 4, cols / 4, ld_dst / 4, valid4);
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_dbg_kernel(vmr_gemm_t g, 
 struct ReduceJob {   // dst[i] += sum_k slab[k][i] in 16-byte quads (the split-K second stage of an EARLIER product)
   const float* slab;
   float* dst;
-  int nsplit, cols4, nblocks;
+  int nsplit, cols4, nblocks, valid4;   // valid4 > 0: only the first valid4 float4 columns of a slab row have a destination
   int64_t n4, ld4;
 };
 
@@ -1085,6 +1085,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma2_kernel(vmr_gemm_t g1, i
     const f32x4* s4 = reinterpret_cast<const f32x4*>(rj.slab);
     f32x4* d4 = reinterpret_cast<f32x4*>(rj.dst);
     for (int64_t i = (int64_t)(bid - nblk12) * 256 + threadIdx.x; i < rj.n4; i += (int64_t)rj.nblocks * 256) {
+      if (rj.valid4 && (int)(i % rj.cols4) >= rj.valid4) continue;
       const int64_t o = rj.cols4 ? (i / rj.cols4) * rj.ld4 + (i % rj.cols4) : i;
       f32x4 acc = d4[o];
       for (int k = 0; k < rj.nsplit; ++k) {
@@ -1528,7 +1529,7 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
 extern "C" int vmr_gemm2_reduce(const vmr_gemm_t* p1, const vmr_gemm_t* p2, const float* slab, float* dst, int nsplit, int64_t n,
                                 int cols, int64_t ld_dst, void* stream) {
   VMR_CHECK(p1 && p2, "vmr_gemm2: null descriptor");
-  VMR_CHECK(!slab || (dst && nsplit > 0 && n % 4 == 0 && (cols == 0 || (cols % 4 == 0 && ld_dst % 4 == 0 && ld_dst >= cols && n % cols == 0))),
+  VMR_CHECK(!slab || (dst && nsplit > 0 && n % 4 == 0 && (cols == 0 || (cols % 4 == 0 && ld_dst % 4 == 0 && ld_dst > 0 && n % cols == 0))),
             "vmr_gemm2_reduce: bad reduction job");
   static int g_merge = -1;
   if (g_merge < 0) {
@@ -1581,6 +1582,8 @@ extern "C" int vmr_gemm2_reduce(const vmr_gemm_t* p1, const vmr_gemm_t* p2, cons
   memset(&rj, 0, sizeof(rj));
   if (slab && n > 0) {
     rj.slab = slab; rj.dst = dst; rj.nsplit = nsplit; rj.n4 = n / 4; rj.cols4 = cols / 4; rj.ld4 = ld_dst / 4;
+    if (cols && ld_dst == cols) rj.cols4 = 0;                  // dense
+    rj.valid4 = (cols && ld_dst < cols) ? (int)(ld_dst / 4) : 0;   // zero-padded K columns: see vmr_splitk_reduce
     rj.nblocks = (int)min((int64_t)384, (n / 4 + 255) / 256);
   }
   const int smem = TALL_SMEM;   // >= both variants' two-stage rings (direct epilogues: no staging tile)

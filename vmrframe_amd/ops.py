@@ -558,9 +558,11 @@ class _Linear(torch.autograd.Function):
             dzb = dyb
             # plain linear layer: the bias gradient (column sums of dz) rides on the weight-gradient GEMM below
             # (vmr_gemm_t.a_colsum) when that GEMM accumulates straight into the arena
+            kf0 = int(np.prod(wshapes[0][1:]))
             colsum_in_gemm = (has_bias and bgrad is not None and db2 is None and
                               all(main_grad(w) is not None for w in ctx.weights) and
-                              (ctx.kslice is not None or all(int(np.prod(shp[1:])) == x.shape[1] for shp in wshapes)))
+                              (ctx.kslice is not None or all(int(np.prod(shp[1:])) == x.shape[1] for shp in wshapes) or
+                               (len(wshapes) == 1 and kf0 < x.shape[1] and kf0 % 4 == 0 and USE_SLABS and M >= 256)))
             if has_bias and not colsum_in_gemm:
                 L.check(lib.vmr_relu_bwd_bias(0, dyb.data_ptr(), None, None, db.data_ptr(), M, Np, Np, 1.0, dt, 0.0, 0,
                                               None, _ptr(db2), dbs, st), "vmr_relu_bwd_bias")
@@ -601,7 +603,10 @@ class _Linear(torch.autograd.Function):
         slots = [main_grad(w) for w in ctx.weights]
         ks = ctx.kslice
         kfull = [int(np.prod(shp[1:])) for shp in wshapes]
-        if all(g is not None for g in slots) and (ks is not None or all(k == Kp for k in kfull)):
+        # (a single weight whose K was zero-padded for the GEMM -- V = 500 -> 512, 400 -> 512 -- takes the arena path too:
+        #  its slab rows are Kp wide, the reduction writes the first K columns of each into the dense [N, K] slot)
+        kpadded = ks is None and len(slots) == 1 and kfull[0] < Kp and kfull[0] % 4 == 0 and USE_SLABS and M >= 256
+        if all(g is not None for g in slots) and (ks is not None or all(k == Kp for k in kfull) or kpadded):
             # accumulate straight into the flat gradient arena: no zero-fill, no autograd add
             side = DW_SIDE_STREAM
             if side is not None:
@@ -625,6 +630,8 @@ class _Linear(torch.autograd.Function):
                     # (a held-back single-round dX product will share this launch: fewer, longer splits)
                     merged = held is not None and _cdiv(M, 160) * _cdiv(Kp, 128) <= 512
                     sk_ = splitk_for(n, Kp, M, SPLITK_TARGET_MERGED if merged else 0)
+                    if kpadded:
+                        sk_ = max(2, sk_)    # (always through slabs: a direct accumulation would need ldc = K < Kp)
                     if ks is not None:       # gradient of the column slice, in place inside the full matrix
                         g_ = g_.view(n, kf)[:, ks[0]:ks[1]]
                     if sk_ > 1 and USE_SLABS:
