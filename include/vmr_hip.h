@@ -333,7 +333,9 @@ int vmr_eltwise(int op, const void* a, const void* b, const void* c, const void*
 /* dst += sum_k slab[k] (fp32): second stage of a split-K GEMM whose splits were written as plain
  * slabs (VMR_EPI_SLAB) instead of float atomics.  slab: [nsplit][n] contiguous; dst: n elements,
  * contiguous when cols == 0, else rows of `cols` elements with leading dimension ld_dst (the
- * gradient of a column slice of a weight matrix inside the arena). */
+ * gradient of a column slice of a weight matrix inside the arena).  ld_dst < cols: the slab rows carry zero-padded K
+ * columns (a [N, 500] weight whose product ran at K = 512); dst is dense [rows, ld_dst] and only the first ld_dst
+ * columns of every slab row are reduced. */
 int vmr_splitk_reduce(const float* slab, float* dst, int nsplit, int64_t n, int cols, int64_t ld_dst,
                       void* stream);
 /* out[m,n] = dtype(sum_k slab[k][m,n] + bias[n] + addend[m,n]) (bias fp32 [cols], addend dtype [rows,cols], both

@@ -172,6 +172,13 @@ def test_gemm_splitk_slabs_colsum(dev, shape):
     L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, M * N, N, N, L.stream_ptr()), "reduce")
     assert torch.equal(dst - 1, A.float().t() @ B.float())
     assert torch.equal(cs - 1, A.float().sum(0))
+    # slab rows wider than the destination (a weight whose K was zero-padded for the product: 500 -> 512): ld_dst < cols
+    # reduces the first ld_dst columns of every slab row into a dense [M, ld_dst] matrix
+    if N >= 128:
+        kf = N - 12
+        dst2 = torch.ones(M, kf, device=dev)
+        L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst2.data_ptr(), sk, M * N, N, kf, L.stream_ptr()), "reduce (padded K)")
+        assert torch.equal(dst2 - 1, (A.float().t() @ B.float())[:, :kf])
 
 
 @pytest.mark.parametrize("shape", [(512, 256, 256, 256, 256, 1024, 4), (9472, 1024, 128, 1024, 1024, 1024, 4),
