@@ -68,12 +68,14 @@ with open(os.path.join(P, f"{tag}_summary.md"), "w") as o:
     if bench:
         o.write(f"Bench line of the traced run: {bench['ms_per_step']} ms/step, {bench['value']} clips/s; roofline {json.dumps(bench.get('roofline'))}\n\n")
     o.write(f"Kernel time summed over the traced run: {tot/1e6:.1f} ms over {steps} steps = {tot/1e6/steps:.2f} ms/step.\n\n"
-            "| kernel | calls/step | avg us | us/step | % | MFMA util | HBM MB/launch |\n|---|---|---|---|---|---|---|\n")
+            "| kernel | calls/step | avg us | us/step | % | MFMA util | HBM MB/launch | HBM TB/s (of 8) |\n|---|---|---|---|---|---|---|---|\n")
     mu = {r[0]: r[4] for r in mrows}; hbm = {r[0]: r[4] for r in hb}
     for r in rows[:40]:
         k = r["Name"][:100]
         o.write(f"| `{k[:90]}` | {int(r['Calls'])/steps:.1f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e3/steps:.0f} | {float(r['Percentage']):.1f} | "
-                f"{mu.get(k, 0):.3f} | {hbm.get(k, 0)/1e6:.1f} |\n")
+                f"{mu.get(k, 0):.3f} | {hbm.get(k, 0)/1e6:.1f} | {hbm.get(k, 0)/max(float(r['AverageNs']), 1.0)/1e3:.2f} |\n")
     o.write("\nMFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); cross-check: SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 = the "
-            "launch's bf16 MFMA flops.  HBM MB = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH correction).\n")
+            "launch's bf16 MFMA flops.  HBM MB = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH correction), counted in the eager PMC passes; "
+            "HBM TB/s = that traffic / the replayed launch's average duration (L2 misses served by the Infinity Cache count as traffic, so a few "
+            "kernels read above what HBM alone delivers).\n")
 print(json.dumps(tj)[:600]); print("bench:", bench.get("ms_per_step"), bench.get("value"))
