@@ -484,8 +484,23 @@ class SeqPAN(nn.Module):
         X = self._cut(X, 2 if self.USE_DUAL_BLOCKS else 0)
         V3, T3 = ops.split_rows(X, Nv) if ops.CQ_TEE else (X[:Nv], X[Nv:])
         V3, T3 = V3.view(B, T, D), T3.view(B, Lq, D)
-        t2v = self._cq_attention("q2v_attn", V3, T3, vmask, tmask, dc)            # [Nv, D]
-        v2t = self._cq_attention("v2q_attn", T3, V3, tmask, vmask, dc)            # [Nt, D]
+        if ops.CQ_STREAMS and V3.is_cuda:
+            # experiment (VMR_CQ_STREAMS=1): the two directions are independent between here and CQConcatenate; the
+            # query-context one is a chain of latency-bound launches on 1280 rows that can hide under the other's GEMMs.
+            # autograd runs each node's backward on the stream of its forward, so the backward pass forks as well.
+            cur = torch.cuda.current_stream()
+            side = getattr(self, "_cq_side", None)
+            if side is None:
+                side = self._cq_side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            t2v = self._cq_attention("q2v_attn", V3, T3, vmask, tmask, dc)
+            with torch.cuda.stream(side):
+                v2t = self._cq_attention("v2q_attn", T3, V3, tmask, vmask, dc)
+            cur.wait_stream(side)
+            v2t.record_stream(cur)
+        else:
+            t2v = self._cq_attention("q2v_attn", V3, T3, vmask, tmask, dc)            # [Nv, D]
+            v2t = self._cq_attention("v2q_attn", T3, V3, tmask, vmask, dc)            # [Nt, D]
         # CQConcatenate (reference layers.py:462-468)
         # conv1d([context | pooled_query]) = context.W[:, :D]^T + (pooled.W[:, D:]^T + b)[clip]: the
         # [Nv, 2D] concat is never built -- the pooled half is a tiny [B, D] GEMM whose rows the main GEMM's

@@ -92,17 +92,33 @@ class PassState:
 
     def __init__(self):
         self.pending_reduce = None   # (slabs kept alive, dst, nsplit, n, cols, ld_dst)
+        self.pending_stream = None   # the stream the pending slabs were produced on
         self.deferred: List[tuple] = []   # (partials kept alive, out0, out1, nblocks, n0, n1, slots)
+        self.deferred_streams: List = []  # streams the queued partial rows were produced on
 
     def reset(self):
         """Drop (never launch) whatever a dead backward pass left behind: stale partials must not be added into the
         freshly zeroed gradient arena.  Called at every forward and from FlatAdamW.zero_grad()."""
         self.pending_reduce = None
+        self.pending_stream = None
         self.deferred.clear()
+        self.deferred_streams.clear()
+
+    @staticmethod
+    def _after(stream):
+        """The current stream waits for `stream` (a held-back second stage may be launched from another stream than
+        the one that produced its partials: two branches of the backward pass on two streams)."""
+        if stream is not None and torch.cuda.is_available():
+            cur = torch.cuda.current_stream()
+            if cur != stream:
+                cur.wait_stream(stream)
 
     # -- split-K second stage ---------------------------------------------------
     def take_reduce(self):
         rj, self.pending_reduce = self.pending_reduce, None
+        if rj is not None:
+            self._after(self.pending_stream)
+        self.pending_stream = None
         return rj
 
     def flush_reduce(self):
@@ -127,6 +143,7 @@ class PassState:
                     "vmr_splitk_reduce")
             return
         self.pending_reduce = (ws, dst, sk, n, cols, ld)
+        self.pending_stream = torch.cuda.current_stream() if ws.is_cuda else None
 
     # -- parameter-gradient column reductions -------------------------------------
     def defer_colreduce(self, part, out0, out1, nblocks, n0, n1, slots):
@@ -135,6 +152,10 @@ class PassState:
         # (queued on every call, not only the first of a pass: the flush is idempotent)
         torch.autograd.Variable._execution_engine.queue_callback(self.flush_colreduce)
         self.deferred.append((part, out0, out1, int(nblocks), int(n0), int(n1), int(slots)))
+        if part.is_cuda:
+            st = torch.cuda.current_stream()
+            if st not in self.deferred_streams:
+                self.deferred_streams.append(st)
 
     def flush_colreduce(self):
         if not self.deferred:
@@ -144,10 +165,13 @@ class PassState:
             it.part, it.out0, it.out1 = part.data_ptr(), o0.data_ptr(), o1.data_ptr()
             it.nblocks, it.n0, it.n1, it.slots = nb, n0, n1, sl
         n = len(self.deferred)
+        for st in self.deferred_streams:
+            self._after(st)
         try:
             L.check(L.lib().vmr_colreduce_batched(items, n, L.stream_ptr()), "vmr_colreduce_batched")
         finally:
             self.deferred.clear()
+            self.deferred_streams.clear()
 
 
 def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=None, residual=None, aux=None,
@@ -209,6 +233,7 @@ def gemm(A, B, Cmat, M, N, K, ta, tb, lda, ldb, ldc, *, dtype, flags=0, bias=Non
 
 
 MERGE_DX_DW = os.environ.get("VMR_MERGE_DX_DW", "1") != "0"
+CQ_STREAMS = os.environ.get("VMR_CQ_STREAMS", "0") != "0"   # experiment: the v2q CQAttention direction on a side stream
 CQ_TEE = os.environ.get("VMR_CQ_TEE", "1") != "0"          # dropout backward + other-consumer gradient in one kernel; one-concat row split
 AUX_BITS = os.environ.get("VMR_AUX_BITS", "1") != "0"      # ReLU / dropout masks of the conv-block products as bit matrices
 GROUP_DW = os.environ.get("VMR_GROUP_DW", "1") != "0"      # one weight-gradient product per grouped projection
