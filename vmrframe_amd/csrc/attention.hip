@@ -61,6 +61,20 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int ks = 0; ks < HD / 32; ++ks)
     qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)qi * a.q_row + ks * 32 + (lane >> 4) * 8);
+  // ---- the masks of this lane's query and keys, requested HERE (index-clamped, unconditional; oldest in the vmcnt
+  // order, so the counted wait below covers them): as 4 x NJ guarded loads inside the softmax they each got their own
+  // "s_waitcnt vmcnt(0)" from hipcc -- up to 32 dependent round trips per lane after the S phase
+  const uint32_t seed = vmr_seed(a.seed, a.step);   // (the device step counter: read with the operands, not mid-kernel)
+  const int zo = z / a.H;
+  const float rmv = a.mode == 0 ? a.rmask[(int64_t)zo * a.Lq + min(q0 + (lane & 15), a.Lq - 1)] : 1.f;
+  float cmv[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kc = min(j * 16 + (lane >> 4) * 4 + r, a.Lk - 1);
+      cmv[j][r] = a.mode == 0 ? a.cmask[(int64_t)zo * a.Lk + kc] : a.cmask[(int64_t)kc * a.cm_stride + zo];
+    }
   // ---- K and V of this (z) slice: global -> LDS DMA, 1 KiB per wave-instruction, images swizzled through
   // the per-lane SOURCE address.  K: k-contiguous rows, 16-B slot = chunk ^ (row&15) within 256 B;
   // V: [key][channel] rows, 32-B slot = channel-tile ^ swz3(key).  Rows >= Lk re-read row Lk-1 (their
@@ -111,8 +125,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
   // lane owns query q = q0 + (lane&15) and keys j*16 + (lane>>4)*4 + r
   const int q = q0 + (lane & 15);
   const bool qok = q < a.Lq;
-  const int zo = z / a.H;
-  const float rm = (a.mode == 0 && qok) ? a.rmask[(int64_t)zo * a.Lq + q] : 1.f;
+  const float rm = (a.mode == 0 && qok) ? rmv : 1.f;
   float mx = -INFINITY;
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
@@ -122,8 +135,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
       float x = -INFINITY;
       if (key < a.Lk) {
         x = st[j][r] * a.scale;
-        if (a.mode == 0) x += (1.0f - rm * a.cmask[(int64_t)zo * a.Lk + key]) * VMR_NEG_INF_MASK;
-        else x += a.cmask[(int64_t)key * a.cm_stride + zo];
+        if (a.mode == 0) x += (1.0f - rm * cmv[j][r]) * VMR_NEG_INF_MASK;
+        else x += cmv[j][r];
       }
       st[j][r] = x;
       mx = fmaxf(mx, x);
@@ -142,7 +155,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.f / sum;
-  const uint32_t seed = vmr_seed(a.seed, a.step);
   const uint32_t thresh = vmr_drop_thresh(a.drop_p);
   const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   // ---- P -> per-wave LDS image [query][key] (k-contiguous rows, 16-B chunk ^= query & PM), 8-byte writes
@@ -170,23 +182,44 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
   f32x4 ot[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) ot[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  // Every fragment read below is inline asm (common.h lds_read_tr): with the builtin, hipcc put "s_waitcnt vmcnt(0)" in
+  // front of the first transposed read -- it cannot see that the V blocks have landed -- which here waited for the P / Pk
+  // global stores just issued.  Groups of 8 channel tiles (16 reads, + the P fragment of the k-step): group g+1 is
+  // requested before the MFMAs of g, "at most 15 outstanding" retires g, and the registers are pinned behind the wait.
+  constexpr int NH8 = NT / 8, NG = (LKP / 32) * NH8;
+  static_assert(NT % 8 == 0, "channel tiles come in groups of 8");
+  bf16x8 vf[2][8], pfr[2];
+  auto issue = [&](int g) {
+    const int ks = g / NH8, hh = g % NH8;
+    if (hh == 0) {
+      const int prow_l = lane & 15, pc = ks * 4 + (lane >> 4);
+      pfr[ks & 1] = lds_read_b128_asm(Ps + prow_l * PRB + ((pc ^ (prow_l & PM)) << 4));
+    }
+    const int gq = lane >> 4, ii = lane & 15, qq = ii >> 2, p = ii & 3;
+    const int r = ks * 32 + 8 * gq + qq;
 #pragma unroll
-  for (int ks = 0; ks < LKP / 32; ++ks) {
-    const int prow_l = lane & 15, pc = ks * 4 + (lane >> 4);
-    const bf16x8 pf = *reinterpret_cast<const bf16x8*>(Ps + prow_l * PRB + ((pc ^ (prow_l & PM)) << 4));
-    const int g = lane >> 4, ii = lane & 15, qq = ii >> 2, p = ii & 3;
-    const int r = ks * 32 + 8 * g + qq;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int i = 0; i < 8; ++i) {
+      const int t = hh * 8 + i;
       const int a0 = r * RB + ((t ^ swz3(r)) << 5) + p * 8;
       const int a1 = (r + 4) * RB + ((t ^ swz3(r + 4)) << 5) + p * 8;
-      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Vs + a0));
-      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Vs + a1));
       union { struct { s16x4 l, h; } s; bf16x8 v; } u;
-      u.s.l = lo; u.s.h = hi;
-      ot[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf, ot[t], 0, 0, 0);
+      u.s.l = lds_read_tr(Vs + a0);
+      u.s.h = lds_read_tr(Vs + a1);
+      vf[g & 1][i] = u.v;
     }
+  };
+  issue(0);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) { issue(g + 1); lgkm_wait<15>(); }
+    else lgkm_wait<0>();
+    const int ks = g / NH8, hh = g % NH8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) frag_pin(vf[g & 1][i]);
+    if (hh == 0) frag_pin(pfr[ks & 1]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      ot[hh * 8 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[g & 1][i], pfr[ks & 1], ot[hh * 8 + i], 0, 0, 0);
   }
   if (qok) {
     bf16_t* Og = a.O + z1 * a.o_s1 + z2 * a.o_s2 + (int64_t)q * a.o_row;

@@ -33,8 +33,6 @@ struct AttnBwdArgs {
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
 __device__ __forceinline__ int swz3(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
 // [ROWS][128 channels] bf16 tile (256-B rows) global -> LDS by DMA, 1 KiB (4 rows) per wave-instruction,
@@ -59,22 +57,50 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned char* img, int rb, int 
   const int r = ks * 32 + 8 * g + qq;
   const int a0 = r * rb + ((t ^ (swz3(r) & sw_mask)) << 5) + p * 8;
   const int a1 = (r + 4) * rb + ((t ^ (swz3(r + 4) & sw_mask)) << 5) + p * 8;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a0));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a1));
   union { struct { s16x4 l, h; } s; bf16x8 v; } u;
-  u.s.l = lo; u.s.h = hi;
+  u.s.l = lds_read_tr(img + a0);      // inline asm (common.h): the builtin drains every LDS-DMA tile in flight
+  u.s.h = lds_read_tr(img + a1);
   return u.v;
+}
+
+// acc[t] += A_t(ks) . B(ks) over NKS 32-deep steps, t = 8 channel tiles.  Every fragment comes from an inline-asm LDS read
+// (ld_a / ld_b), so the waits are ours: group ks+1 (>= 17 reads) is requested before the MFMAs of ks, "at most 15
+// outstanding" then retires all of group ks (the LDS returns in order), and the registers are pinned behind the wait.
+template <int NKS, class FA, class FB>
+__device__ __forceinline__ void asm_product(f32x4 (&acc)[8], FA&& ld_a, FB&& ld_b) {
+  bf16x8 fa[2][8], fb[2];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) fa[0][t] = ld_a(t, 0);
+  fb[0] = ld_b(0);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < NKS) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) fa[cur ^ 1][t] = ld_a(t, ks + 1);
+      fb[cur ^ 1] = ld_b(ks + 1);
+      lgkm_wait<15>();
+    } else {
+      lgkm_wait<0>();
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) frag_pin(fa[cur][t]);
+    frag_pin(fb[cur]);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][t], fb[cur], acc[t], 0, 0, 0);
+  }
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() {
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   else if (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else static_assert(N == 0 || N == 1 || N == 2 || N == 4 || N == 9 || N == 10 || N == 12, "add the immediate");
+  else static_assert(N == 0 || N == 1 || N == 2 || N == 3 || N == 4 || N == 9 || N == 10 || N == 12, "add the immediate");
 }
 
 template <int HD, int LQP, int LKP>
@@ -110,6 +136,20 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
 #pragma unroll
   for (int ks = 0; ks < HD / 32; ++ks)
     dof[ks] = *reinterpret_cast<const bf16x8*>(Og + (int64_t)qi * a.do_row + ks * 32 + (lane >> 4) * 8);
+  // the forward's probabilities of this lane's (query, 4 keys per tile) pairs, requested with the operands (index-
+  // clamped, unconditional): as NJ guarded loads inside the softmax backward each got its own "s_waitcnt vmcnt(0)" from
+  // hipcc -- NJ dependent round trips in the middle of the kernel, draining the phase-2 tiles just requested as well
+  typedef __attribute__((ext_vector_type(2))) uint32_t pk_raw_t;
+  pk_raw_t pkraw[NJ];
+  {
+    const int64_t prow0 = (int64_t)z * a.Lq + qi;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int kc = min(j * 16 + (lane >> 4) * 4, max(a.ldP - 4, 0));
+      pkraw[j] = *reinterpret_cast<const pk_raw_t*>(a.Pk + prow0 * a.ldP + kc);
+    }
+  }
+  const uint32_t seed = vmr_seed(a.seed, a.step);   // (the device step counter: read here, not between the phase-2 tiles)
   // the image rows this wave will not write (query rows of inactive waves) must read as zero
   if (!qact && r0 < LQP) {
     for (int i = lane; i < 16 * PRB / 16; i += 64) {
@@ -146,7 +186,6 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
     const int q = r0 + (lane & 15);
     const bool qok = q < a.Lq;
     const int64_t prow = (int64_t)z * a.Lq + min(q, a.Lq - 1);
-    const uint32_t seed = vmr_seed(a.seed, a.step);
     const uint32_t thresh = vmr_drop_thresh(a.drop_p);
     const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     float pk[NJ][4], kp[NJ][4];
@@ -154,8 +193,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int key0 = j * 16 + (lane >> 4) * 4;
-      float pv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (qok && key0 < a.ldP) Vec4<bf16_t>::load(a.Pk + prow * a.ldP + key0, pv);
+      const float pv[4] = {__uint_as_float(pkraw[j][0] << 16), __uint_as_float(pkraw[j][0] & 0xFFFF0000u),
+                           __uint_as_float(pkraw[j][1] << 16), __uint_as_float(pkraw[j][1] & 0xFFFF0000u)};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = key0 + r;
@@ -197,19 +236,40 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (qact) {
+      const int qr = r0 + (lane & 15), half = (lane >> 4) & 1;
+      asm_product<LKP / 32>(
+          acc, [&](int t, int ks) { return frag_tr(bufX, 256, 7, t, ks, lane); },
+          [&](int ks) {
+            const int c32 = ks * 2 + (lane >> 5);
+            return lds_read_b128_asm(Simg + qr * PRB + ((c32 ^ (swz3(qr) & PSW)) << 5) + half * 16);
+          });
+    }
+    // dQ accumulation (the second attention form of a query stream adds into the first one's dQ): the eight old quads
+    // are requested together and BEFORE the next DMA tile (so the wait for them does not drain it); one load -> wait ->
+    // add -> store per channel tile was eight dependent round trips per half
+    // (read unconditionally -- dQ is allocated either way -- and masked to +0.0 when not accumulating)
+    pk_raw_t oldq[8];
+    const uint32_t accm = a.accum_dq ? 0xFFFFFFFFu : 0u;
+    {
+      const int qc = min(r0 + (lane & 15), a.Lq - 1);
+      const bf16_t* dqc = a.dQ + z1 * a.dq_s1 + z2 * a.dq_s2 + (int64_t)qc * a.dq_row + h * 128 + (lane >> 4) * 4;
+      // (inline-asm loads with our own counted wait: left to hipcc, the wait for these became "vmcnt(0)" -- after the
+      //  dO tile below had been requested -- or, with the first use under a branch, a second full drain after the stores)
 #pragma unroll
-      for (int ks = 0; ks < LKP / 32; ++ks) {
-        const int qr = r0 + (lane & 15);
-        const int c32 = ks * 2 + (lane >> 5), half = (lane >> 4) & 1;
-        const bf16x8 sf = *reinterpret_cast<const bf16x8*>(Simg + qr * PRB + ((c32 ^ (swz3(qr) & PSW)) << 5) + half * 16);
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(bufX, 256, 7, t, ks, lane), sf, acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < 8; ++t)
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(oldq[t]) : "v"(dqc + t * 16) : "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                     // bufX is free
     dma_tile<LQP, true>(Og, a.do_row, a.Lq, h * 128, bufX, wid, lane);          // dO_h -> bufX
+    wait_vm<NBQ>();                                   // the old dQ values (and Q_h before them) are here; dO_h flies
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      asm volatile("" : "+v"(oldq[t]));
+      const uint32_t w0 = oldq[t][0] & accm, w1 = oldq[t][1] & accm;
+      acc[t][0] += __uint_as_float(w0 << 16); acc[t][1] += __uint_as_float(w0 & 0xFFFF0000u);
+      acc[t][2] += __uint_as_float(w1 << 16); acc[t][3] += __uint_as_float(w1 & 0xFFFF0000u);
+    }
     if (qact) {
       const int q = r0 + (lane & 15);
       if (q < a.Lq) {
@@ -217,12 +277,6 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           float o4[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-          if (a.accum_dq) {
-            float old[4];
-            Vec4<bf16_t>::load(dq + t * 16, old);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o4[e] += old[e];
-          }
           Vec4<bf16_t>::store(dq + t * 16, o4);
         }
       }
@@ -232,15 +286,10 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (kact) {
-#pragma unroll
-      for (int ks = 0; ks < LQP / 32; ++ks) {
-        const bf16x8 sf = frag_tr(Simg, PRB, PSW, wid, ks, lane);
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(bufY, 256, 7, t, ks, lane), sf, acc[t], 0, 0, 0);
-      }
-    }
+    if (kact)
+      asm_product<LQP / 32>(
+          acc, [&](int t, int ks) { return frag_tr(bufY, 256, 7, t, ks, lane); },
+          [&](int ks) { return frag_tr(Simg, PRB, PSW, wid, ks, lane); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                     // bufY is free
     if (h + 1 < NH) dma_tile<LKP, true>(Kg, a.k_row, a.Lk, (h + 1) * 128, bufY, wid, lane);   // K_{h+1} -> bufY (swapped below)
@@ -261,15 +310,10 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (kact) {
-#pragma unroll
-      for (int ks = 0; ks < LQP / 32; ++ks) {
-        const bf16x8 pf = frag_tr(Pimg, PRB, PSW, wid, ks, lane);
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(bufX, 256, 7, t, ks, lane), pf, acc[t], 0, 0, 0);
-      }
-    }
+    if (kact)
+      asm_product<LQP / 32>(
+          acc, [&](int t, int ks) { return frag_tr(bufX, 256, 7, t, ks, lane); },
+          [&](int ks) { return frag_tr(Pimg, PRB, PSW, wid, ks, lane); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                     // bufX is free
     if (h + 1 < NH) dma_tile<LQP, true>(Qg, a.q_row, a.Lq, (h + 1) * 128, bufX, wid, lane);   // Q_{h+1} -> bufX

@@ -17,6 +17,33 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define WAVE 64
 
+// ------------------------------------------------- LDS reads under LDS-DMA
+// ds_read_b64_tr_b16 as inline asm, NOT __builtin_amdgcn_ds_read_tr16_b64_*: hipcc (ROCm 7.2) treats the builtin as an
+// LDS access that may alias an LDS-DMA write in flight and puts "s_waitcnt vmcnt(0)" in front of the first one after any
+// global_load_lds -- draining the very stage(s) the ring had just requested (a plain ds_read_b128 does not get that wait).
+// The asm read is invisible to the compiler's lgkmcnt bookkeeping: every user waits itself (lgkm_wait<N>) and then
+// pins the fragment registers (frag_pin) so the MFMAs cannot be scheduled above the wait.
+__device__ __forceinline__ s16x4 lds_read_tr(const unsigned char* p) {
+  typedef __attribute__((address_space(3))) const unsigned char lds_u8;
+  const uint32_t addr = (uint32_t)(uintptr_t)(lds_u8*)p;
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+template <int N> __device__ __forceinline__ void lgkm_wait() {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit field");
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void frag_pin(bf16x8& f) { asm volatile("" : "+v"(f)); }
+__device__ __forceinline__ bf16x8 lds_read_b128_asm(const unsigned char* p) {   // same contract, for loops that mix both kinds
+  typedef __attribute__((address_space(3))) const unsigned char lds_u8;
+  const uint32_t addr = (uint32_t)(uintptr_t)(lds_u8*)p;
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+
 // ---------------------------------------------------------------- errors
 extern thread_local char g_vmr_err[256];
 int vmr_fail(int code, const char* fmt, ...);

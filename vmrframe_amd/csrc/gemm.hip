@@ -310,8 +310,10 @@ __device__ __forceinline__ void store_operand(unsigned char* lds, const bf16x8 (
   }
 }
 
+// (lds_read_tr / lgkm_wait / frag_pin: common.h)
 // fragment for the 16-row (or 16-col) MFMA tile `t16` (0..7 within the 128 tile), 32-deep k-substep kk
-template <bool KC, int BK>
+// ASMTR: the transposed read is the inline-asm one (LDS-DMA kernels); false: the builtin, waits left to the compiler
+template <bool KC, int BK, bool ASMTR = false>
 __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int t16, int kk, int lane) {
   if (KC) {
     const int row = t16 * 16 + (lane & 15);
@@ -328,11 +330,15 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int t16, i
     t16 &= 7;
     const int a0 = r * 256 + ((t16 ^ swz_tr(r)) << 5) + p * 8;
     const int a1 = (r + 4) * 256 + ((t16 ^ swz_tr(r + 4)) << 5) + p * 8;
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a0));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a1));
     union { struct { s16x4 l, h; } s; bf16x8 v; } u;
-    u.s.l = lo; u.s.h = hi;
+    if constexpr (ASMTR) {
+      u.s.l = lds_read_tr(lds + a0);
+      u.s.h = lds_read_tr(lds + a1);
+    } else {
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      u.s.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a0));
+      u.s.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a1));
+    }
     return u.v;
   }
 }
@@ -676,6 +682,19 @@ __device__ __forceinline__ void gemm_dma_body(const vmr_gemm_t& g, int tiles_m, 
     }
     __builtin_amdgcn_s_setprio(0);
   };
+  // transposed operands are read by inline asm (lds_read_tr): wait for the OLDER substep's fragments ourselves -- the LDS
+  // returns in order, so "at most as many outstanding as were issued since" retires them -- and pin their registers
+  constexpr int NEWER = (TA ? 2 * MT : MT) + (TB ? 8 : 4);          // LDS reads of one substep
+  auto settle = [&](int buf, bool last) {
+    if constexpr (TA || TB) {
+      if (last) lgkm_wait<0>();
+      else lgkm_wait<(NEWER < 15 ? NEWER : 15)>();
+#pragma unroll
+      for (int i = 0; i < MT; ++i) frag_pin(fa[buf][i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) frag_pin(fb[buf][j]);
+    }
+  };
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's loads of step kt must have landed; those of the later NST-2 steps stay in flight
     const int later = min(nk - 1 - kt, NST - 2);
@@ -696,15 +715,15 @@ __device__ __forceinline__ void gemm_dma_body(const vmr_gemm_t& g, int tiles_m, 
     for (int kk = 0; kk < NKK; ++kk) {
       const int buf = kk & 1;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) fa[buf][i] = read_frag<!TA, BK>(cur, wm * MT + i, kk, lane);
+      for (int i = 0; i < MT; ++i) fa[buf][i] = read_frag<!TA, BK, true>(cur, wm * MT + i, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[buf][j] = read_frag<!TB, BK>(cur + OPA, wn * 4 + j, kk, lane);
+      for (int j = 0; j < 4; ++j) fb[buf][j] = read_frag<!TB, BK, true>(cur + OPA, wn * 4 + j, kk, lane);
       // while those reads fly: the MFMAs of the PREVIOUS substep (the last one of step kt-1 when kk == 0)
-      if (kk > 0) mma((kk - 1) & 1);
-      else if (kt > 0) mma((NKK - 1) & 1);
+      if (kk > 0) { settle((kk - 1) & 1, false); mma((kk - 1) & 1); }
+      else if (kt > 0) { settle((NKK - 1) & 1, false); mma((NKK - 1) & 1); }
     }
   }
-  if (nk > 0) mma((NKK - 1) & 1);
+  if (nk > 0) { settle((NKK - 1) & 1, true); mma((NKK - 1) & 1); }
   if constexpr (TA) {
     if (colsum && lane < 16) {   // every row of the ones-product holds the column sums: lanes 0..15 carry m = lane
 #pragma unroll
@@ -976,22 +995,22 @@ __device__ __forceinline__ void gemm_p8_body(const vmr_gemm_t& g, int tiles_m, i
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) flo[j][kk] = read_frag<!TR, 64>(cur + 1 * P8_UNIT, wn * 2 + j, kk, lane);
+            for (int kk = 0; kk < 2; ++kk) flo[j][kk] = read_frag<!TR, 64, true>(cur + 1 * P8_UNIT, wn * 2 + j, kk, lane);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag<!TR, 64>(cur + 0 * P8_UNIT, wm * 4 + i, kk, lane);
+            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag<!TR, 64, true>(cur + 0 * P8_UNIT, wm * 4 + i, kk, lane);
         } else if (ph == 1) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fhi[j][kk] = read_frag<!TR, 64>(cur + 2 * P8_UNIT, wn * 2 + j, kk, lane);
+            for (int kk = 0; kk < 2; ++kk) fhi[j][kk] = read_frag<!TR, 64, true>(cur + 2 * P8_UNIT, wn * 2 + j, kk, lane);
         } else if (ph == 2) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag<!TR, 64>(cur + 3 * P8_UNIT, wm * 4 + i, kk, lane);
+            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag<!TR, 64, true>(cur + 3 * P8_UNIT, wm * 4 + i, kk, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         // 2. one unit of a later K-tile, then "everything the next phase reads has landed" (this wave's parts)
@@ -1008,6 +1027,14 @@ __device__ __forceinline__ void gemm_p8_body(const vmr_gemm_t& g, int tiles_m, i
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (TR) {          // (asm fragment reads: see lds_read_tr)
+          if (ph == 0 || ph == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { frag_pin(fa[i][0]); frag_pin(fa[i][1]); }
+          }
+          if (ph == 0) { frag_pin(flo[0][0]); frag_pin(flo[0][1]); frag_pin(flo[1][0]); frag_pin(flo[1][1]); }
+          if (ph == 1) { frag_pin(fhi[0][0]); frag_pin(fhi[0][1]); frag_pin(fhi[1][0]); frag_pin(fhi[1][1]); }
+        }
         __builtin_amdgcn_sched_barrier(0);
         // 3. the quadrant
         if (!(dbg & 2)) {
