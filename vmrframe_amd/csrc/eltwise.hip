@@ -94,9 +94,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (valid4 && (int)(i % cols4) >= valid4) continue;   // zero-padded K columns of the slab: no destination
     const int64_t o = cols4 ? (i / cols4) * ld4 + (i % cols4) : i;
     f32x4 acc = d4[o];
-    for (int k = 0; k < nsplit; ++k) {
-      const f32x4 v = s4[k * stride4 + i];
-      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    for (int k0 = 0; k0 < nsplit; k0 += 8) {      // eight slabs per round trip (see the rider in gemm.hip)
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = s4[(int64_t)min(k0 + u, nsplit - 1) * stride4 + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u < nsplit) { acc[0] += v[u][0]; acc[1] += v[u][1]; acc[2] += v[u][2]; acc[3] += v[u][3]; }
     }
     d4[o] = acc;
   }
@@ -112,9 +116,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_cast_kernel(const float* __
   const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 acc = s4[i];
-    for (int k = 1; k < nsplit; ++k) {
-      const f32x4 v = s4[k * n4 + i];
-      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    for (int k0 = 1; k0 < nsplit; k0 += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = s4[(int64_t)min(k0 + u, nsplit - 1) * n4 + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u < nsplit) { acc[0] += v[u][0]; acc[1] += v[u][1]; acc[2] += v[u][2]; acc[3] += v[u][3]; }
     }
     if (bias) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (i % cols4) * 4);

@@ -1114,10 +1114,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma2_kernel(vmr_gemm_t g1, i
     for (int64_t i = (int64_t)(bid - nblk12) * 256 + threadIdx.x; i < rj.n4; i += (int64_t)rj.nblocks * 256) {
       if (rj.valid4 && (int)(i % rj.cols4) >= rj.valid4) continue;
       const int64_t o = rj.cols4 ? (i / rj.cols4) * rj.ld4 + (i % rj.cols4) : i;
+      // eight slabs per round trip (index-clamped, unconditional loads; the surplus ones are not added): a "load, add"
+      // loop over a runtime nsplit compiles to one dependent HBM round trip per slab, and these workgroups then
+      // outlast the two products they ride with.  Same summation order as the stand-alone reduction.
       f32x4 acc = d4[o];
-      for (int k = 0; k < rj.nsplit; ++k) {
-        const f32x4 v = s4[k * rj.n4 + i];
-        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+      for (int k0 = 0; k0 < rj.nsplit; k0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s4[(int64_t)min(k0 + u, rj.nsplit - 1) * rj.n4 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u < rj.nsplit) { acc[0] += v[u][0]; acc[1] += v[u][1]; acc[2] += v[u][2]; acc[3] += v[u][3]; }
       }
       d4[o] = acc;
     }
