@@ -40,6 +40,10 @@ int vmr_debug_poison_lds(uint32_t pattern, void* scratch_u32, void* stream);
 /* Test / A-B utility: tile-variant policy of vmr_gemm for the 256 x 256 "8-phase" kernel: 0 never, 1 where the rounds
  * model picks it (default, also VMR_GEMM_P8), 2 wherever the shape allows; -1 re-reads the environment. */
 int vmr_debug_set_gemm_p8(int mode);
+/* Test / A-B utility: operand-ring variant of the LDS-DMA GEMM kernels: 0 register-staged kernel only, 1 BK = 32 x 4 stages,
+ * 2 BK = 64 x 2 stages (default, also VMR_GEMM_DMA), 3 BK = 32 x 3 stages with three workgroups per CU; -1 re-reads the
+ * environment. */
+int vmr_debug_set_gemm_dma(int mode);
 
 /* ------------------------------------------------------------------ GEMM
  * C[z] = epilogue(alpha * opA(A[z]) . opB(B[z]))

@@ -112,6 +112,45 @@ def test_gemm_lds_dma_kernels_exact(dev, shape):
     assert torch.equal(dz1, dz3) and torch.allclose(db1, db3, rtol=1e-6, atol=1e-3)
 
 
+def test_gemm_every_ring_variant_exact(dev):
+    """vmr_gemm under each operand-ring variant of the LDS-DMA kernels (vmr_debug_set_gemm_dma 1, 2, 3; 0 = the register-
+    staged kernel): all four operand layouts, K = 128 .. 1088 (1 .. 34 ring steps, odd counts included), the fused
+    epilogue and a split-K slab product, bit-exact on small integers.  (Variant 1's BK = 32 loop dropped its first K
+    step until round 2 -- no test selected it.)"""
+    ops = _ops()
+    from vmrframe_amd import _lib as L
+    dt = torch.bfloat16
+    lib = L.lib()
+    try:
+        for mode in (1, 3, 2, 0):
+            lib.vmr_debug_set_gemm_dma(mode)
+            for (M, N, K) in [(256, 128, 128), (384, 256, 192), (1280, 384, 1088), (128, 128, 320)]:
+                for ta, tb in ((0, 0), (1, 1), (0, 1), (1, 0)):
+                    torch.manual_seed(M + N + K + 2 * ta + tb)
+                    A = _ints(K, M, dt, dev) if ta else _ints(M, K, dt, dev)
+                    B = _ints(K, N, dt, dev) if tb else _ints(N, K, dt, dev)
+                    ref = (A.float().t() if ta else A.float()) @ (B.float() if tb else B.float().t())
+                    assert torch.equal(ops.mm(A, B, ta, tb, out_f32=True), ref), (mode, M, N, K, ta, tb)
+            M, N, K = 640, 256, 448
+            A, B = _ints(M, K, dt, dev), _ints(N, K, dt, dev)
+            ref = A.float() @ B.float().t()
+            bias, res = torch.randn(N, device=dev), _ints(M, N, dt, dev)
+            out = torch.empty(M, N, device=dev, dtype=dt)
+            aux = torch.empty_like(out)
+            ops.gemm(A, B, out, M, N, K, 0, 0, K, K, N, dtype=L.BF16, bias=bias, residual=res, aux=aux, ldr=N,
+                     flags=L.EPI_BIAS | L.EPI_RELU | L.EPI_DROPOUT | L.EPI_RESIDUAL | L.EPI_AUX, drop=(0.25, 9, None))
+            mask = ops.dropout_mask(M * N, 0.25, 9, dev).view(M, N)
+            h = torch.relu(ref + bias) * mask
+            assert torch.equal(aux, h.to(dt)) and torch.equal(out, (h + res.float()).to(dt)), mode
+            M, N, K, sk = 256, 384, 1152, 3
+            A, B = _ints(K, M, dt, dev), _ints(K, N, dt, dev)
+            ws = torch.empty(sk, M, N, device=dev)
+            ops.gemm(A, B, ws, M, N, K, 1, 1, M, N, N, dtype=L.BF16, flags=L.EPI_SLAB, splitk=sk)
+            assert torch.equal(ws.sum(0), A.float().t() @ B.float()), mode
+    finally:
+        lib.vmr_debug_set_gemm_dma(-1)
+
+
 def test_gemm_8phase_kernel_exact(dev):
     """The 256 x 256 8-phase kernel (gemm_p8_body), forced wherever the shape allows: K-contiguous operands (plain,
     ragged last row tile, fused epilogue with 16-byte permuted stores) and the transposed-operand split-K slab layout,

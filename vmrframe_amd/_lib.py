@@ -138,6 +138,7 @@ SIGNATURES = {
     "vmr_add_pos_bwd": [_P, _P, _L, _I, _I, _I, _P],
     "vmr_debug_poison_lds": [_U, _P, _P],
     "vmr_debug_set_gemm_p8": [_I],
+    "vmr_debug_set_gemm_dma": [_I],
     "vmr_gemm_aux_bits_supported": [_P],
     "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P, _F, _F, _L, _P],
 }

@@ -711,6 +711,18 @@ __device__ __forceinline__ void gemm_dma_body(const vmr_gemm_t& g, int tiles_m, 
       dma_operand<!TB, BK, 128, NW, PERM>(B, g.ldb, n0, k0, dst + OPA, wid, lane);
     }
     const unsigned char* cur = smem + (kt % NST) * (OPA + OPB);
+    if constexpr (NKK == 1) {
+      // BK = 32: one substep per step, so there is no "other" fragment set to keep in flight -- read, wait, multiply (the
+      // other resident waves cover the wait).  (Until round 2 this case went through the rotated loop below, whose
+      // "previous substep" was the set just overwritten: step 0 was dropped and the last step counted twice.  Only
+      // VMR_GEMM_DMA=1 ever selected it, and no test did; tests/test_gpu_a_ops.py now covers every ring variant.)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[0][i] = read_frag<!TA, BK, true>(cur, wm * MT + i, 0, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[0][j] = read_frag<!TB, BK, true>(cur + OPA, wn * 4 + j, 0, lane);
+      if constexpr (TA || TB) settle(0, true);
+      mma(0);
+    } else {
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
       const int buf = kk & 1;
@@ -722,8 +734,11 @@ __device__ __forceinline__ void gemm_dma_body(const vmr_gemm_t& g, int tiles_m, 
       if (kk > 0) { settle((kk - 1) & 1, false); mma((kk - 1) & 1); }
       else if (kt > 0) { settle((NKK - 1) & 1, false); mma((NKK - 1) & 1); }
     }
+    }
   }
-  if (nk > 0) { settle((NKK - 1) & 1, true); mma((NKK - 1) & 1); }
+  if constexpr (NKK > 1) {
+    if (nk > 0) { settle((NKK - 1) & 1, true); mma((NKK - 1) & 1); }
+  }
   if constexpr (TA) {
     if (colsum && lane < 16) {   // every row of the ones-product holds the column sums: lanes 0..15 carry m = lane
 #pragma unroll
@@ -749,7 +764,7 @@ __device__ __forceinline__ void gemm_dma_body(const vmr_gemm_t& g, int tiles_m, 
 }
 
 template <bool TA, bool TB, int BK, int NST, int MT = 4, int WM = 2>
-__global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(WM * 128, (WM == 2 ? (BK == 32 && NST == 3 ? 3 : 2) : 1)) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   gemm_dma_body<TA, TB, BK, NST, MT, WM>(g, tiles_m, tiles_n, smem, blockIdx.x, blockIdx.z, gridDim.z);
 }
@@ -1274,7 +1289,7 @@ Pick pick_trans(int ta, int tb, int dtype, int bk) {
 
 int g_p8 = -1;        // VMR_GEMM_P8 / vmr_debug_set_gemm_p8: 256 x 256 8-phase kernel 0 never, 1 (default) by the rounds model, 2 wherever allowed
 int g_gemm_bk = 0;   // 0 = not read yet; VMR_GEMM_BK=32|64 selects the bf16 K-step of the register-staged path
-int g_gemm_dma = -1;  // VMR_GEMM_DMA: 0 off (register-staged kernel only), 1: BK=32 x 4 stages, 2 (default): BK=64 x 2 stages
+int g_gemm_dma = -1;  // VMR_GEMM_DMA / vmr_debug_set_gemm_dma: 0 off (register-staged kernel only), 1: BK=32 x 4 stages, 2 (default): BK=64 x 2 stages, 3: BK=32 x 3 stages, three workgroups per CU
 
 template <int BK, int NST>
 gemm_fn pick_dma_t(int ta, int tb) {
@@ -1305,9 +1320,13 @@ inline double rounds_cost(int64_t tiles, double tile_weight) {
   const int64_t full = tiles / 512, rem = tiles % 512;
   return ((double)full + (rem == 0 ? 0.0 : (rem <= 256 ? 0.5 : 1.0))) * tile_weight;
 }
-Pick pick_dma(int ta, int tb, int variant) {
+Pick pick_dma(int ta, int tb, int variant, int flags = 0) {
   // 64 KiB of stages; 67,584 B so the epilogue can stage the whole fp32 tile in one pass (still 2 / CU)
   if (variant == 2) return {pick_dma_t<64, 2>(ta, tb), 128 * CST_LD * 4};
+  // variant 3: BK = 32 x 3 stages = 48 KiB and <= 170 VGPRs: THREE workgroups (12 waves) per CU -- the operand fill of a
+  // CU follows the number of waves issuing loads.  The atomic-accumulate epilogue stages the fp32 tile
+  // through LDS and keeps the two-per-CU footprint.
+  if (variant == 3) return {pick_dma_t<32, 3>(ta, tb), (flags & VMR_EPI_ACCUM) ? 128 * CST_LD * 4 : 3 * 16384};
   return {pick_dma_t<32, 4>(ta, tb), 128 * CST_LD * 4};
 }
 
@@ -1354,7 +1373,8 @@ bool p8_ok(const vmr_gemm_t& g, int64_t Z) {
 bool gemm_perm_direct(const vmr_gemm_t& g) {
   const int dma = g_gemm_dma < 0 ? 2 : g_gemm_dma;
   const int64_t Z = (int64_t)(g.Z1 > 0 ? g.Z1 : 1) * (g.Z2 > 0 ? g.Z2 : 1);
-  return dma >= 2 && g.dtype == VMR_BF16 && !g.transB && Z == 1 && g.splitk <= 1 && gemm_aligned(g) && g.M % BM == 0 &&
+  // (dma == 2: only the BK = 64 kernels permute the weight rows)
+  return dma == 2 && g.dtype == VMR_BF16 && !g.transB && Z == 1 && g.splitk <= 1 && gemm_aligned(g) && g.M % BM == 0 &&
          g.N % BN == 0 && g.K % 64 == 0 && g.K >= 128 && !(g.flags & (VMR_EPI_ACCUM | VMR_EPI_OUT_F32 | VMR_EPI_SLAB)) &&
          (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));
 }
@@ -1417,7 +1437,7 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   const bool dma_ok = g_gemm_dma && al && g.dtype == VMR_BF16 && g.M % BM == 0 && g.N % BN == 0 && g.K % 64 == 0 &&
                       g.K >= 128 * g.splitk &&
                       (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));   // the direct epilogue loads bias as float4
-  if (dma_ok) pk = pick_dma(g.transA, g.transB, g_gemm_dma >= 2 ? 2 : 1);
+  if (dma_ok) pk = pick_dma(g.transA, g.transB, g_gemm_dma == 3 ? 3 : (g_gemm_dma >= 2 ? 2 : 1), g.flags);
   // 160-row tiles when they save a (partial) round: e.g. [9472 x 1024]: 592 tiles = 1.16 rounds of 128x128
   // -> 480 tiles = one round of 160x128
   static int g_tall = -1;
@@ -1434,7 +1454,7 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
     const char* e = getenv("VMR_GEMM_WIDE");
     g_wide = e ? atoi(e) : 1;
   }
-  const bool tall_ok = g_tall && g_gemm_dma >= 2 && al && g.dtype == VMR_BF16 && !g.transA && g.N % BN == 0 && g.K % 64 == 0 &&
+  const bool tall_ok = g_tall && g_gemm_dma == 2 && al && g.dtype == VMR_BF16 && !g.transA && g.N % BN == 0 && g.K % 64 == 0 &&
                        g.K >= 128 && g.splitk == 1 && !(g.flags & VMR_EPI_ACCUM) && g.M % 8 == 0 &&
                        (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));
   const double c128 = dma_ok ? rounds_cost((int64_t)tiles_m * tiles_n * Z, 1.0) : 1e30;
@@ -1645,6 +1665,11 @@ extern "C" int vmr_gemm_aux_bits_supported(const vmr_gemm_t* gp) {
 
 extern "C" int vmr_debug_set_gemm_p8(int mode) {
   g_p8 = mode;
+  return 0;
+}
+
+extern "C" int vmr_debug_set_gemm_dma(int mode) {
+  g_gemm_dma = mode;      // -1: re-read VMR_GEMM_DMA at the next call
   return 0;
 }
 
