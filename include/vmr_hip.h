@@ -541,6 +541,29 @@ int vmr_map2d_pool_bwd(const void* x, const void* dM, const void* dR, const int3
 int vmr_map2d_scatter(const void* cells, const int32_t* cell_of, const float* fill, void* out, int B, int N, int W,
                       int64_t C, int dtype, void* stream);
 
+/* ------------------------------------------------ BAN encoders: bidirectional LSTM, pointwise half (N2)
+ * Replaces the recurrence inside nn.LSTM(batch_first, bidirectional) as QueryEncoder / VisualEncoder use it
+ * (models/BANlib/model.py:27-45,60-72: packed by length, zero initial state, outputs zero past each length).  The matrix
+ * halves are vmr_gemm launches of the caller; one call = step s of BOTH directions (z = 0 forward in time, 1 backward).
+ * Step order: direction 0 handles time t = s, direction 1 time t = len[b] - 1 - s, both only while s < len[b]; the caller
+ * builds direction 1's input projection on the per-sample reversed sequence (vmr_lstm_reverse_rows).
+ *   gx  [2][B][T][4H] dtype  x-part of the gate pre-activations incl. both biases, by step (gate order i, f, g, o)
+ *   gh  [2][B][4H]    f32    h_{s-1} . W_hh^T of this step          c  [2][B][H] f32 cell state (in/out, start at 0)
+ *   hs  [2][B][H]     dtype  h for the next step's product (in/out, start at 0)
+ *   act [2][B][T][4H] dtype  post-activation gates by step, cs [2][B][T][H] f32 cell state after step s,
+ *   hp  [2][B][T][H]  dtype  h before step s                        (all three: saved for the backward)
+ *   y   [B][T][2H]    dtype  output by TIME; rows past len[b] are not written (zero-fill once before step 0)
+ * Backward, step s (descending): dy [B][T][2H]; dh [2][B][H] f32 = dg_{s+1} . W_hh (zeros at s = T-1); dc [2][B][H] f32
+ * carried cell gradient (in/out, start at 0); dg [2][B][T][4H] dtype = gradient of the gate pre-activations of step s
+ * (= gradient of gx; dW_hh = sum_s dg_s^T hp_s).  dtype VMR_F32 or VMR_BF16. */
+int vmr_lstm_cell_fwd(const void* gx, const void* gh, const int32_t* len, void* c, void* hs, void* act, void* cs, void* hp,
+                      void* y, int B, int T, int H, int s, int dtype, void* stream);
+int vmr_lstm_cell_bwd(const void* dy, const void* act, const void* cs, const int32_t* len, const void* dh, void* dc, void* dg,
+                      int B, int T, int H, int s, int dtype, void* stream);
+/* dst[b][s][:] = s < len[b] ? src[b][len[b]-1-s][:] : 0 for [B][T][D] rows (its own inverse on the valid part).  D a
+ * multiple of 16 bytes, 16-byte aligned pointers. */
+int vmr_lstm_reverse_rows(const void* src, const int32_t* len, void* dst, int B, int T, int D, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,83 @@
+"""Golden vectors for the BAN encoders (row N2): outputs AND gradients of the reference's own `VisualEncoder` and
+`QueryEncoder` (models/BANlib/model.py:8-86), imported from /root/reference in the build container and run on the CPU
+in fp32 with a deterministic numpy weight recipe.  Writes tests/golden/g_ban_enc.npz.  Test infrastructure only.
+
+    python oracle/gen_golden_ban_enc.py
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def import_banlib():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    pkg = types.ModuleType("models"); pkg.__path__ = ["/root/reference/models"]; sys.modules["models"] = pkg
+    sub = types.ModuleType("models.BANlib"); sub.__path__ = ["/root/reference/models/BANlib"]; sys.modules["models.BANlib"] = sub
+    return importlib.import_module("models.BANlib.model")
+
+
+def fill(module, rng, scale=0.15):
+    with torch.no_grad():
+        for _, p in sorted(module.named_parameters()):
+            p.copy_(torch.from_numpy(rng.uniform(-scale, scale, size=tuple(p.shape)).astype(np.float32)))
+
+
+def main():
+    M = import_banlib()
+    rng = np.random.default_rng(20261004)
+    out = {}
+    # ---- VisualEncoder: B = 5, T = 12, I = 24, H = 16; lengths incl. 1, full and unsorted
+    B, T, I, H = 5, 12, 24, 16
+    enc = M.VisualEncoder(I, H, 1)
+    fill(enc, rng)
+    x = torch.from_numpy(rng.standard_normal((B, T, I)).astype(np.float32)).requires_grad_(True)
+    lens = torch.tensor([7, 12, 1, 9, 12])
+    vec, y = enc(x, lens, T)
+    wy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+    wv = torch.from_numpy(rng.standard_normal(tuple(vec.shape)).astype(np.float32))
+    ((y * wy).sum() + (vec * wv).sum()).backward()
+    out.update(v_x=x.detach().numpy(), v_len=lens.numpy().astype(np.int32), v_vec=vec.detach().numpy(), v_y=y.detach().numpy(),
+               v_wy=wy.numpy(), v_wv=wv.numpy(), v_dx=x.grad.numpy())
+    for k, p in enc.named_parameters():
+        out["v_p_" + k] = p.detach().numpy()
+        out["v_g_" + k] = p.grad.numpy()
+    # ---- QueryEncoder with pre-trained vectors: vocab 30 (+ pad, unk), E = 12 (not a multiple of 8), H = 8, L = 9
+    V, E, H2, Lq = 30, 12, 8, 9
+    glove = rng.standard_normal((V, E)).astype(np.float32)
+    qenc = M.QueryEncoder(V + 2, H2, embed_dim=E, num_layers=1, pre_train_weights=None)
+    # (the reference's constructor copies pre_train_weights into an nn.Embedding of vocab_size rows that it never uses;
+    #  build the three tables the forward reads exactly as its `if pre_train_weights is not None` branch does)
+    qenc.pad_vec = torch.nn.Parameter(torch.zeros(1, E), requires_grad=False)
+    qenc.unk_vec = torch.nn.Parameter(torch.from_numpy(rng.uniform(-0.3, 0.3, (1, E)).astype(np.float32)), requires_grad=True)
+    qenc.glove_vec = torch.nn.Parameter(torch.from_numpy(glove), requires_grad=False)
+    fill(qenc.biLSTM, rng)
+    qlens = torch.tensor([9, 3, 6, 1])
+    toks = torch.zeros(4, Lq, dtype=torch.long)
+    for b, n in enumerate(qlens.tolist()):
+        toks[b, :n] = torch.from_numpy(rng.integers(1, V + 2, size=n))
+    toks[0, 2] = 1                      # an <unk>
+    qvec, qy = qenc(toks, qlens)
+    wq = torch.from_numpy(rng.standard_normal(tuple(qy.shape)).astype(np.float32))
+    wqv = torch.from_numpy(rng.standard_normal(tuple(qvec.shape)).astype(np.float32))
+    ((qy * wq).sum() + (qvec * wqv).sum()).backward()
+    out.update(q_tok=toks.numpy(), q_len=qlens.numpy().astype(np.int32), q_glove=glove, q_unk=qenc.unk_vec.detach().numpy(),
+               q_vec=qvec.detach().numpy(), q_y=qy.detach().numpy(), q_wy=wq.numpy(), q_wv=wqv.numpy(),
+               q_dunk=qenc.unk_vec.grad.numpy())
+    for k, p in qenc.biLSTM.named_parameters():
+        out["q_p_" + k] = p.detach().numpy()
+        out["q_g_" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, "g_ban_enc.npz"), **out)
+    print("wrote g_ban_enc.npz:", {k: v.shape for k, v in out.items() if k.endswith(("_y", "_vec"))})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,188 @@
+"""BAN's sequence encoders on the HIP library (second slice): the bidirectional LSTM of
+`QueryEncoder` / `VisualEncoder` (reference models/BANlib/model.py:8-86).
+
+The reference runs `nn.LSTM(input, hidden, 1, batch_first=True, bidirectional=True)` on a sequence packed by length
+(`pack_padded_sequence(..., enforce_sorted=False)`), pads the output back and mean-pools the valid steps.  Here:
+
+  * the input projections of all steps are two `vmr_gemm` products (direction 1 on the per-sample REVERSED sequence,
+    `vmr_lstm_reverse_rows`), both biases folded into their epilogue;
+  * the recurrence runs in STEP order for both directions at once: step s = time s for direction 0 and time
+    len_b - 1 - s for direction 1, both active while s < len_b -- which is what packing computes (a sample's reverse
+    pass starts at its own last valid step from a zero state) with one mask for both directions.  Per step: one
+    batched product h . W_hh^T (both directions, `Z1 = 2`) and one `vmr_lstm_cell_fwd` launch (gates, state, the scatter
+    of h into the time-ordered [B, T, 2H] output);
+  * backward: per step `vmr_lstm_cell_bwd` + the batched product dg_s . W_hh; after the loop ONE product per weight over
+    all steps (dW_hh = dg^T . h_prev, dW_ih = dg^T . x, K = B*T), the bias gradients as column sums, dx = dg . W_ih with
+    direction 1 mapped back through the same reversal.
+  * no per-sample host loop: the mean over valid steps is sum_t / len (the output is zero past len).
+
+State-dict keys are the reference's (`biLSTM.weight_ih_l0`, `..._reverse`, ...), so a BAN checkpoint's encoder
+weights load unchanged.  This is a correct, measured first version, not a tuned one: the per-step products are
+[B, 4H, H] with B = 64 rows -- launch-bound; a persistent recurrence kernel is the next step.
+NOT built: QueryEncoder's embedding front (`F.embedding` over [pad | unk | glove]) is ops.embedding's job and is
+wired in `QueryEncoder` below; everything else of BAN outside ban_map.py (CQAttention variant, TemporalDifference,
+sampling, losses) is still out.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+
+def _reverse_rows(x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
+    B, T, D = x.shape
+    out = torch.empty_like(x)
+    L.check(L.lib().vmr_lstm_reverse_rows(x.data_ptr(), lens.data_ptr(), out.data_ptr(), B, T, D, L.dtype_code(x),
+                                          L.stream_ptr()), "vmr_lstm_reverse_rows")
+    return out
+
+
+class _BiLSTM(torch.autograd.Function):
+    """y [B, T, 2H] = bi-LSTM(x [B, T, I], lens int32 [B]); w_ih [2, 4H, I], w_hh [2, 4H, H], bias [2, 4H] (= b_ih + b_hh),
+    all in x's dtype (fp32 or bf16).  Gradients for x, w_ih, w_hh, bias."""
+
+    @staticmethod
+    def forward(ctx, x, lens, w_ih, w_hh, bias):
+        L.require_gpu(x, lens, w_ih, w_hh, bias)
+        assert lens.dtype == torch.int32 and x.is_contiguous() and w_ih.is_contiguous() and w_hh.is_contiguous()
+        B, T, I = x.shape
+        H = w_hh.shape[2]
+        dt, dc = x.dtype, L.dtype_code(x)
+        lib, dev = L.lib(), x.device
+        xs = torch.stack((x, _reverse_rows(x, lens)))                     # [2, B, T, I] by step
+        gx = torch.empty(2, B, T, 4 * H, device=dev, dtype=dt)
+        bias32 = bias.float().contiguous()
+        for z in range(2):                                                # x-part of every step, biases in the epilogue
+            ops.mm(xs[z].view(B * T, I), w_ih[z], 0, 0, out=gx[z].view(B * T, 4 * H), bias=bias32[z], flags=L.EPI_BIAS)
+        c = torch.zeros(2, B, H, device=dev)
+        hs = torch.zeros(2, B, H, device=dev, dtype=dt)
+        gh = torch.zeros(2, B, 4 * H, device=dev)
+        act = torch.empty(2, B, T, 4 * H, device=dev, dtype=dt)
+        cs = torch.empty(2, B, T, H, device=dev)
+        hp = torch.empty(2, B, T, H, device=dev, dtype=dt)
+        y = torch.zeros(B, T, 2 * H, device=dev, dtype=dt)
+        f32out = L.EPI_OUT_F32 if dc != L.F32 else 0
+        for s in range(T):
+            if s > 0:                                                     # gh[z] = hs[z] . w_hh[z]^T, both directions
+                ops.gemm(hs, w_hh, gh, B, 4 * H, H, 0, 0, H, H, 4 * H, dtype=dc, flags=f32out, Z1=2,
+                         sA=(B * H, 0), sB=(4 * H * H, 0), sC=(B * 4 * H, 0))
+            L.check(lib.vmr_lstm_cell_fwd(gx.data_ptr(), gh.data_ptr(), lens.data_ptr(), c.data_ptr(), hs.data_ptr(),
+                                          act.data_ptr(), cs.data_ptr(), hp.data_ptr(), y.data_ptr(), B, T, H, s, dc,
+                                          L.stream_ptr()), "vmr_lstm_cell_fwd")
+        ctx.save_for_backward(xs, lens, w_ih, w_hh, act, cs, hp)
+        ctx.mark_non_differentiable(lens)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, lens, w_ih, w_hh, act, cs, hp = ctx.saved_tensors
+        _, B, T, I = xs.shape
+        H = w_hh.shape[2]
+        dt, dc = xs.dtype, L.dtype_code(xs)
+        lib, dev = L.lib(), xs.device
+        dy = dy.contiguous()
+        dg = torch.empty(2, B, T, 4 * H, device=dev, dtype=dt)
+        dh = torch.zeros(2, B, H, device=dev)
+        dcell = torch.zeros(2, B, H, device=dev)
+        f32out = L.EPI_OUT_F32 if dc != L.F32 else 0
+        for s in range(T - 1, -1, -1):
+            L.check(lib.vmr_lstm_cell_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), dh.data_ptr(),
+                                          dcell.data_ptr(), dg.data_ptr(), B, T, H, s, dc, L.stream_ptr()),
+                    "vmr_lstm_cell_bwd")
+            if s > 0:      # dh[z] = dg[z][:, s, :] . w_hh[z]   (A rows strided by T*4H; W_hh is the [K][N] operand)
+                ops.gemm(dg[:, :, s], w_hh, dh, B, H, 4 * H, 0, 1, T * 4 * H, H, H, dtype=dc, flags=f32out, Z1=2,
+                         sA=(B * T * 4 * H, 0), sB=(4 * H * H, 0), sC=(B * H, 0))
+        dg2 = dg.view(2, B * T, 4 * H)
+        dw_hh = torch.empty(2, 4 * H, H, device=dev)
+        dw_ih = torch.empty(2, 4 * H, I, device=dev)
+        dxs = torch.empty(2, B, T, I, device=dev, dtype=dt)
+        for z in range(2):   # one product per weight over all steps (K = B*T); dx of each direction's step sequence
+            ops.mm(dg2[z], hp[z].view(B * T, H), 1, 1, out=dw_hh[z], out_f32=True)
+            ops.mm(dg2[z], xs[z].view(B * T, I), 1, 1, out=dw_ih[z], out_f32=True)
+            ops.mm(dg2[z], w_ih[z], 0, 1, out=dxs[z].view(B * T, I))
+        dbias = dg2.float().sum(1)
+        dx = dxs[0] + _reverse_rows(dxs[1], lens)                        # (the reversal is its own inverse; zero past len)
+        return dx, None, dw_ih.to(w_ih.dtype), dw_hh.to(w_hh.dtype), dbias.to(dt)
+
+
+def bilstm(x, lens, w_ih, w_hh, bias):
+    return _BiLSTM.apply(x, lens, w_ih, w_hh, bias)
+
+
+class _EncoderBase(nn.Module):
+    """Parameter holder with nn.LSTM's key names under `biLSTM.` + the HIP forward."""
+
+    def __init__(self, input_dim: int, hidden_dim: int, compute_dtype=torch.float32):
+        super().__init__()
+        assert input_dim % 8 == 0 and hidden_dim % 8 == 0, "16-byte rows"
+        self.biLSTM = nn.LSTM(input_dim, hidden_dim, 1, dropout=0.0, batch_first=True, bidirectional=True)
+        self.hidden_dim, self.compute_dtype = hidden_dim, compute_dtype
+
+    def _run(self, x: torch.Tensor, lengths: torch.Tensor, max_seq_len=None):
+        m, dt = self.biLSTM, self.compute_dtype
+        if max_seq_len is not None and x.shape[1] != max_seq_len:          # (pad_packed_sequence(total_length=...))
+            x = x[:, :max_seq_len] if x.shape[1] > max_seq_len else torch.nn.functional.pad(x, (0, 0, 0, max_seq_len - x.shape[1]))
+        lens = lengths.to(device=x.device, dtype=torch.int32).clamp(max=x.shape[1]).contiguous()
+        w_ih = torch.stack((m.weight_ih_l0, m.weight_ih_l0_reverse)).to(dt)
+        w_hh = torch.stack((m.weight_hh_l0, m.weight_hh_l0_reverse)).to(dt)
+        bias = torch.stack((m.bias_ih_l0 + m.bias_hh_l0, m.bias_ih_l0_reverse + m.bias_hh_l0_reverse)).to(dt)
+        out = bilstm(x.to(dt).contiguous(), lens, w_ih.contiguous(), w_hh.contiguous(), bias.contiguous())
+        vec = out.float().sum(1) / lens.clamp(min=1).unsqueeze(1).float()   # mean over the valid steps (zero past len)
+        return vec.to(out.dtype), out
+
+
+class VisualEncoder(_EncoderBase):
+    """reference models/BANlib/model.py:60-86: forward(visual_data [B,T,I], visual_length [B], max_seq_len) ->
+    (v_vector [B, 2H], output [B, max_seq_len, 2H])."""
+
+    def __init__(self, input_dim=500, hidden_dim=512, num_layers=1, bidirection=True, compute_dtype=torch.float32):
+        assert num_layers == 1 and bidirection, "the reference instantiates one bidirectional layer"
+        super().__init__(input_dim, hidden_dim, compute_dtype)
+
+    def forward(self, visual_data, visual_length, max_seq_len):
+        return self._run(visual_data, visual_length, max_seq_len)
+
+
+class QueryEncoder(_EncoderBase):
+    """reference models/BANlib/model.py:8-57 with pre-trained vectors: the table is [pad_vec | unk_vec | glove_vec]
+    (pad and glove frozen, unk trainable), forward(query_tokens [B,L], query_length [B]) -> (q_vector, output
+    [B, max(query_length), 2H])."""
+
+    def __init__(self, vocab_size, hidden_dim=512, embed_dim=300, num_layers=1, bidirection=True, pre_train_weights=None,
+                 compute_dtype=torch.float32):
+        assert num_layers == 1 and bidirection and pre_train_weights is not None
+        # the embedding width is padded with zero columns to a multiple of 8 (16-byte rows); W_ih gets matching zero columns
+        # at forward time, and the gradient of those columns is dropped by the pad's own backward
+        super().__init__((embed_dim + 7) // 8 * 8, hidden_dim, compute_dtype)
+        self.embed_dim = embed_dim
+        self.embed_pad = (embed_dim + 7) // 8 * 8
+        self.biLSTM = nn.LSTM(embed_dim, hidden_dim, 1, dropout=0.0, batch_first=True, bidirectional=True)
+        self.embedding = nn.Embedding(vocab_size, embed_dim, padding_idx=0)      # (held, unused: as in the reference)
+        self.embedding.weight.requires_grad = False
+        w = torch.as_tensor(pre_train_weights, dtype=torch.float32)
+        self.pad_vec = nn.Parameter(torch.zeros(1, embed_dim), requires_grad=False)
+        unk = torch.empty(1, embed_dim)
+        nn.init.xavier_uniform_(unk)
+        self.unk_vec = nn.Parameter(unk, requires_grad=True)
+        self.glove_vec = nn.Parameter(w.clone(), requires_grad=False)
+
+    def forward(self, query_tokens, query_length):
+        table = torch.cat([self.pad_vec, self.unk_vec, self.glove_vec], dim=0)
+        emb = ops.embedding(query_tokens, table, padding_idx=0)                # [B, L, E] fp32
+        pad = self.embed_pad - self.embed_dim
+        m, dt = self.biLSTM, self.compute_dtype
+        x = torch.nn.functional.pad(emb, (0, pad)) if pad else emb
+        Lmax = int(query_length.max())                                        # pad_packed_sequence trims to the longest
+        x = x[:, :Lmax]
+        lens = query_length.to(device=x.device, dtype=torch.int32).contiguous()
+        w_ih = torch.nn.functional.pad(torch.stack((m.weight_ih_l0, m.weight_ih_l0_reverse)), (0, pad)).to(dt)
+        w_hh = torch.stack((m.weight_hh_l0, m.weight_hh_l0_reverse)).to(dt)
+        bias = torch.stack((m.bias_ih_l0 + m.bias_hh_l0, m.bias_ih_l0_reverse + m.bias_hh_l0_reverse)).to(dt)
+        out = bilstm(x.to(dt).contiguous(), lens, w_ih.contiguous(), w_hh.contiguous(), bias.contiguous())
+        vec = out.float().sum(1) / lens.clamp(min=1).unsqueeze(1).float()
+        return vec.to(out.dtype), out
