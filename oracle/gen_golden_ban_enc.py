@@ -50,6 +50,19 @@ def main():
     for k, p in enc.named_parameters():
         out["v_p_" + k] = p.detach().numpy()
         out["v_g_" + k] = p.grad.numpy()
+    # ---- two stacked layers (config/anet/BAN.yaml: lstm_layer 2), I = 20 (not a multiple of 8)
+    enc2 = M.VisualEncoder(20, 8, 2)
+    fill(enc2, rng, 0.3)
+    x2 = torch.from_numpy(rng.standard_normal((4, 10, 20)).astype(np.float32)).requires_grad_(True)
+    lens2 = torch.tensor([10, 4, 1, 8])
+    vec2, y2 = enc2(x2, lens2, 10)
+    w2 = torch.from_numpy(rng.standard_normal(tuple(y2.shape)).astype(np.float32))
+    ((y2 * w2).sum() + vec2.sum()).backward()
+    out.update(w_x=x2.detach().numpy(), w_len=lens2.numpy().astype(np.int32), w_vec=vec2.detach().numpy(),
+               w_y=y2.detach().numpy(), w_wy=w2.numpy(), w_dx=x2.grad.numpy())
+    for k, p in enc2.named_parameters():
+        out["w_p_" + k] = p.detach().numpy()
+        out["w_g_" + k] = p.grad.numpy()
     # ---- QueryEncoder with pre-trained vectors: vocab 30 (+ pad, unk), E = 12 (not a multiple of 8), H = 8, L = 9
     V, E, H2, Lq = 30, 12, 8, 9
     glove = rng.standard_normal((V, E)).astype(np.float32)

@@ -115,25 +115,32 @@ def bilstm(x, lens, w_ih, w_hh, bias):
 
 
 class _EncoderBase(nn.Module):
-    """Parameter holder with nn.LSTM's key names under `biLSTM.` + the HIP forward."""
+    """Parameter holder with nn.LSTM's key names under `biLSTM.` + the HIP forward (stacked layers: layer l + 1 reads layer
+    l's [B, T, 2H] output with the same lengths -- what nn.LSTM does on a packed sequence; inter-layer dropout is 0.0 in
+    the reference)."""
 
-    def __init__(self, input_dim: int, hidden_dim: int, compute_dtype=torch.float32):
+    def __init__(self, input_dim: int, hidden_dim: int, num_layers: int = 1, compute_dtype=torch.float32):
         super().__init__()
-        assert input_dim % 8 == 0 and hidden_dim % 8 == 0, "16-byte rows"
-        self.biLSTM = nn.LSTM(input_dim, hidden_dim, 1, dropout=0.0, batch_first=True, bidirectional=True)
-        self.hidden_dim, self.compute_dtype = hidden_dim, compute_dtype
+        assert hidden_dim % 8 == 0, "16-byte rows"
+        self.biLSTM = nn.LSTM(input_dim, hidden_dim, num_layers, dropout=0.0, batch_first=True, bidirectional=True)
+        self.hidden_dim, self.num_layers, self.compute_dtype = hidden_dim, num_layers, compute_dtype
 
-    def _run(self, x: torch.Tensor, lengths: torch.Tensor, max_seq_len=None):
+    def _layers(self, x: torch.Tensor, lens: torch.Tensor):
+        """x [B, T, I] (any float dtype), lens int32 [B] on x's device -> (mean over valid steps [B, 2H], output [B, T, 2H])"""
         m, dt = self.biLSTM, self.compute_dtype
-        if max_seq_len is not None and x.shape[1] != max_seq_len:          # (pad_packed_sequence(total_length=...))
-            x = x[:, :max_seq_len] if x.shape[1] > max_seq_len else torch.nn.functional.pad(x, (0, 0, 0, max_seq_len - x.shape[1]))
-        lens = lengths.to(device=x.device, dtype=torch.int32).clamp(max=x.shape[1]).contiguous()
-        w_ih = torch.stack((m.weight_ih_l0, m.weight_ih_l0_reverse)).to(dt)
-        w_hh = torch.stack((m.weight_hh_l0, m.weight_hh_l0_reverse)).to(dt)
-        bias = torch.stack((m.bias_ih_l0 + m.bias_hh_l0, m.bias_ih_l0_reverse + m.bias_hh_l0_reverse)).to(dt)
-        out = bilstm(x.to(dt).contiguous(), lens, w_ih.contiguous(), w_hh.contiguous(), bias.contiguous())
-        vec = out.float().sum(1) / lens.clamp(min=1).unsqueeze(1).float()   # mean over the valid steps (zero past len)
-        return vec.to(out.dtype), out
+        h = x.to(dt)
+        for l in range(self.num_layers):
+            w_ih = torch.stack((getattr(m, f"weight_ih_l{l}"), getattr(m, f"weight_ih_l{l}_reverse")))
+            w_hh = torch.stack((getattr(m, f"weight_hh_l{l}"), getattr(m, f"weight_hh_l{l}_reverse")))
+            bias = torch.stack((getattr(m, f"bias_ih_l{l}") + getattr(m, f"bias_hh_l{l}"),
+                                getattr(m, f"bias_ih_l{l}_reverse") + getattr(m, f"bias_hh_l{l}_reverse")))
+            pad = (-h.shape[2]) % 8           # 16-byte rows: zero columns on both sides of the first product
+            if pad:
+                h = torch.nn.functional.pad(h, (0, pad))
+                w_ih = torch.nn.functional.pad(w_ih, (0, pad))
+            h = bilstm(h.contiguous(), lens, w_ih.to(dt).contiguous(), w_hh.to(dt).contiguous(), bias.to(dt).contiguous())
+        vec = h.float().sum(1) / lens.clamp(min=1).unsqueeze(1).float()     # mean over the valid steps (zero past len)
+        return vec.to(h.dtype), h
 
 
 class VisualEncoder(_EncoderBase):
@@ -141,11 +148,15 @@ class VisualEncoder(_EncoderBase):
     (v_vector [B, 2H], output [B, max_seq_len, 2H])."""
 
     def __init__(self, input_dim=500, hidden_dim=512, num_layers=1, bidirection=True, compute_dtype=torch.float32):
-        assert num_layers == 1 and bidirection, "the reference instantiates one bidirectional layer"
-        super().__init__(input_dim, hidden_dim, compute_dtype)
+        assert bidirection, "the reference instantiates bidirectional encoders only"
+        super().__init__(input_dim, hidden_dim, num_layers, compute_dtype)
 
     def forward(self, visual_data, visual_length, max_seq_len):
-        return self._run(visual_data, visual_length, max_seq_len)
+        x = visual_data
+        if x.shape[1] != max_seq_len:                                      # (pad_packed_sequence(total_length=...))
+            x = x[:, :max_seq_len] if x.shape[1] > max_seq_len else torch.nn.functional.pad(x, (0, 0, 0, max_seq_len - x.shape[1]))
+        lens = visual_length.to(device=x.device, dtype=torch.int32).clamp(max=x.shape[1]).contiguous()
+        return self._layers(x, lens)
 
 
 class QueryEncoder(_EncoderBase):
@@ -155,13 +166,9 @@ class QueryEncoder(_EncoderBase):
 
     def __init__(self, vocab_size, hidden_dim=512, embed_dim=300, num_layers=1, bidirection=True, pre_train_weights=None,
                  compute_dtype=torch.float32):
-        assert num_layers == 1 and bidirection and pre_train_weights is not None
-        # the embedding width is padded with zero columns to a multiple of 8 (16-byte rows); W_ih gets matching zero columns
-        # at forward time, and the gradient of those columns is dropped by the pad's own backward
-        super().__init__((embed_dim + 7) // 8 * 8, hidden_dim, compute_dtype)
+        assert bidirection and pre_train_weights is not None
+        super().__init__(embed_dim, hidden_dim, num_layers, compute_dtype)
         self.embed_dim = embed_dim
-        self.embed_pad = (embed_dim + 7) // 8 * 8
-        self.biLSTM = nn.LSTM(embed_dim, hidden_dim, 1, dropout=0.0, batch_first=True, bidirectional=True)
         self.embedding = nn.Embedding(vocab_size, embed_dim, padding_idx=0)      # (held, unused: as in the reference)
         self.embedding.weight.requires_grad = False
         w = torch.as_tensor(pre_train_weights, dtype=torch.float32)
@@ -174,15 +181,6 @@ class QueryEncoder(_EncoderBase):
     def forward(self, query_tokens, query_length):
         table = torch.cat([self.pad_vec, self.unk_vec, self.glove_vec], dim=0)
         emb = ops.embedding(query_tokens, table, padding_idx=0)                # [B, L, E] fp32
-        pad = self.embed_pad - self.embed_dim
-        m, dt = self.biLSTM, self.compute_dtype
-        x = torch.nn.functional.pad(emb, (0, pad)) if pad else emb
         Lmax = int(query_length.max())                                        # pad_packed_sequence trims to the longest
-        x = x[:, :Lmax]
-        lens = query_length.to(device=x.device, dtype=torch.int32).contiguous()
-        w_ih = torch.nn.functional.pad(torch.stack((m.weight_ih_l0, m.weight_ih_l0_reverse)), (0, pad)).to(dt)
-        w_hh = torch.stack((m.weight_hh_l0, m.weight_hh_l0_reverse)).to(dt)
-        bias = torch.stack((m.bias_ih_l0 + m.bias_hh_l0, m.bias_ih_l0_reverse + m.bias_hh_l0_reverse)).to(dt)
-        out = bilstm(x.to(dt).contiguous(), lens, w_ih.contiguous(), w_hh.contiguous(), bias.contiguous())
-        vec = out.float().sum(1) / lens.clamp(min=1).unsqueeze(1).float()
-        return vec.to(out.dtype), out
+        lens = query_length.to(device=emb.device, dtype=torch.int32).contiguous()
+        return self._layers(emb[:, :Lmax], lens)
