@@ -1,5 +1,6 @@
-"""Golden vectors for the BAN encoders (row N2): outputs AND gradients of the reference's own `VisualEncoder` and
-`QueryEncoder` (models/BANlib/model.py:8-86), imported from /root/reference in the build container and run on the CPU
+"""Golden vectors for the BAN encoders and trunk (row N2): outputs AND gradients of the reference's own `VisualEncoder` and
+`QueryEncoder` (models/BANlib/model.py:8-86), and of the trunk of `BAN.forward` (models/BAN.py:75-84: encoders ->
+`CQAttention` -> cross encoder -> `TemporalDifference`) composed from the reference's modules, imported from /root/reference in the build container and run on the CPU
 in fp32 with a deterministic numpy weight recipe.  Writes tests/golden/g_ban_enc.npz.  Test infrastructure only.
 
     python oracle/gen_golden_ban_enc.py
@@ -88,6 +89,62 @@ def main():
     for k, p in qenc.biLSTM.named_parameters():
         out["q_p_" + k] = p.detach().numpy()
         out["q_g_" + k] = p.grad.numpy()
+    # ---- the trunk of BAN.forward (models/BAN.py:75-84) composed from the reference's own modules, eval mode:
+    # visual / query encoders -> CQAttention -> cross encoder -> TemporalDifference.  vdim 24, dim 8 (fuse_dim 16),
+    # two LSTM layers, T = vlen = 12, 4 clips
+    from types import SimpleNamespace
+    Bt, Tt, vdim, dim, NL, Et, Vt = 4, 12, 24, 8, 2, 12, 30
+    fd = 2 * dim
+    cfg = SimpleNamespace(model=SimpleNamespace(fuse_dim=fd, droprate=0.1))
+    ve, ce = M.VisualEncoder(vdim, dim, NL), M.VisualEncoder(4 * fd, dim, NL)
+    qe = M.QueryEncoder(Vt + 2, dim, embed_dim=Et, num_layers=NL, pre_train_weights=None)
+    gl = rng.standard_normal((Vt, Et)).astype(np.float32)
+    qe.pad_vec = torch.nn.Parameter(torch.zeros(1, Et), requires_grad=False)
+    qe.unk_vec = torch.nn.Parameter(torch.from_numpy(rng.uniform(-0.3, 0.3, (1, Et)).astype(np.float32)), requires_grad=True)
+    qe.glove_vec = torch.nn.Parameter(torch.from_numpy(gl), requires_grad=False)
+    cq = M.CQAttention(fd)
+    tdm = M.TemporalDifference(cfg, in_dim=fd, layer_num=2)
+    mods = {"visual_encoder": ve, "query_encoder": qe, "cross_encoder": ce, "cqa_att": cq, "boundary_aware": tdm}
+    for name in ("visual_encoder", "cross_encoder", "cqa_att", "boundary_aware"):
+        fill(mods[name], rng, 0.3)
+    fill(qe.biLSTM, rng, 0.3)
+    with torch.no_grad():
+        cq.bias.fill_(0.37)                      # (cancelled by both softmaxes; non-zero on purpose)
+    for m in mods.values():
+        m.eval()
+    xv = torch.from_numpy(rng.standard_normal((Bt, Tt, vdim)).astype(np.float32)).requires_grad_(True)
+    vl = torch.tensor([12, 7, 12, 3])
+    ql = torch.tensor([5, 9, 2, 7])
+    tk = torch.zeros(Bt, 9, dtype=torch.long)
+    for b, n in enumerate(ql.tolist()):
+        tk[b, :n] = torch.from_numpy(rng.integers(1, Vt + 2, size=n))
+    video_feature, clip_feature = ve(xv, vl, Tt)
+    sentence_feature, word_feature = qe(tk, ql)
+    mask_word = M.sequence2mask(ql)
+    cat_feature = cq(clip_feature, word_feature, mask_word)
+    _, fuse_feature = ce(cat_feature, vl, Tt)
+    o = tdm(fuse_feature)
+    hidden_b, hidden_c = o["feature"]
+    ws = {k: torch.from_numpy(rng.standard_normal(tuple(v.shape)).astype(np.float32))
+          for k, v in dict(fuse_feature=fuse_feature, hidden_b=hidden_b, hidden_c=hidden_c, td=o["td"],
+                           sentence_feature=sentence_feature, video_feature=video_feature).items()}
+    loss = sum((v * ws[k]).sum() for k, v in dict(fuse_feature=fuse_feature, hidden_b=hidden_b, hidden_c=hidden_c, td=o["td"],
+                                                  sentence_feature=sentence_feature, video_feature=video_feature).items())
+    loss.backward()
+    out.update(t_x=xv.detach().numpy(), t_vlen=vl.numpy().astype(np.int32), t_tok=tk.numpy(), t_qlen=ql.numpy().astype(np.int32),
+               t_glove=gl, t_dx=xv.grad.numpy(), t_cat=cat_feature.detach().numpy(),
+               t_fuse_feature=fuse_feature.detach().numpy(), t_hidden_b=hidden_b.detach().numpy(),
+               t_hidden_c=hidden_c.detach().numpy(), t_td=o["td"].detach().numpy(),
+               t_sentence_feature=sentence_feature.detach().numpy(), t_video_feature=video_feature.detach().numpy())
+    for k, w in ws.items():
+        out["t_w_" + k] = w.numpy()
+    for name, m in mods.items():
+        for k, p in m.named_parameters():
+            if k.startswith("embedding."):
+                continue
+            out[f"t_p_{name}.{k}"] = p.detach().numpy()
+            if p.requires_grad:
+                out[f"t_g_{name}.{k}"] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
     np.savez_compressed(os.path.join(GOLD, "g_ban_enc.npz"), **out)
     print("wrote g_ban_enc.npz:", {k: v.shape for k, v in out.items() if k.endswith(("_y", "_vec"))})
 

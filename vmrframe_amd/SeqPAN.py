@@ -172,6 +172,55 @@ def _init_param(name: str, shape, gen: torch.Generator) -> torch.Tensor:
     return kaiming_u(t)
 
 
+def cq_attention_core(ctx, qry, cmask, qmask, w4C, w4Q, w4mlu, dc, prefix):
+    """cat4 = [C | c2q | C*c2q | C*q2c] as rows [B*Lc, 4D] of CQAttention (reference layers.py:417-437; BAN's variant
+    models/BANlib/model.py:100-143 is the same computation with an all-ones context mask and a scalar bias that both
+    softmaxes cancel).  The rank-1 terms of the trilinear score are folded onto the SHORTER stream so the long [B,T,D]
+    tensor is read once by the MFMA GEMM and never by an elementwise pass:
+      S = C.(Q*w4mlu + w4C)^T + (Q.w4Q)^T        (query stream short)
+        = (C*w4mlu + w4Q).Q^T + C.w4C            (context stream short)
+    and q2c is re-associated as S_.(S_t^T.C) (no [Lc,Lc] intermediate)."""
+    B, Lc, D = ctx.shape
+    Lq = qry.shape[1]
+    cdt = ctx.dtype
+    # (tee: the apply stage reads the aliases, so the gradients of ctx / qry from the apply stage join the dropout
+    #  backward inside its kernel instead of through separate add passes)
+    if ops.CQ_TEE:
+        cd, ctx = ops.dropout(ctx, dc.next(prefix + ".c"), tee=True)
+        qd, qry = ops.dropout(qry, dc.next(prefix + ".q"), tee=True)
+    else:
+        cd = ops.dropout(ctx, dc.next(prefix + ".c"))
+        qd = ops.dropout(qry, dc.next(prefix + ".q"))
+    whole = ops.cq_block_supported(Lc, Lq, D, cdt)   # score + softmaxes + apply stage as fused kernels each way
+    if Lq <= Lc:      # (rank-1 terms: one scale-shift kernel + one matrix-vector kernel on the short stream)
+        bop = ops.scale_shift(qd, w4mlu, w4C)
+        colterm = ops.narrow_linear(qd.reshape(B * Lq, D), w4Q, None, N=1).view(B, Lq)
+        if whole:
+            return ops.cq_block(ctx, qry, cd, bop, colterm, cmask, qmask, 0)
+        fused = ops.cq_score_supported(Lc, Lq, D, cdt)
+        if fused:     # score + both softmaxes in one kernel: short operand in LDS, video rows streamed once
+            S_p, S_tp = ops.cq_score(cd, bop, colterm, cmask, qmask, 0)
+        else:
+            S2, rowterm = ops.bmm(cd, bop, 0, 0, out_f32=True), None
+    else:
+        aop = ops.scale_shift(cd, w4mlu, w4Q)
+        rowterm = ops.narrow_linear(cd.reshape(B * Lc, D), w4C, None, N=1).view(B, Lc)
+        if whole:
+            return ops.cq_block(ctx, qry, qd, aop, rowterm, qmask, cmask, 1)
+        fused = ops.cq_score_supported(Lq, Lc, D, cdt)
+        if fused:
+            S_p, S_tp = ops.cq_score(qd, aop, rowterm, qmask, cmask, 1)
+        else:
+            S2, colterm = ops.bmm(aop, qd, 0, 0, out_f32=True), None
+    if not fused:
+        # both masked softmaxes in one HIP kernel; outputs are 8-padded so the GEMMs below use 16-byte loads
+        S_p, S_tp = ops.cq_softmax(S2, rowterm, colterm, cmask, qmask, cdt)
+    c2q = ops.bmm(S_p, qry, 0, 1)                      # [B,Lc,D]
+    mid = ops.bmm(S_tp, ctx, 1, 1)                     # S_t^T . C   [B,Lq,D]
+    q2c = ops.bmm(S_p, mid, 0, 1)                      # [B,Lc,D]
+    return ops.cat4(ctx.reshape(B * Lc, D), c2q.reshape(B * Lc, D), q2c.reshape(B * Lc, D))
+
+
 class SeqPAN(nn.Module):
     """Drop-in for reference models/SeqPAN.py:10-95 (same constructor, forward
     signature, output dict and state_dict keys)."""
@@ -381,52 +430,10 @@ class SeqPAN(nn.Module):
         return self._lin(o2, prefix + ".dense_2", drop=dc.next(prefix + ".d2"), residual=o1r)
 
     def _cq_attention(self, prefix, ctx, qry, cmask, qmask, dc):
-        """CQAttention.forward (reference layers.py:417-437).  The rank-1 terms of the
-        trilinear score are folded onto the SHORTER stream so the long [B,T,D] tensor is read
-        once by the MFMA GEMM and never by an elementwise pass:
-          S = C.(Q*w4mlu + w4C)^T + (Q.w4Q)^T        (query stream short)
-            = (C*w4mlu + w4Q).Q^T + C.w4C            (context stream short)
-        and q2c is re-associated as S_.(S_t^T.C) (no [Lc,Lc] intermediate)."""
-        B, Lc, D = ctx.shape
-        Lq = qry.shape[1]
-        cdt = ctx.dtype
-        w4C, w4Q, w4mlu = self.P(prefix + ".w4C"), self.P(prefix + ".w4Q"), self.P(prefix + ".w4mlu")
-        # (tee: the apply stage reads the aliases, so the gradients of ctx / qry from the apply stage join the dropout
-        #  backward inside its kernel instead of through separate add passes)
-        if ops.CQ_TEE:
-            cd, ctx = ops.dropout(ctx, dc.next(prefix + ".c"), tee=True)
-            qd, qry = ops.dropout(qry, dc.next(prefix + ".q"), tee=True)
-        else:
-            cd = ops.dropout(ctx, dc.next(prefix + ".c"))
-            qd = ops.dropout(qry, dc.next(prefix + ".q"))
-        whole = ops.cq_block_supported(Lc, Lq, D, cdt)   # score + softmaxes + apply stage as fused kernels each way
-        if Lq <= Lc:      # (rank-1 terms: one scale-shift kernel + one matrix-vector kernel on the short stream)
-            bop = ops.scale_shift(qd, w4mlu, w4C)
-            colterm = ops.narrow_linear(qd.reshape(B * Lq, D), w4Q, None, N=1).view(B, Lq)
-            if whole:
-                return self._lin(ops.cq_block(ctx, qry, cd, bop, colterm, cmask, qmask, 0), prefix + ".cqa_linear")
-            fused = ops.cq_score_supported(Lc, Lq, D, cdt)
-            if fused:     # score + both softmaxes in one kernel: short operand in LDS, video rows streamed once
-                S_p, S_tp = ops.cq_score(cd, bop, colterm, cmask, qmask, 0)
-            else:
-                S2, rowterm = ops.bmm(cd, bop, 0, 0, out_f32=True), None
-        else:
-            aop = ops.scale_shift(cd, w4mlu, w4Q)
-            rowterm = ops.narrow_linear(cd.reshape(B * Lc, D), w4C, None, N=1).view(B, Lc)
-            if whole:
-                return self._lin(ops.cq_block(ctx, qry, qd, aop, rowterm, qmask, cmask, 1), prefix + ".cqa_linear")
-            fused = ops.cq_score_supported(Lq, Lc, D, cdt)
-            if fused:
-                S_p, S_tp = ops.cq_score(qd, aop, rowterm, qmask, cmask, 1)
-            else:
-                S2, colterm = ops.bmm(aop, qd, 0, 0, out_f32=True), None
-        if not fused:
-            # both masked softmaxes in one HIP kernel; outputs are 8-padded so the GEMMs below use 16-byte loads
-            S_p, S_tp = ops.cq_softmax(S2, rowterm, colterm, cmask, qmask, cdt)
-        c2q = ops.bmm(S_p, qry, 0, 1)                      # [B,Lc,D]
-        mid = ops.bmm(S_tp, ctx, 1, 1)                     # S_t^T . C   [B,Lq,D]
-        q2c = ops.bmm(S_p, mid, 0, 1)                      # [B,Lc,D]
-        cat4 = ops.cat4(ctx.reshape(B * Lc, D), c2q.reshape(B * Lc, D), q2c.reshape(B * Lc, D))
+        """CQAttention.forward (reference layers.py:417-437): the score / softmax / apply core (`cq_attention_core`
+        below, shared with BAN's variant) followed by `cqa_linear`."""
+        cat4 = cq_attention_core(ctx, qry, cmask, qmask, self.P(prefix + ".w4C"), self.P(prefix + ".w4Q"),
+                                 self.P(prefix + ".w4mlu"), dc, prefix)
         return self._lin(cat4, prefix + ".cqa_linear")
 
     def _predict_encoder(self, x, vmask, B, T, dc, tag):
