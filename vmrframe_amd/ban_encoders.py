@@ -25,13 +25,16 @@ sampling, losses) is still out.
 """
 from __future__ import annotations
 
-import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
 
 from . import _lib as L
 from . import ops
+
+
+FUSED_STEP = os.environ.get("VMR_LSTM_FUSED", "1") != "0"      # A/B: one launch per step (bf16, H = 256 / 512) vs product + cell
 
 
 def _reverse_rows(x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
@@ -60,12 +63,23 @@ class _BiLSTM(torch.autograd.Function):
         for z in range(2):                                                # x-part of every step, biases in the epilogue
             ops.mm(xs[z].view(B * T, I), w_ih[z], 0, 0, out=gx[z].view(B * T, 4 * H), bias=bias32[z], flags=L.EPI_BIAS)
         c = torch.zeros(2, B, H, device=dev)
-        hs = torch.zeros(2, B, H, device=dev, dtype=dt)
-        gh = torch.zeros(2, B, 4 * H, device=dev)
         act = torch.empty(2, B, T, 4 * H, device=dev, dtype=dt)
         cs = torch.empty(2, B, T, H, device=dev)
         hp = torch.empty(2, B, T, H, device=dev, dtype=dt)
         y = torch.zeros(B, T, 2 * H, device=dev, dtype=dt)
+        ctx.fused = bool(FUSED_STEP and lib.vmr_lstm_step_supported(H, dc))
+        if ctx.fused:            # product + gates + state in one launch per step; h ping-pongs between two buffers
+            hb = torch.zeros(2, 2, B, H, device=dev, dtype=dt)
+            for s in range(T):
+                L.check(lib.vmr_lstm_step_fwd(gx.data_ptr(), hb[s & 1].data_ptr(), w_hh.data_ptr(), lens.data_ptr(),
+                                              c.data_ptr(), hb[(s + 1) & 1].data_ptr(), act.data_ptr(), cs.data_ptr(),
+                                              hp.data_ptr(), y.data_ptr(), B, T, H, s, dc, L.stream_ptr()),
+                        "vmr_lstm_step_fwd")
+            ctx.save_for_backward(xs, lens, w_ih, w_hh, act, cs, hp)
+            ctx.mark_non_differentiable(lens)
+            return y
+        hs = torch.zeros(2, B, H, device=dev, dtype=dt)
+        gh = torch.zeros(2, B, 4 * H, device=dev)
         f32out = L.EPI_OUT_F32 if dc != L.F32 else 0
         for s in range(T):
             if s > 0:                                                     # gh[z] = hs[z] . w_hh[z]^T, both directions
@@ -90,7 +104,13 @@ class _BiLSTM(torch.autograd.Function):
         dh = torch.zeros(2, B, H, device=dev)
         dcell = torch.zeros(2, B, H, device=dev)
         f32out = L.EPI_OUT_F32 if dc != L.F32 else 0
-        for s in range(T - 1, -1, -1):
+        if ctx.fused:
+            whht = w_hh.transpose(1, 2).contiguous()                      # [2, H, 4H]: the K-contiguous operand of dg . W_hh
+            for s in range(T - 1, -1, -1):
+                L.check(lib.vmr_lstm_step_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), whht.data_ptr(),
+                                              dcell.data_ptr(), dg.data_ptr(), B, T, H, s, dc, L.stream_ptr()),
+                        "vmr_lstm_step_bwd")
+        for s in (() if ctx.fused else range(T - 1, -1, -1)):
             L.check(lib.vmr_lstm_cell_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), dh.data_ptr(),
                                           dcell.data_ptr(), dg.data_ptr(), B, T, H, s, dc, L.stream_ptr()),
                     "vmr_lstm_cell_bwd")
@@ -111,7 +131,8 @@ class _BiLSTM(torch.autograd.Function):
 
 
 def bilstm(x, lens, w_ih, w_hh, bias):
-    return _BiLSTM.apply(x, lens, w_ih, w_hh, bias)
+    """lens is clamped to [0, T]: the kernels index time by it."""
+    return _BiLSTM.apply(x, lens.clamp(min=0, max=x.shape[1]), w_ih, w_hh, bias)
 
 
 class _EncoderBase(nn.Module):
@@ -178,9 +199,11 @@ class QueryEncoder(_EncoderBase):
         self.unk_vec = nn.Parameter(unk, requires_grad=True)
         self.glove_vec = nn.Parameter(w.clone(), requires_grad=False)
 
-    def forward(self, query_tokens, query_length):
+    def forward(self, query_tokens, query_length, max_len=None):
+        """max_len (not in the reference): the longest query of the batch when the caller knows it -- spares the
+        device-to-host read of `query_length.max()`, which is illegal while a hipGraph is being captured."""
         table = torch.cat([self.pad_vec, self.unk_vec, self.glove_vec], dim=0)
         emb = ops.embedding(query_tokens, table, padding_idx=0)                # [B, L, E] fp32
-        Lmax = int(query_length.max())                                        # pad_packed_sequence trims to the longest
+        Lmax = int(query_length.max()) if max_len is None else int(max_len)   # pad_packed_sequence trims to the longest
         lens = query_length.to(device=emb.device, dtype=torch.int32).contiguous()
         return self._layers(emb[:, :Lmax], lens)

@@ -111,13 +111,14 @@ class BANTrunk(nn.Module):
         self.drop_step = None
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
 
-    def forward(self, data_visual, data_text, video_seq_len, text_seq_len):
-        self._calls += 1
+    def forward(self, data_visual, data_text, video_seq_len, text_seq_len, max_qlen=None):
+        if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            self._calls += 1        # (a captured step replays one seed set; the device step counter varies the masks)
         self._cache.state.reset()
         cqdc = ops.DropCtx(self.cqa_att.dropout, self.training, self.base_seed + 7919 * self._calls, self.drop_step)
         dc = ops.DropCtx(self.droprate, self.training, self.base_seed + 104729 * self._calls, self.drop_step)
         video_feature, clip_feature = self.visual_encoder(data_visual, video_seq_len, self.vlen)
-        sentence_feature, word_feature = self.query_encoder(data_text, text_seq_len)
+        sentence_feature, word_feature = self.query_encoder(data_text, text_seq_len, max_len=max_qlen)
         Lq = word_feature.shape[1]
         mask_word = torch.arange(Lq, device=word_feature.device).unsqueeze(0) < text_seq_len.to(word_feature.device).view(-1, 1)
         cat_feature = self.cqa_att(clip_feature, word_feature, mask_word, cqdc)

@@ -94,6 +94,139 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const T* __restrict_
   dg[ga + 3 * H] = (T)(dht * th * og * (1.f - og));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused step (bf16, H = 256 or 512): the recurrent product AND the pointwise half in one launch -- a step is one graph node
+// instead of two, and the product stops going through the generic register-staged GEMM (64 batch rows fill no 128-row tile).
+// Both operands go global -> fragment registers directly (16-byte loads in MFMA layout; W_hh is L2-resident, h is 32-64 KB).
+// What shapes the tiling: ONE WAVE sustains only ~6.7 GB/s of loads, so a step costs (bytes per wave) x 150 ns
+// per KiB.  The first version (64 batch x 16 units x 4 gates per workgroup, each wave re-loading the whole 32-KiB weight tile:
+// 40-64 KiB per wave) took 8.7 / 11.0 us per step; these tiles load 16 KiB per wave and spread over 128-256 workgroups:
+//   forward:  workgroup = (z, 4 units, 64 batch rows), wave = 16 batch rows; the 16 weight rows of the tile are the FOUR
+//             gates of the four units (MFMA column n: gate n >> 2, unit n & 3), so one accumulator holds i, f, g, o of a
+//             (batch row, unit) in four lanes of the same 16-lane group -- regrouped through 4 KiB of LDS to one
+//             (batch row, unit) per thread;
+//   backward: workgroup = (z, 16 units, 16 batch rows), wave w = the K range of gate w (K = 4H split four ways), partial
+//             dh tiles summed through 4 KiB of LDS; then one (batch row, unit) per thread.
+// h ping-pongs between two [2][B][H] buffers (a workgroup reads ALL of h_{s-1} while others write h_s).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS>
+__device__ __forceinline__ void ld_frags(const bf16_t* __restrict__ p, bf16x8 (&f)[KS]) {   // KS k-steps of 32, lane offset applied
+#pragma unroll
+  for (int k = 0; k < KS; ++k) f[k] = *reinterpret_cast<const bf16x8*>(p + k * 32);
+}
+
+template <int HH>
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ hprev,
+                                                            const bf16_t* __restrict__ whh, const int* __restrict__ len,
+                                                            float* __restrict__ c, bf16_t* __restrict__ hnext,
+                                                            bf16_t* __restrict__ act, float* __restrict__ cs,
+                                                            bf16_t* __restrict__ hp, bf16_t* __restrict__ y, int B, int Tn, int s) {
+  constexpr int H = HH, KS = HH / 32;
+  __shared__ float tile[64][17];                     // [batch row of the workgroup][gate * 4 + unit]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int z = blockIdx.y, u0 = blockIdx.x * 4, b0 = blockIdx.z * 64;
+  const int r16 = lane & 15, kq = lane >> 4;
+  // this thread's (batch row, unit) of the 64 x 4 tile and its pointwise operands, requested FIRST and unconditionally
+  // (row clamped).  One pair per thread keeps the memory instructions per wave low: a wave issues roughly one every
+  // 150 ns whatever its width, and the lane-per-MFMA-column form (4 rows x 9 narrow stores per lane) spent 5 us on them.
+  const int m = threadIdx.x >> 2, un = threadIdx.x & 3, j = u0 + un;
+  const int b = b0 + m, bc = min(b, B - 1);
+  const int64_t zb = (int64_t)z * B + bc;
+  const int64_t ga = (zb * Tn + s) * 4 * H + j;
+  const int L = len[bc];
+  float gxv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) gxv[g] = (float)gx[ga + g * H];
+  const float cprev = c[zb * H + j];
+  const bf16_t hpv = hprev[zb * H + j];              // (both ping-pong buffers start zeroed: valid at s = 0 too)
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (s > 0) {                                       // (h_{-1} = 0: step 0 has no recurrent part)
+    bf16x8 a[KS], bw[KS];
+    ld_frags<KS>(hprev + ((int64_t)z * B + min(b0 + w * 16 + r16, B - 1)) * H + kq * 8, a);
+    ld_frags<KS>(whh + ((int64_t)z * 4 * H + (r16 >> 2) * H + u0 + (r16 & 3)) * H + kq * 8, bw);
+    __builtin_amdgcn_sched_barrier(0);               // every fragment load in flight before the first MFMA
+#pragma unroll
+    for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], bw[k], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[w * 16 + kq * 4 + r][r16] = acc[r];   // D[batch kq*4 + r][n = gate * 4 + unit]
+  __syncthreads();
+  if (b >= B) return;
+  hp[(zb * Tn + s) * H + j] = hpv;
+  if (s >= L) {
+    act[ga] = (bf16_t)0.f; act[ga + H] = (bf16_t)0.f; act[ga + 2 * H] = (bf16_t)0.f; act[ga + 3 * H] = (bf16_t)0.f;
+    cs[(zb * Tn + s) * H + j] = cprev;
+    hnext[zb * H + j] = hpv;
+    return;
+  }
+  const float ig = sigm(gxv[0] + tile[m][un]);
+  const float fg = sigm(gxv[1] + tile[m][4 + un]);
+  const float gg = tanh_f(gxv[2] + tile[m][8 + un]);
+  const float og = sigm(gxv[3] + tile[m][12 + un]);
+  const float cn = fg * cprev + ig * gg;
+  const float hn = og * tanh_f(cn);
+  c[zb * H + j] = cn;
+  cs[(zb * Tn + s) * H + j] = cn;
+  act[ga] = (bf16_t)ig; act[ga + H] = (bf16_t)fg; act[ga + 2 * H] = (bf16_t)gg; act[ga + 3 * H] = (bf16_t)og;
+  hnext[zb * H + j] = (bf16_t)hn;
+  const int t = z == 0 ? s : L - 1 - s;
+  y[((int64_t)b * Tn + t) * 2 * H + z * H + j] = (bf16_t)hn;
+}
+
+template <int HH>
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ act,
+                                                            const float* __restrict__ cs, const int* __restrict__ len,
+                                                            const bf16_t* __restrict__ whht, float* __restrict__ dc,
+                                                            bf16_t* __restrict__ dg, int B, int Tn, int s) {
+  constexpr int H = HH, KS = HH / 32;
+  __shared__ float part[4][16][17];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int z = blockIdx.y, j0 = blockIdx.x * 16, b0 = blockIdx.z * 16;
+  const int r16 = lane & 15, kq = lane >> 4;
+  // this thread's (batch row, unit) of the tile, its pointwise operands first (unconditional, row clamped)
+  const int m = threadIdx.x >> 4, j = j0 + (threadIdx.x & 15);
+  const int b = b0 + m, bc = min(b, B - 1);
+  const int64_t zb = (int64_t)z * B + bc;
+  const int64_t ga = (zb * Tn + s) * 4 * H + j;
+  const int L = len[bc];
+  float av[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) av[g] = (float)act[ga + g * H];
+  const float cn = cs[(zb * Tn + s) * H + j];
+  const float cpv = cs[(zb * Tn + max(s - 1, 0)) * H + j];
+  const float dcv = dc[zb * H + j];
+  const int t = min(max(z == 0 ? s : L - 1 - s, 0), Tn - 1);
+  const float dyv = (float)dy[((int64_t)bc * Tn + t) * 2 * H + z * H + j];
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (s + 1 < Tn) {                                  // dh = dg_{s+1} . W_hh (nothing flows into the last step); wave w: gate w's K range
+    bf16x8 a[KS], bw[KS];
+    ld_frags<KS>(dg + (((int64_t)z * B + min(b0 + r16, B - 1)) * Tn + s + 1) * 4 * H + w * H + kq * 8, a);
+    ld_frags<KS>(whht + ((int64_t)z * H + j0 + r16) * 4 * H + w * H + kq * 8, bw);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], bw[k], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[w][kq * 4 + r][r16] = acc[r];      // D[batch kq*4 + r][unit r16]
+  __syncthreads();
+  if (b >= B) return;
+  if (s >= L) {
+    dg[ga] = (bf16_t)0.f; dg[ga + H] = (bf16_t)0.f; dg[ga + 2 * H] = (bf16_t)0.f; dg[ga + 3 * H] = (bf16_t)0.f;
+    return;
+  }
+  const int n = threadIdx.x & 15;
+  const float dht = dyv + part[0][m][n] + part[1][m][n] + part[2][m][n] + part[3][m][n];
+  const float ig = av[0], fg = av[1], gg = av[2], og = av[3];
+  const float cp = s > 0 ? cpv : 0.f;
+  const float th = tanh_f(cn);
+  const float dct = dcv + dht * og * (1.f - th * th);
+  dc[zb * H + j] = dct * fg;
+  dg[ga] = (bf16_t)(dct * gg * ig * (1.f - ig));
+  dg[ga + H] = (bf16_t)(dct * cp * fg * (1.f - fg));
+  dg[ga + 2 * H] = (bf16_t)(dct * ig * (1.f - gg * gg));
+  dg[ga + 3 * H] = (bf16_t)(dht * th * og * (1.f - og));
+}
+
 // dst[b][s][:] = s < len_b ? src[b][len_b - 1 - s][:] : 0   (its own inverse on the valid part: also maps gradients back)
 template <typename T>
 __global__ __launch_bounds__(256) void lstm_reverse_rows_kernel(const T* __restrict__ src, const int* __restrict__ len,
@@ -138,6 +271,42 @@ extern "C" int vmr_lstm_cell_bwd(const void* dy, const void* act, const void* cs
   else
     hipLaunchKernelGGL(lstm_cell_bwd_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
                        (const float*)act, (const float*)cs, len, (const float*)dh, (float*)dc, (float*)dg, B, T, H, s);
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_lstm_step_supported(int H, int dtype) { return dtype == VMR_BF16 && (H == 256 || H == 512); }
+
+extern "C" int vmr_lstm_step_fwd(const void* gx, const void* hprev, const void* whh, const int* len, void* c, void* hnext,
+                                 void* act, void* cs, void* hp, void* y, int B, int T, int H, int s, int dtype, void* stream) {
+  VMR_CHECK(gx && hprev && whh && len && c && hnext && act && cs && hp && y, "vmr_lstm_step_fwd: null pointer");
+  VMR_CHECK(hprev != hnext, "vmr_lstm_step_fwd: h must ping-pong between two buffers");
+  VMR_CHECK(vmr_lstm_step_supported(H, dtype), "vmr_lstm_step_fwd: unsupported H=%d dtype=%d", H, dtype);
+  VMR_CHECK(B > 0 && T > 0 && s >= 0 && s < T, "vmr_lstm_step_fwd: bad shape B=%d T=%d s=%d", B, T, s);
+  VMR_CHECK((((uintptr_t)hprev | (uintptr_t)whh) & 15) == 0, "vmr_lstm_step_fwd: 16-byte alignment");
+  const dim3 grid(H / 4, 2, (B + 63) / 64);
+#define VMR_LSTM_FWD(HH)                                                                                                      \
+  hipLaunchKernelGGL(lstm_step_fwd_kernel<HH>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gx, (const bf16_t*)hprev, \
+                     (const bf16_t*)whh, len, (float*)c, (bf16_t*)hnext, (bf16_t*)act, (float*)cs, (bf16_t*)hp, (bf16_t*)y, B, T, s)
+  if (H == 256) VMR_LSTM_FWD(256); else VMR_LSTM_FWD(512);
+#undef VMR_LSTM_FWD
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_lstm_step_bwd(const void* dy, const void* act, const void* cs, const int* len, const void* whht, void* dc,
+                                 void* dg, int B, int T, int H, int s, int dtype, void* stream) {
+  VMR_CHECK(dy && act && cs && len && whht && dc && dg, "vmr_lstm_step_bwd: null pointer");
+  VMR_CHECK(vmr_lstm_step_supported(H, dtype), "vmr_lstm_step_bwd: unsupported H=%d dtype=%d", H, dtype);
+  VMR_CHECK(B > 0 && T > 0 && s >= 0 && s < T, "vmr_lstm_step_bwd: bad shape B=%d T=%d s=%d", B, T, s);
+  VMR_CHECK((((uintptr_t)dg | (uintptr_t)whht) & 15) == 0, "vmr_lstm_step_bwd: 16-byte alignment");
+  const dim3 grid(H / 16, 2, (B + 15) / 16);
+  if (H == 256)
+    hipLaunchKernelGGL(lstm_step_bwd_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)act,
+                       (const float*)cs, len, (const bf16_t*)whht, (float*)dc, (bf16_t*)dg, B, T, s);
+  else
+    hipLaunchKernelGGL(lstm_step_bwd_kernel<512>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)act,
+                       (const float*)cs, len, (const bf16_t*)whht, (float*)dc, (bf16_t*)dg, B, T, s);
   VMR_LAUNCH_CHECK();
   return 0;
 }
