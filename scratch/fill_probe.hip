@@ -114,6 +114,44 @@ void run_ring(const unsigned char* buf, int nwg, int64_t wg_stride, int64_t span
          bytes / (ms * 1e-3) / 1e9 / (nwg < 256 ? nwg : 256));
 }
 
+// Width of the access: the same ring with W bytes per lane per instruction (4 / 8 / 16), VGPR loads, one stage of 64 such
+// instructions per wave in flight: is the per-wave ceiling a byte rate or an instruction rate?
+template <int W>
+__global__ __launch_bounds__(256, 2) void probe_width(const unsigned char* __restrict__ src, int64_t span, int steps,
+                                                      unsigned int* __restrict__ sink) {
+  typedef __attribute__((ext_vector_type(W / 4))) unsigned int vec_t;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  unsigned int acc = 0;
+  constexpr int NI = 16;
+  for (int s = 0; s < steps; ++s) {
+    vec_t r[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      r[i] = *reinterpret_cast<const vec_t*>(src + (((int64_t)(blockIdx.x * 4 + wid) * steps + s) * NI + i) * 64 * W % span + lane * W);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc ^= r[i][0];
+  }
+  if (acc == 0x12345u) sink[0] = 1;
+}
+
+template <int W>
+void run_width(const unsigned char* buf, int nwg, int64_t span, unsigned int* sink) {
+  const int steps = 64;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(probe_width<W>, dim3(nwg), dim3(256), 0, 0, buf, span, steps, sink);
+  hipEventRecord(e0);
+  const int reps = 10;
+  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(probe_width<W>, dim3(nwg), dim3(256), 0, 0, buf, span, steps, sink);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double instr = (double)nwg * 4 * steps * 16 * reps;
+  printf("width %2d B/lane, %4d workgroups: %7.1f us/launch  %6.1f GB/s per CU  %6.1f ns per wave-instruction\n", W, nwg, ms * 1e3 / reps,
+         instr * 64 * W / (ms * 1e-3) / 1e9 / 256, ms * 1e-3 / reps / (steps * 16.0) * 1e9);
+}
+
 template <int MODE>
 void run(const char* name, const unsigned char* buf, int nwg, int64_t wg_stride, int64_t span, int steps, unsigned int* sink) {
   hipFuncSetAttribute((const void*)probe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
@@ -169,6 +207,12 @@ int main() {
     for (int k : {1, 2, 4}) run_ring<1, 16384>(buf, 256 * k, stride, span, 16ll * STAGE, sink);
     for (int k : {1, 2, 4, 8}) run_ring<1, 8192>(buf, 256 * k, stride, span, 16ll * STAGE, sink);
     for (int k : {4, 8}) run_ring<2, 4096>(buf, 256 * k, stride, span, 16ll * STAGE, sink);
+  }
+  printf("--- access width (L2-resident 2 MiB, 16 loads in flight per wave)\n");
+  for (int nwg : {256, 512, 1024}) {
+    run_width<4>(buf, nwg, 2 << 20, sink);
+    run_width<8>(buf, nwg, 2 << 20, sink);
+    run_width<16>(buf, nwg, 2 << 20, sink);
   }
   return 0;
 }
