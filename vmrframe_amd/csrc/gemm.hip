@@ -764,7 +764,7 @@ __device__ __forceinline__ void gemm_dma_body(const vmr_gemm_t& g, int tiles_m, 
 }
 
 template <bool TA, bool TB, int BK, int NST, int MT = 4, int WM = 2>
-__global__ __launch_bounds__(WM * 128, (WM == 2 ? (BK == 32 && NST == 3 ? 3 : 2) : 1)) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(WM * 128, (WM == 2 ? (BK == 32 && NST == 3 ? 3 : 2) : (MT == 2 ? 2 : 1))) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   gemm_dma_body<TA, TB, BK, NST, MT, WM>(g, tiles_m, tiles_n, smem, blockIdx.x, blockIdx.z, gridDim.z);
 }
@@ -1564,6 +1564,20 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   }
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)Z);
   if (g.splitk > 1 && g.Z1 * g.Z2 == 1) grid = dim3((unsigned)(tiles_m * tiles_n * g.splitk), 1, 1);   // see tile_coord
+  // VMR_GEMM_W16=1 (experiment): the same 128 x 128 x 64 two-stage tile worked by EIGHT waves (4 x 2, wave tile
+  // 32 x 64, <= 128 VGPRs) so that two resident workgroups put 16 waves on the CU -- the operand fill follows the number of
+  // waves issuing loads.  x.W^T layout, register-direct epilogue only.
+  static int g_w16 = -1;
+  if (g_w16 < 0) {
+    const char* e = getenv("VMR_GEMM_W16");
+    g_w16 = e ? atoi(e) : 0;
+  }
+  if (g_w16 && dma_ok && g_gemm_dma == 2 && !g.transA && !g.transB && g.splitk <= 1 && !(g.flags & VMR_EPI_ACCUM)) {
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false, 64, 2, 2, 4>), grid, dim3(512), 2 * (128 * 64 * 2 + 128 * 64 * 2),
+                       (hipStream_t)stream, g, tiles_m, tiles_n);
+    VMR_LAUNCH_CHECK();
+    return 0;
+  }
   float* colsum_fallback = nullptr;
   if (g.a_colsum && !dma_ok) {   // only the LDS-DMA kernel folds the column sums into the product
     colsum_fallback = g.a_colsum;
