@@ -145,6 +145,59 @@ def main():
             out[f"t_p_{name}.{k}"] = p.detach().numpy()
             if p.requires_grad:
                 out[f"t_g_{name}.{k}"] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    # ---- the proposal head (models/BAN.py:98,107-118) from the reference's modules: PropPositionalEncoding ->
+    # Adaptive_Prop_Interaction (2 edge-conv blocks) -> predictor2 / predictor_offset, and contrast_encoder_t
+    Bh, Nh, Dh, dimh, Ch = 3, 10, 16, 8, 12
+    hcfg = SimpleNamespace(model=SimpleNamespace(gcn=SimpleNamespace(hidden_size=Dh, num_blocks=2)))
+    pe_m = M.PropPositionalEncoding(Dh, dimh)
+    gcn = M.Adaptive_Prop_Interaction(hcfg)
+    pred2 = M.NaivePredictor(Dh, Dh, intermediate=True)
+    poff = torch.nn.Sequential(torch.nn.Linear(Dh, Dh), torch.nn.ReLU(inplace=True), torch.nn.Dropout(0.1), torch.nn.Linear(Dh, 2))
+    cet = torch.nn.Sequential(torch.nn.Linear(Dh, Ch), torch.nn.ReLU(inplace=True), torch.nn.Linear(Ch, Ch))
+    hm = {"prop_pe": pe_m, "prop_interact": gcn, "predictor2": pred2, "predictor_offset": poff, "contrast_encoder_t": cet}
+    for m in hm.values():
+        fill(m, rng, 0.4)
+        m.eval()
+    pf = torch.from_numpy(rng.standard_normal((Bh * Nh, Dh)).astype(np.float32)).requires_grad_(True)
+    st = rng.integers(0, 100, size=Bh * Nh)
+    se = torch.from_numpy(np.stack([st, st + rng.integers(1, 28, size=Bh * Nh)], axis=1).astype(np.int64))
+    sf = torch.from_numpy(rng.standard_normal((Bh, Dh)).astype(np.float32)).requires_grad_(True)
+    xh = pe_m(pf.view(-1, Dh), se.view(-1, 2)).view(Bh, Nh, Dh)
+    xh = gcn(xh)
+    fp = pred2(xh)
+    off = poff(xh)
+    sp = cet(sf)
+    wf, wo, wsp = (torch.from_numpy(rng.standard_normal(tuple(t.shape)).astype(np.float32)) for t in (fp, off, sp))
+    ((fp * wf).sum() + (off * wo).sum() + (sp * wsp).sum()).backward()
+    out.update(h_pf=pf.detach().numpy(), h_se=se.numpy(), h_sf=sf.detach().numpy(), h_final_pred=fp.detach().numpy(),
+               h_offset=off.detach().numpy(), h_sen_proj=sp.detach().numpy(), h_gcn_out=xh.detach().numpy(),
+               h_w_final_pred=wf.numpy(), h_w_offset=wo.numpy(), h_w_sen_proj=wsp.numpy(), h_dpf=pf.grad.numpy(), h_dsf=sf.grad.numpy())
+    for name, m in hm.items():
+        for k, p in m.named_parameters():
+            out[f"h_p_{name}.{k}"] = p.detach().numpy()
+            out[f"h_g_{name}.{k}"] = p.grad.numpy()
+    # ---- the sampler (models/BANlib/model.py:371-435): the reference's own Aaptive_Proposal_Sampling on a random score map
+    # over a sparse mask, N = 32; two parameter sets (the anet config's topk 20 / neighbor 3 / negative 0 at thresh 0.7 as
+    # BAN.py:40 passes it, and the function's defaults with negatives)
+    Ns = 32
+    sp_pool = M.SparseMaxPool([7, 4, 4], Ns)
+    mask2d = sp_pool.mask2d
+    for tag, (tk, nb, ng, th) in {"a": (20, 3, 0, 0.7), "b": (5, 16, 16, 0.5), "c": (3, 2, 4, 0.3)}.items():
+        smp = M.Aaptive_Proposal_Sampling(tk, nb, ng, th)
+        Bs, Ds = 3, 4
+        score = torch.from_numpy(rng.uniform(0, 1, (Bs, Ns, Ns)).astype(np.float32)) * mask2d
+        map2d = torch.from_numpy(rng.standard_normal((Bs, Ns, Ns, Ds)).astype(np.float32))
+        offg = torch.from_numpy(rng.standard_normal((Bs, Ns, Ns, 2)).astype(np.float32))
+        tmap = torch.from_numpy(rng.standard_normal((Bs, Ns, Ns)).astype(np.float32))
+        try:
+            pfeat, pse, og, psc = smp(score, mask2d, map2d, offg, tmap)
+        except RuntimeError:
+            continue
+        n_per = pse.shape[0] // Bs
+        out.update({f"s{tag}_score": score.numpy(), f"s{tag}_mask": mask2d.numpy(), f"s{tag}_map2d": map2d.numpy(),
+                    f"s{tag}_offg": offg.numpy(), f"s{tag}_tmap": tmap.numpy(), f"s{tag}_pse": pse.numpy().reshape(Bs, n_per, 2),
+                    f"s{tag}_pfeat": pfeat.numpy(), f"s{tag}_og": og.numpy(), f"s{tag}_psc": psc.numpy(),
+                    f"s{tag}_params": np.asarray([tk, nb, ng, th], dtype=np.float64)})
     np.savez_compressed(os.path.join(GOLD, "g_ban_enc.npz"), **out)
     print("wrote g_ban_enc.npz:", {k: v.shape for k, v in out.items() if k.endswith(("_y", "_vec"))})
 
