@@ -198,6 +198,50 @@ def main():
                     f"s{tag}_offg": offg.numpy(), f"s{tag}_tmap": tmap.numpy(), f"s{tag}_pse": pse.numpy().reshape(Bs, n_per, 2),
                     f"s{tag}_pfeat": pfeat.numpy(), f"s{tag}_og": og.numpy(), f"s{tag}_psc": psc.numpy(),
                     f"s{tag}_params": np.asarray([tk, nb, ng, th], dtype=np.float64)})
+    # ---- the whole model: the reference's BAN(cfg, pre_train_emb).forward and train_engine_BAN (models/BAN.py:14-134,
+    # 211-258), eval mode (no dropout), CPU fp32
+    torch.cuda.synchronize = lambda *a, **k: None
+    BANmod = importlib.import_module("models.BAN")
+    vl_, fd_, dm_ = 16, 64, 32
+    cfgb = SimpleNamespace(device="cpu",
+                           model=SimpleNamespace(vlen=vl_, topk=3, neighbor=2, negative=0, prop_num=9, sparse_sample=True,
+                                                 pooling_counts=[3, 2, 2], fuse_dim=fd_, vdim=24, dim=dm_, lstm_layer=2,
+                                                 query_embed_dim=12, contrast_dim=8, droprate=0.1,
+                                                 gcn=SimpleNamespace(num_blocks=2, k=9, hidden_size=fd_)),
+                           loss=SimpleNamespace(min_iou=0.3, max_iou=0.9, bce=1.0, refine=0.7, td=0.5, offset=0.8, contrast=0.6))
+    glb = rng.standard_normal((30, 12)).astype(np.float32)
+    ban = BANmod.BAN(cfgb, pre_train_emb=np.concatenate([np.zeros((2, 12), np.float32), glb]))
+    # the constructor's pre-trained branch: tables as its forward reads them
+    fill(ban, rng, 0.25)
+    with torch.no_grad():
+        ban.query_encoder.pad_vec.zero_()
+        ban.query_encoder.glove_vec.copy_(torch.from_numpy(np.concatenate([np.zeros((2, 12), np.float32), glb])))
+    ban.eval()
+    Bb = 3
+    dv = torch.from_numpy(rng.standard_normal((Bb, vl_, 24)).astype(np.float32))
+    vlb = torch.tensor([16, 11, 16])
+    qlb = torch.tensor([6, 9, 3])
+    tkb = torch.zeros(Bb, 9, dtype=torch.long)
+    for b_, n_ in enumerate(qlb.tolist()):
+        tkb[b_, :n_] = torch.from_numpy(rng.integers(1, 34, size=n_))
+    data = {"vfeats": dv, "words_ids": tkb, "vlens": vlb, "tlens": qlb,
+            "start_end_offset": torch.from_numpy(rng.standard_normal((Bb, vl_, vl_, 2)).astype(np.float32)),
+            "iou2ds": torch.from_numpy(rng.uniform(0, 1, (Bb, vl_, vl_)).astype(np.float32)),
+            "dist_idxs": torch.from_numpy(rng.uniform(0, 1, (Bb, 2, vl_)).astype(np.float32)),
+            "map2d_contrasts": torch.from_numpy(rng.integers(0, 2, (Bb, 2, vl_, vl_)).astype(bool))}
+    lossb, outb = BANmod.train_engine_BAN(ban, data, cfgb)
+    lossb.backward()
+    out["b_loss"] = np.asarray(float(lossb))
+    for k, v in data.items():
+        out["b_in_" + k] = v.numpy()
+    for k in ("tmap", "map2d_proj", "sen_proj", "coarse_pred", "final_pred", "offset", "offset_gt", "td"):
+        out["b_out_" + k] = outb[k].detach().numpy()
+    out["b_out_map2d_mask"] = outb["map2d_mask"].numpy()
+    for k, p in ban.named_parameters():
+        out["b_p_" + k] = p.detach().numpy()
+        if p.requires_grad:
+            out["b_g_" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    print("BAN loss", float(lossb), "coarse_pred[0]", outb["coarse_pred"][:9].tolist())
     np.savez_compressed(os.path.join(GOLD, "g_ban_enc.npz"), **out)
     print("wrote g_ban_enc.npz:", {k: v.shape for k, v in out.items() if k.endswith(("_y", "_vec"))})
 

@@ -10,7 +10,8 @@ from .metrics import IoUMeter, append_ious, get_i345_mi  # noqa: F401
 from .staging import FeatureArena  # noqa: F401
 from .ban_map import ProposalMap2D, train_engine_ProposalMap2D  # noqa: F401  (row N2: the BAN 2-D proposal-map stage)
 from .ban_encoders import QueryEncoder, VisualEncoder  # noqa: F401  (row N2: BAN's bi-LSTM encoders, reference models/BANlib/model.py:8-86)
+from .ban import BAN, infer_BAN, train_engine_BAN  # noqa: F401  (row N2: the assembled model and its engine, reference models/BAN.py)
 
 __all__ = ["SeqPAN", "train_engine_SeqPAN", "infer_SeqPAN", "BaseFast", "train_engine_BaseFast", "infer_BaseFast",
            "infer_basic", "infer_basic_device", "lossfun_loc", "lossfun_match", "IoUMeter", "append_ious", "get_i345_mi", "FeatureArena",
-           "ProposalMap2D", "train_engine_ProposalMap2D", "VisualEncoder", "QueryEncoder"]
+           "ProposalMap2D", "train_engine_ProposalMap2D", "VisualEncoder", "QueryEncoder", "BAN", "train_engine_BAN", "infer_BAN"]

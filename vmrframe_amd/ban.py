@@ -1,0 +1,152 @@
+"""BAN on the HIP library: the reference's `BAN`, `train_engine_BAN`, `infer_BAN`
+(models/BAN.py:14-134, 211-271, 303-316) assembled from the slices of this package:
+
+    ban_trunk.BANTrunk        encoders -> CQAttention -> cross encoder -> TemporalDifference          (BAN.py:75-84)
+    ban_map.ProposalMap2D     boundary / content aggregation -> map2d_proj -> predictor, contrast_encoder (:87-97)
+    ban_sampler (host)        Aaptive_Proposal_Sampling on sigmoid(tmap).detach()                      (:99-105)
+    ban_head.BANHead          prop_pe -> prop_interact -> predictor2 / predictor_offset, contrast_encoder_t (:98,107-118)
+
+`BAN(cfg, pre_train_emb)` takes the reference's config object (cfg.model.{vlen, topk, neighbor, negative, prop_num,
+sparse_sample, pooling_counts, fuse_dim, vdim, dim, lstm_layer, query_embed_dim, contrast_dim, droprate, gcn.*}) and exposes
+the reference's parameter names (the slices' sub-modules are re-registered at the top level; `fc_fuse`, which the reference
+constructs and never uses, is kept as a parameter holder), so a reference checkpoint loads with `load_state_dict`.
+`forward(data_visual, data_text, video_seq_len, text_seq_len, offset_gt)` returns the reference's output dict.
+
+`train_engine_BAN(model, data, configs, runtype="train")` takes main.py's 4-argument call (the reference's own engine has a
+3-argument signature, SURVEY.md section 2 row 12 -- the adapter is part of this row) and computes the five losses of
+models/BAN.py:213-258 on the device: the map BCE on the compact cells, the refinement BCE at the sampled proposals, the
+temporal-difference loss, the two smooth-L1 offset terms and the contrast loss (batched over the compact cells instead of a
+per-sample masked-select loop).  The one host round trip per step is the sampler's (ban_sampler.py).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .ban_head import BANHead
+from .ban_map import ProposalMap2D, infer_tmap
+from .ban_sampler import sample_proposals
+from .ban_trunk import BANTrunk
+
+
+class BAN(nn.Module):
+    def __init__(self, cfg, pre_train_emb=None, compute_dtype=torch.bfloat16, sync_timing=True):
+        super().__init__()
+        m = cfg.model
+        self.vlen, self.topk, self.neighbor, self.negative, self.prop_num = m.vlen, m.topk, m.neighbor, m.negative, m.prop_num
+        vocab_size = pre_train_emb.shape[0]
+        droprate = float(getattr(m, "droprate", 0.1))
+        trunk = BANTrunk(vocab_size, m.vdim, m.dim, m.lstm_layer, m.query_embed_dim, m.fuse_dim, m.vlen, pre_train_emb,
+                         droprate=droprate, compute_dtype=compute_dtype)
+        pmap = ProposalMap2D(m.fuse_dim, m.contrast_dim, m.vlen, list(m.pooling_counts), sparse_sample=bool(m.sparse_sample),
+                             compute_dtype=compute_dtype, droprate=0.1)
+        head = BANHead(m.fuse_dim, m.dim, m.contrast_dim, gcn_blocks=int(m.gcn.num_blocks), vlen=m.vlen, droprate=0.1,
+                       compute_dtype=compute_dtype)
+        assert int(m.gcn.hidden_size) == m.fuse_dim
+        # the slices keep working as objects; their sub-modules are registered HERE under the reference's names
+        for holder, names in ((trunk, ("visual_encoder", "query_encoder", "cross_encoder", "cqa_att", "boundary_aware")),
+                              (pmap, ("map2d_proj", "predictor", "contrast_encoder")),
+                              (head, ("prop_pe", "prop_interact", "predictor2", "predictor_offset", "contrast_encoder_t"))):
+            for n in names:
+                setattr(self, n, getattr(holder, n))
+        self.fc_fuse = nn.Linear(6 * m.dim, m.fuse_dim)              # (constructed and unused in the reference too)
+        object.__setattr__(self, "_trunk", trunk)
+        object.__setattr__(self, "_pmap", pmap)
+        object.__setattr__(self, "_head", head)
+        self.sampler_thresh = 0.7                                    # models/BAN.py:40
+        self.sync_timing = sync_timing
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        for h in (self._trunk, self._pmap, self._head):
+            h.train(mode)
+        return self
+
+    def forward(self, data_visual, data_text, video_seq_len, text_seq_len, offset_gt):
+        sync = self.sync_timing and not torch.cuda.is_current_stream_capturing()
+        if sync:
+            torch.cuda.synchronize()
+        start = time.time()
+        dev = data_visual.device
+        o = self._trunk(data_visual, data_text, video_seq_len, text_seq_len)
+        r = self._pmap(o["hidden_b"], o["fuse_feature"])
+        lay = self._pmap.layout
+        B, N, C = data_visual.shape[0], self.vlen, lay.C
+        # ---- sampling on the host (one [B, C] copy down, one [B, prop_num, 2] copy up): sigmoid(tmap) at the kept cells,
+        # in the reference's mask.nonzero() (row-major) cell order
+        rm = np.argsort(lay.ii.astype(np.int64) * N + lay.jj, kind="stable")
+        score = torch.sigmoid(r["tmap_cells"].detach().float()).cpu().numpy()[:, rm]
+        cells = np.stack([lay.ii[rm], lay.jj[rm]], axis=1)
+        pse = sample_proposals(score, cells, thresh=self.sampler_thresh, topk=self.topk, neighbor=self.neighbor,
+                               negative=self.negative)
+        assert pse.shape[1] == self.prop_num, f"sampler returned {pse.shape[1]} proposals, cfg.model.prop_num = {self.prop_num}"
+        pred_s_e = torch.from_numpy(pse).to(dev)                                     # [B, P, 2]: (start, end + 1)
+        s_idx, e_idx = pred_s_e[..., 0], pred_s_e[..., 1] - 1
+        cid = lay.cell_of[s_idx, e_idx].long()                                       # compact cell of every proposal
+        bidx = torch.arange(B, device=dev).unsqueeze(1).expand_as(cid)
+        prop_feature = r["map2d_cells"][bidx, cid]                                   # [B, P, F]
+        off_gt = offset_gt.to(dev)[bidx, s_idx, e_idx]                               # [B, P, 2]
+        h = self._head(prop_feature.reshape(B * self.prop_num, -1), pred_s_e.reshape(-1, 2), o["sentence_feature"], B)
+        if sync:
+            torch.cuda.synchronize()
+        return {"tmap": r["tmap"], "map2d_mask": r["map2d_mask"], "map2d_proj": r["map2d_proj"], "sen_proj": h["sen_proj"],
+                "coarse_pred": pred_s_e, "coarse_pred_round": pred_s_e, "final_pred": h["final_pred"], "offset": h["offset"],
+                "offset_gt": off_gt, "td": o["td"], "video_seq_len": video_seq_len, "consume_time": time.time() - start,
+                # compact tensors the losses use instead of masked selects over the dense maps
+                "tmap_cells": r["tmap_cells"], "map2d_proj_cells": r["map2d_proj_cells"]}
+
+
+def temporal_difference_loss(td, position_mask):
+    """reference models/BANlib/model.py:674-684"""
+    logp = torch.log_softmax(td.float(), dim=-1)
+    num = (position_mask * logp).sum(dim=-1)
+    return (-num / (position_mask.sum(dim=-1) + 1e-8)).mean()
+
+
+def contrast_loss(sen_proj, proj_cells, pos_cells, neg_cells, tao=1.0):
+    """ContrastLoss (reference models/BANlib/model.py:639-671) on the compact cells: for every clip with at least one positive
+    and one negative cell, -log(sum_pos exp(cos) / (sum_pos+neg exp(cos) + 1e-8)), averaged over those clips."""
+    q = sen_proj.float()
+    q = q / (torch.linalg.norm(q, dim=-1, keepdim=True) + 1e-8)
+    y = proj_cells.float()
+    y = y / torch.linalg.norm(y, dim=-1, keepdim=True).clamp(min=1e-30)
+    sim = torch.einsum("bd,bcd->bc", q, y) / (1.0 + 1e-8)
+    e = torch.exp(sim / tao)
+    pos, neg = pos_cells.float(), neg_cells.float()
+    num = (e * pos).sum(-1)
+    den = (e * (pos + neg)).sum(-1)
+    ok = (pos.sum(-1) > 0) & (neg.sum(-1) > 0)
+    per = -torch.log(num.clamp(min=1e-38) / (den + 1e-8))
+    return (per * ok.float()).sum() / ok.float().sum().clamp(min=1.0)
+
+
+def train_engine_BAN(model: BAN, data, configs, runtype="train"):
+    """The five losses of reference models/BAN.py:211-258; `data` as `collate_fn_BAN` builds it (:136-206)."""
+    data = {k: v.to(configs.device) for k, v in data.items()}
+    out = model(data["vfeats"], data["words_ids"], data["vlens"], data["tlens"], data["start_end_offset"])
+    lay = model._pmap.layout
+    ii, jj = lay.ii_t, lay.jj_t
+    L = configs.loss
+    ious = ((data["iou2ds"] - L.min_iou) / (L.max_iou - L.min_iou)).clamp(0, 1)
+    loss_bce = F.binary_cross_entropy_with_logits(out["tmap_cells"].float(), ious[:, ii, jj].float())
+    pse = out["coarse_pred_round"]
+    B = pse.shape[0]
+    bidx = torch.arange(B, device=pse.device).unsqueeze(1).expand(B, pse.shape[1])
+    ious_gt = ious[bidx, pse[..., 0], pse[..., 1] - 1]
+    loss_refine = F.binary_cross_entropy_with_logits(out["final_pred"].float().flatten(), ious_gt.float().flatten())
+    loss_td = temporal_difference_loss(out["td"], data["dist_idxs"].sum(dim=1))
+    op, og = out["offset"].reshape(-1, 2).float(), out["offset_gt"].reshape(-1, 2).float()
+    loss_offset = F.smooth_l1_loss(op[:, 0], og[:, 0]) + F.smooth_l1_loss(op[:, 1], og[:, 1])
+    mc = data["map2d_contrasts"].bool()
+    loss_contrast = contrast_loss(out["sen_proj"], out["map2d_proj_cells"], mc[:, 0][:, ii, jj], mc[:, 1][:, ii, jj])
+    loss = loss_bce * L.bce + loss_refine * L.refine + loss_td * L.td + loss_offset * L.offset + loss_contrast * L.contrast
+    return loss, out
+
+
+def infer_BAN(output, configs=None):
+    """reference models/BAN.py:303-316"""
+    return infer_tmap(output["tmap"], output["video_seq_len"])
