@@ -573,6 +573,16 @@ int vmr_lstm_step_bwd(const void* dy, const void* act, const void* cs, const int
  * multiple of 16 bytes, 16-byte aligned pointers. */
 int vmr_lstm_reverse_rows(const void* src, const int32_t* len, void* dst, int B, int T, int D, int dtype, void* stream);
 
+/* ------------------------------------------------ BAN proposal sampling (N2), HOST routine
+ * Replaces Aaptive_Proposal_Sampling / proposal_selection_with_negative (models/BANlib/model.py:371-435): per clip, the
+ * greedy pick-and-suppress loop over the kept cells of the score map in descending score order.  Sequential and tiny, so it
+ * runs on the host (8 threads over the clips) between the map stage and the proposal head.  All pointers are HOST memory:
+ * scores [B][C] = sigmoid(tmap) at the kept cells in mask.nonzero() (row-major) order, cells [C][2] = (i, j) of those cells;
+ * out [B][n_out][2] int64 receives (start, end + 1) in the reference's order [negatives | padding | selected by rank].
+ * Equal scores keep cell order.  Fails (-22) when a clip yields a count != n_out. */
+int vmr_ban_sample_host(const float* scores, const int32_t* cells, int B, int C, float thresh, int topk, int neighbor,
+                        int negative, int n_out, int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

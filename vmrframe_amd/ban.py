@@ -3,7 +3,7 @@
 
     ban_trunk.BANTrunk        encoders -> CQAttention -> cross encoder -> TemporalDifference          (BAN.py:75-84)
     ban_map.ProposalMap2D     boundary / content aggregation -> map2d_proj -> predictor, contrast_encoder (:87-97)
-    ban_sampler (host)        Aaptive_Proposal_Sampling on sigmoid(tmap).detach()                      (:99-105)
+    ban_sampler (host, C++)   Aaptive_Proposal_Sampling on sigmoid(tmap).detach(): vmr_ban_sample_host  (:99-105)
     ban_head.BANHead          prop_pe -> prop_interact -> predictor2 / predictor_offset, contrast_encoder_t (:98,107-118)
 
 `BAN(cfg, pre_train_emb)` takes the reference's config object (cfg.model.{vlen, topk, neighbor, negative, prop_num,
@@ -82,8 +82,7 @@ class BAN(nn.Module):
         score = torch.sigmoid(r["tmap_cells"].detach().float()).cpu().numpy()[:, rm]
         cells = np.stack([lay.ii[rm], lay.jj[rm]], axis=1)
         pse = sample_proposals(score, cells, thresh=self.sampler_thresh, topk=self.topk, neighbor=self.neighbor,
-                               negative=self.negative)
-        assert pse.shape[1] == self.prop_num, f"sampler returned {pse.shape[1]} proposals, cfg.model.prop_num = {self.prop_num}"
+                               negative=self.negative, n_out=self.prop_num)       # vmr_ban_sample_host (C++, host threads)
         pred_s_e = torch.from_numpy(pse).to(dev)                                     # [B, P, 2]: (start, end + 1)
         s_idx, e_idx = pred_s_e[..., 0], pred_s_e[..., 1] - 1
         cid = lay.cell_of[s_idx, e_idx].long()                                       # compact cell of every proposal

@@ -52,10 +52,63 @@ def select_with_negative(moments: np.ndarray, scores: np.ndarray, thresh=0.5, to
     return np.concatenate([neg, m[select]], axis=0)
 
 
-def sample_proposals(scores_cells: np.ndarray, cells_ij: np.ndarray, thresh=0.5, topk=5, neighbor=16, negative=16) -> np.ndarray:
-    """scores_cells float [B, C] = score_pred at the kept cells in `mask.nonzero()` (row-major) order, cells_ij int [C, 2]
-    -> pred_s_e int64 [B, n, 2] with the reference's (start, end + 1) convention (models/BANlib/model.py:413-433)."""
-    moments = cells_ij.astype(np.int64).copy()
-    moments[:, 1] += 1
-    return np.stack([select_with_negative(moments, scores_cells[b], thresh, topk, neighbor, negative)
-                     for b in range(scores_cells.shape[0])])
+def sample_proposals_numpy(scores_cells: np.ndarray, cells_ij: np.ndarray, thresh=0.5, topk=5, neighbor=16, negative=16) -> np.ndarray:
+    """(test oracle of the library routine) scores_cells float [B, C] = score_pred at the kept cells in `mask.nonzero()`
+    (row-major) order, cells_ij int [C, 2] -> pred_s_e int64 [B, n, 2] with the reference's (start, end + 1) convention
+    (models/BANlib/model.py:413-433).
+
+    All clips advance together: the loop is sequential in the picks (<= topk) but every step is a [B, C] vector operation
+    (64 clips x 5376 cells: 0.6 ms per clip one at a time -> a few ms for the batch).  Same result as
+    `select_with_negative` clip by clip (tests/test_gpu_ban_encoders.py)."""
+    B, C = scores_cells.shape
+    base = cells_ij.astype(np.int64).copy()
+    base[:, 1] += 1
+    order = np.argsort(-scores_cells.astype(np.float64), axis=1, kind="stable")          # [B, C]
+    m = base[order]                                                                     # [B, C, 2] by rank
+    start, end = m[..., 0].astype(np.float32), m[..., 1].astype(np.float32)
+    suppressed = np.zeros((B, C), dtype=bool)
+    select = np.zeros((B, C), dtype=bool)
+    rank = np.arange(C)[None, :]
+    rows = np.arange(B)
+    alive = np.ones(B, dtype=bool)                       # clips whose loop is still running
+    for _ in range(topk):
+        cand = ~suppressed & (rank < C - 1)              # the reference's loop never anchors on the last rank
+        has = cand.any(axis=1) & alive
+        if not has.any():
+            break
+        i = np.where(has, cand.argmax(axis=1), 0)        # first unsuppressed rank of every running clip
+        s, e = start[rows, i][:, None], end[rows, i][:, None]
+        inter = np.minimum(end, e) - np.maximum(start, s)
+        union = np.maximum(end, e) - np.minimum(start, s)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mask = (np.clip(inter, 0, None) / union > thresh) & (rank > i[:, None]) & has[:, None]
+        suppressed[rows[has], i[has]] = True
+        select[rows[has], i[has]] = True
+        select |= mask & (np.cumsum(mask, axis=1) <= neighbor)          # the first `neighbor` overlapping moments
+        suppressed |= mask
+        alive = has
+    total = topk * (neighbor + 1)
+    out = []
+    for b in range(B):
+        free = m[b][~suppressed[b]]
+        neg = free[::-1][:negative]
+        nsel = int(select[b].sum())
+        parts = [neg, free[: total - nsel], m[b][select[b]]] if nsel < total else [neg, m[b][select[b]]]
+        out.append(np.concatenate(parts, axis=0))
+    return np.stack(out)
+
+
+def sample_proposals(scores_cells: np.ndarray, cells_ij: np.ndarray, thresh=0.5, topk=5, neighbor=16, negative=16,
+                     n_out=None) -> np.ndarray:
+    """The product path: `vmr_ban_sample_host` of libvmr_hip.so (C++, 8 threads over the clips; ~1 ms for 64 clips x 5376
+    cells where the numpy forms above take 34-40 ms).  Same arguments and result as `sample_proposals_numpy`; n_out = the
+    expected proposals per clip (default topk * (neighbor + 1) + negative)."""
+    from . import _lib as L
+    sc = np.ascontiguousarray(scores_cells, dtype=np.float32)
+    ce = np.ascontiguousarray(cells_ij, dtype=np.int32)
+    B, C = sc.shape
+    n = int(topk * (neighbor + 1) + negative) if n_out is None else int(n_out)
+    out = np.empty((B, n, 2), dtype=np.int64)
+    L.check(L.lib().vmr_ban_sample_host(sc.ctypes.data, ce.ctypes.data, B, C, float(thresh), int(topk), int(neighbor),
+                                        int(negative), n, out.ctypes.data), "vmr_ban_sample_host")
+    return out
