@@ -555,20 +555,23 @@ int vmr_map2d_scatter(const void* cells, const int32_t* cell_of, const float* fi
  *   y   [B][T][2H]    dtype  output by TIME; rows past len[b] are not written (zero-fill once before step 0)
  * Backward, step s (descending): dy [B][T][2H]; dh [2][B][H] f32 = dg_{s+1} . W_hh (zeros at s = T-1); dc [2][B][H] f32
  * carried cell gradient (in/out, start at 0); dg [2][B][T][4H] dtype = gradient of the gate pre-activations of step s
- * (= gradient of gx; dW_hh = sum_s dg_s^T hp_s).  dtype VMR_F32 or VMR_BF16. */
+ * (= gradient of gx; dW_hh = sum_s dg_s^T hp_s).  dtype VMR_F32 or VMR_BF16.
+ * ndir = 2 x the number of INDEPENDENT LSTMs advanced by the call (same B, T, H and lengths, their own weights and inputs:
+ * TemporalDifference's two, models/BANlib/model.py:168-171): every leading [2] above becomes [ndir] (direction z belongs to LSTM
+ * z >> 1 and runs backward in time when z is odd) and y / dy become [ndir/2][B][T][2H]. */
 int vmr_lstm_cell_fwd(const void* gx, const void* gh, const int32_t* len, void* c, void* hs, void* act, void* cs, void* hp,
-                      void* y, int B, int T, int H, int s, int dtype, void* stream);
+                      void* y, int B, int T, int H, int s, int ndir, int dtype, void* stream);
 int vmr_lstm_cell_bwd(const void* dy, const void* act, const void* cs, const int32_t* len, const void* dh, void* dc, void* dg,
-                      int B, int T, int H, int s, int dtype, void* stream);
+                      int B, int T, int H, int s, int ndir, int dtype, void* stream);
 /* Fused step (bf16, H = 256 or 512: vmr_lstm_step_supported): the recurrent product and the pointwise half in ONE launch.
  * Forward: hprev / hnext are two distinct [2][B][H] buffers (h ping-pongs; hprev is not read at s = 0), whh [2][4H][H];
  * everything else as vmr_lstm_cell_fwd.  Backward: whht [2][H][4H] = W_hh transposed; reads dg[:, :, s+1, :] (written by
  * the call for step s+1; nothing at s = T-1), writes dg[:, :, s, :]; dc as vmr_lstm_cell_bwd. */
 int vmr_lstm_step_supported(int H, int dtype);
 int vmr_lstm_step_fwd(const void* gx, const void* hprev, const void* whh, const int32_t* len, void* c, void* hnext, void* act,
-                      void* cs, void* hp, void* y, int B, int T, int H, int s, int dtype, void* stream);
+                      void* cs, void* hp, void* y, int B, int T, int H, int s, int ndir, int dtype, void* stream);
 int vmr_lstm_step_bwd(const void* dy, const void* act, const void* cs, const int32_t* len, const void* whht, void* dc, void* dg,
-                      int B, int T, int H, int s, int dtype, void* stream);
+                      int B, int T, int H, int s, int ndir, int dtype, void* stream);
 /* dst[b][s][:] = s < len[b] ? src[b][len[b]-1-s][:] : 0 for [B][T][D] rows (its own inverse on the valid part).  D a
  * multiple of 16 bytes, 16-byte aligned pointers. */
 int vmr_lstm_reverse_rows(const void* src, const int32_t* len, void* dst, int B, int T, int D, int dtype, void* stream);

@@ -132,13 +132,13 @@ SIGNATURES = {
     "vmr_map2d_pool_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "vmr_map2d_scatter": [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     "vmr_sumsq": [_P, _P, _L, _P],
-    "vmr_lstm_cell_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "vmr_lstm_cell_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vmr_lstm_cell_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vmr_lstm_cell_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_lstm_reverse_rows": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vmr_lstm_step_supported": [_I, _I],
     "vmr_ban_sample_host": [_P, _P, _I, _I, _F, _I, _I, _I, _I, _P],
-    "vmr_lstm_step_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "vmr_lstm_step_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vmr_lstm_step_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vmr_lstm_step_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_add_pos_fwd": [_P, _P, _P, _L, _I, _I, _I, _P],
     "vmr_label_fuse_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "vmr_label_fuse_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],

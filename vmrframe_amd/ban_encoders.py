@@ -46,48 +46,50 @@ def _reverse_rows(x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
 
 
 class _BiLSTM(torch.autograd.Function):
-    """y [B, T, 2H] = bi-LSTM(x [B, T, I], lens int32 [B]); w_ih [2, 4H, I], w_hh [2, 4H, H], bias [2, 4H] (= b_ih + b_hh),
-    all in x's dtype (fp32 or bf16).  Gradients for x, w_ih, w_hh, bias."""
+    """y [K, B, T, 2H] = K independent bi-LSTMs advanced together (x [K, B, T, I], lens int32 [B] shared);
+    w_ih [2K, 4H, I], w_hh [2K, 4H, H], bias [2K, 4H] (= b_ih + b_hh; rows 2k / 2k + 1 = forward / reverse direction of LSTM k),
+    all in x's dtype (fp32 or bf16).  Gradients for x, w_ih, w_hh, bias.  K = 1 is the plain encoder; K = 2 is
+    TemporalDifference's pair (same shapes, own weights): one launch per step serves both."""
 
     @staticmethod
     def forward(ctx, x, lens, w_ih, w_hh, bias):
         L.require_gpu(x, lens, w_ih, w_hh, bias)
         assert lens.dtype == torch.int32 and x.is_contiguous() and w_ih.is_contiguous() and w_hh.is_contiguous()
-        B, T, I = x.shape
-        H = w_hh.shape[2]
+        K, B, T, I = x.shape
+        Z, H = 2 * K, w_hh.shape[2]
+        assert w_ih.shape[0] == Z and w_hh.shape[0] == Z
         dt, dc = x.dtype, L.dtype_code(x)
         lib, dev = L.lib(), x.device
-        xs = torch.stack((x, _reverse_rows(x, lens)))                     # [2, B, T, I] by step
-        gx = torch.empty(2, B, T, 4 * H, device=dev, dtype=dt)
+        xr = _reverse_rows(x.view(K * B, T, I), lens.repeat(K)).view(K, B, T, I)
+        xs = torch.stack((x, xr), dim=1).view(Z, B, T, I)                  # [Z, B, T, I] by step (z = 2k + direction)
+        gx = torch.empty(Z, B, T, 4 * H, device=dev, dtype=dt)
         bias32 = bias.float().contiguous()
-        for z in range(2):                                                # x-part of every step, biases in the epilogue
+        for z in range(Z):                                                # x-part of every step, biases in the epilogue
             ops.mm(xs[z].view(B * T, I), w_ih[z], 0, 0, out=gx[z].view(B * T, 4 * H), bias=bias32[z], flags=L.EPI_BIAS)
-        c = torch.zeros(2, B, H, device=dev)
-        act = torch.empty(2, B, T, 4 * H, device=dev, dtype=dt)
-        cs = torch.empty(2, B, T, H, device=dev)
-        hp = torch.empty(2, B, T, H, device=dev, dtype=dt)
-        y = torch.zeros(B, T, 2 * H, device=dev, dtype=dt)
+        c = torch.zeros(Z, B, H, device=dev)
+        act = torch.empty(Z, B, T, 4 * H, device=dev, dtype=dt)
+        cs = torch.empty(Z, B, T, H, device=dev)
+        hp = torch.empty(Z, B, T, H, device=dev, dtype=dt)
+        y = torch.zeros(K, B, T, 2 * H, device=dev, dtype=dt)
         ctx.fused = bool(FUSED_STEP and lib.vmr_lstm_step_supported(H, dc))
         if ctx.fused:            # product + gates + state in one launch per step; h ping-pongs between two buffers
-            hb = torch.zeros(2, 2, B, H, device=dev, dtype=dt)
+            hb = torch.zeros(2, Z, B, H, device=dev, dtype=dt)
             for s in range(T):
                 L.check(lib.vmr_lstm_step_fwd(gx.data_ptr(), hb[s & 1].data_ptr(), w_hh.data_ptr(), lens.data_ptr(),
                                               c.data_ptr(), hb[(s + 1) & 1].data_ptr(), act.data_ptr(), cs.data_ptr(),
-                                              hp.data_ptr(), y.data_ptr(), B, T, H, s, dc, L.stream_ptr()),
+                                              hp.data_ptr(), y.data_ptr(), B, T, H, s, Z, dc, L.stream_ptr()),
                         "vmr_lstm_step_fwd")
-            ctx.save_for_backward(xs, lens, w_ih, w_hh, act, cs, hp)
-            ctx.mark_non_differentiable(lens)
-            return y
-        hs = torch.zeros(2, B, H, device=dev, dtype=dt)
-        gh = torch.zeros(2, B, 4 * H, device=dev)
-        f32out = L.EPI_OUT_F32 if dc != L.F32 else 0
-        for s in range(T):
-            if s > 0:                                                     # gh[z] = hs[z] . w_hh[z]^T, both directions
-                ops.gemm(hs, w_hh, gh, B, 4 * H, H, 0, 0, H, H, 4 * H, dtype=dc, flags=f32out, Z1=2,
-                         sA=(B * H, 0), sB=(4 * H * H, 0), sC=(B * 4 * H, 0))
-            L.check(lib.vmr_lstm_cell_fwd(gx.data_ptr(), gh.data_ptr(), lens.data_ptr(), c.data_ptr(), hs.data_ptr(),
-                                          act.data_ptr(), cs.data_ptr(), hp.data_ptr(), y.data_ptr(), B, T, H, s, dc,
-                                          L.stream_ptr()), "vmr_lstm_cell_fwd")
+        else:
+            hs = torch.zeros(Z, B, H, device=dev, dtype=dt)
+            gh = torch.zeros(Z, B, 4 * H, device=dev)
+            f32out = L.EPI_OUT_F32 if dc != L.F32 else 0
+            for s in range(T):
+                if s > 0:                                                 # gh[z] = hs[z] . w_hh[z]^T, every direction
+                    ops.gemm(hs, w_hh, gh, B, 4 * H, H, 0, 0, H, H, 4 * H, dtype=dc, flags=f32out, Z1=Z,
+                             sA=(B * H, 0), sB=(4 * H * H, 0), sC=(B * 4 * H, 0))
+                L.check(lib.vmr_lstm_cell_fwd(gx.data_ptr(), gh.data_ptr(), lens.data_ptr(), c.data_ptr(), hs.data_ptr(),
+                                              act.data_ptr(), cs.data_ptr(), hp.data_ptr(), y.data_ptr(), B, T, H, s, Z, dc,
+                                              L.stream_ptr()), "vmr_lstm_cell_fwd")
         ctx.save_for_backward(xs, lens, w_ih, w_hh, act, cs, hp)
         ctx.mark_non_differentiable(lens)
         return y
@@ -95,44 +97,52 @@ class _BiLSTM(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xs, lens, w_ih, w_hh, act, cs, hp = ctx.saved_tensors
-        _, B, T, I = xs.shape
-        H = w_hh.shape[2]
+        Z, B, T, I = xs.shape
+        K, H = Z // 2, w_hh.shape[2]
         dt, dc = xs.dtype, L.dtype_code(xs)
         lib, dev = L.lib(), xs.device
         dy = dy.contiguous()
-        dg = torch.empty(2, B, T, 4 * H, device=dev, dtype=dt)
-        dh = torch.zeros(2, B, H, device=dev)
-        dcell = torch.zeros(2, B, H, device=dev)
-        f32out = L.EPI_OUT_F32 if dc != L.F32 else 0
+        dg = torch.empty(Z, B, T, 4 * H, device=dev, dtype=dt)
+        dcell = torch.zeros(Z, B, H, device=dev)
         if ctx.fused:
-            whht = w_hh.transpose(1, 2).contiguous()                      # [2, H, 4H]: the K-contiguous operand of dg . W_hh
+            whht = w_hh.transpose(1, 2).contiguous()                      # [Z, H, 4H]: the K-contiguous operand of dg . W_hh
             for s in range(T - 1, -1, -1):
                 L.check(lib.vmr_lstm_step_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), whht.data_ptr(),
-                                              dcell.data_ptr(), dg.data_ptr(), B, T, H, s, dc, L.stream_ptr()),
+                                              dcell.data_ptr(), dg.data_ptr(), B, T, H, s, Z, dc, L.stream_ptr()),
                         "vmr_lstm_step_bwd")
-        for s in (() if ctx.fused else range(T - 1, -1, -1)):
-            L.check(lib.vmr_lstm_cell_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), dh.data_ptr(),
-                                          dcell.data_ptr(), dg.data_ptr(), B, T, H, s, dc, L.stream_ptr()),
-                    "vmr_lstm_cell_bwd")
-            if s > 0:      # dh[z] = dg[z][:, s, :] . w_hh[z]   (A rows strided by T*4H; W_hh is the [K][N] operand)
-                ops.gemm(dg[:, :, s], w_hh, dh, B, H, 4 * H, 0, 1, T * 4 * H, H, H, dtype=dc, flags=f32out, Z1=2,
-                         sA=(B * T * 4 * H, 0), sB=(4 * H * H, 0), sC=(B * H, 0))
-        dg2 = dg.view(2, B * T, 4 * H)
-        dw_hh = torch.empty(2, 4 * H, H, device=dev)
-        dw_ih = torch.empty(2, 4 * H, I, device=dev)
-        dxs = torch.empty(2, B, T, I, device=dev, dtype=dt)
-        for z in range(2):   # one product per weight over all steps (K = B*T); dx of each direction's step sequence
+        else:
+            dh = torch.zeros(Z, B, H, device=dev)
+            f32out = L.EPI_OUT_F32 if dc != L.F32 else 0
+            for s in range(T - 1, -1, -1):
+                L.check(lib.vmr_lstm_cell_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), dh.data_ptr(),
+                                              dcell.data_ptr(), dg.data_ptr(), B, T, H, s, Z, dc, L.stream_ptr()),
+                        "vmr_lstm_cell_bwd")
+                if s > 0:  # dh[z] = dg[z][:, s, :] . w_hh[z]   (A rows strided by T*4H; W_hh is the [K][N] operand)
+                    ops.gemm(dg[:, :, s], w_hh, dh, B, H, 4 * H, 0, 1, T * 4 * H, H, H, dtype=dc, flags=f32out, Z1=Z,
+                             sA=(B * T * 4 * H, 0), sB=(4 * H * H, 0), sC=(B * H, 0))
+        dg2 = dg.view(Z, B * T, 4 * H)
+        dw_hh = torch.empty(Z, 4 * H, H, device=dev)
+        dw_ih = torch.empty(Z, 4 * H, I, device=dev)
+        dxs = torch.empty(Z, B, T, I, device=dev, dtype=dt)
+        for z in range(Z):   # one product per weight over all steps (K = B*T); dx of each direction's step sequence
             ops.mm(dg2[z], hp[z].view(B * T, H), 1, 1, out=dw_hh[z], out_f32=True)
             ops.mm(dg2[z], xs[z].view(B * T, I), 1, 1, out=dw_ih[z], out_f32=True)
             ops.mm(dg2[z], w_ih[z], 0, 1, out=dxs[z].view(B * T, I))
         dbias = dg2.float().sum(1)
-        dx = dxs[0] + _reverse_rows(dxs[1], lens)                        # (the reversal is its own inverse; zero past len)
+        dxs = dxs.view(K, 2, B, T, I)                                    # (the reversal is its own inverse; zero past len)
+        dx = dxs[:, 0] + _reverse_rows(dxs[:, 1].reshape(K * B, T, I), lens.repeat(K)).view(K, B, T, I)
         return dx, None, dw_ih.to(w_ih.dtype), dw_hh.to(w_hh.dtype), dbias.to(dt)
 
 
 def bilstm(x, lens, w_ih, w_hh, bias):
-    """lens is clamped to [0, T]: the kernels index time by it."""
-    return _BiLSTM.apply(x, lens.clamp(min=0, max=x.shape[1]), w_ih, w_hh, bias)
+    """One bi-LSTM: x [B, T, I] -> [B, T, 2H].  lens is clamped to [0, T]: the kernels index time by it."""
+    return _BiLSTM.apply(x.unsqueeze(0), lens.clamp(min=0, max=x.shape[1]), w_ih, w_hh, bias)[0]
+
+
+def bilstm_multi(x, lens, w_ih, w_hh, bias):
+    """K independent bi-LSTMs of the same shape advanced by the same launches: x [K, B, T, I] -> [K, B, T, 2H];
+    w_ih [2K, 4H, I], w_hh [2K, 4H, H], bias [2K, 4H] (LSTM k: rows 2k forward, 2k + 1 reverse)."""
+    return _BiLSTM.apply(x.contiguous(), lens.clamp(min=0, max=x.shape[2]), w_ih, w_hh, bias)
 
 
 class _EncoderBase(nn.Module):

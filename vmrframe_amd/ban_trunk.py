@@ -24,12 +24,17 @@ Still NOT built: proposal sampling (`Aaptive_Proposal_Sampling`, a per-sample NM
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
 from . import ops
 from .SeqPAN import cq_attention_core
-from .ban_encoders import QueryEncoder, VisualEncoder, bilstm
+from .ban_encoders import QueryEncoder, VisualEncoder, bilstm, bilstm_multi
+
+
+PAIRED = os.environ.get("VMR_LSTM_PAIR", "0") == "1"     # A/B: TemporalDifference's two LSTMs in the same launches
 
 
 class CQAttention(nn.Module):
@@ -64,22 +69,40 @@ class TemporalDifference(nn.Module):
         self.feature_proj_c = nn.Sequential(nn.Linear(2 * fuse_dim, fuse_dim), nn.ReLU(inplace=True), nn.Dropout(droprate))
         self.layer_num, self.compute_dtype = layer_num, compute_dtype
 
-    def _lstm(self, m: nn.LSTM, x, lens):
-        dt, h = self.compute_dtype, x
+    def _lstm_pair(self, x, lens):
+        """feature_transform_b and feature_transform_c (same input, same shapes, own weights).  PAIRED (VMR_LSTM_PAIR=1):
+        advanced by the SAME launches (bilstm_multi, K = 2) -- half the recurrence launches; measured SLOWER at the anet
+        sizes (trunk 21.3 vs 20.0 ms, whole step 42 vs 34 ms: at H = 512 a step kernel over four directions is 512-1024
+        workgroups and takes twice as long, and the stacked inputs / gradients add copies), so the default runs them one
+        after the other."""
+        dt, mods = self.compute_dtype, (self.feature_transform_b, self.feature_transform_c)
+        if not PAIRED:
+            outs = []
+            for m in mods:
+                h = x
+                for l in range(self.layer_num):
+                    w_ih = torch.stack((getattr(m, f"weight_ih_l{l}"), getattr(m, f"weight_ih_l{l}_reverse")))
+                    w_hh = torch.stack((getattr(m, f"weight_hh_l{l}"), getattr(m, f"weight_hh_l{l}_reverse")))
+                    bias = torch.stack((getattr(m, f"bias_ih_l{l}") + getattr(m, f"bias_hh_l{l}"),
+                                        getattr(m, f"bias_ih_l{l}_reverse") + getattr(m, f"bias_hh_l{l}_reverse")))
+                    h = bilstm(h.contiguous(), lens, w_ih.to(dt).contiguous(), w_hh.to(dt).contiguous(), bias.to(dt).contiguous())
+                outs.append(h)
+            return outs[0], outs[1]
+        h = torch.stack((x, x))                                            # [2, B, T, I]
         for l in range(self.layer_num):
-            w_ih = torch.stack((getattr(m, f"weight_ih_l{l}"), getattr(m, f"weight_ih_l{l}_reverse")))
-            w_hh = torch.stack((getattr(m, f"weight_hh_l{l}"), getattr(m, f"weight_hh_l{l}_reverse")))
-            bias = torch.stack((getattr(m, f"bias_ih_l{l}") + getattr(m, f"bias_hh_l{l}"),
-                                getattr(m, f"bias_ih_l{l}_reverse") + getattr(m, f"bias_hh_l{l}_reverse")))
-            h = bilstm(h.contiguous(), lens, w_ih.to(dt).contiguous(), w_hh.to(dt).contiguous(), bias.to(dt).contiguous())
-        return h
+            w_ih = torch.stack([getattr(m, f"weight_ih_l{l}{sfx}") for m in mods for sfx in ("", "_reverse")])
+            w_hh = torch.stack([getattr(m, f"weight_hh_l{l}{sfx}") for m in mods for sfx in ("", "_reverse")])
+            bias = torch.stack([getattr(m, f"bias_ih_l{l}{sfx}") + getattr(m, f"bias_hh_l{l}{sfx}")
+                                for m in mods for sfx in ("", "_reverse")])
+            h = bilstm_multi(h.contiguous(), lens, w_ih.to(dt).contiguous(), w_hh.to(dt).contiguous(), bias.to(dt).contiguous())
+        return h[0], h[1]
 
     def forward(self, visual_input, dc: ops.DropCtx, cache: ops.WeightCache):
         B, T, F2 = visual_input.shape
         x = visual_input.to(self.compute_dtype)
         full = torch.full((B,), T, device=x.device, dtype=torch.int32)      # (the reference runs these LSTMs unpacked)
-        hb = self._lstm(self.feature_transform_b, x, full).reshape(B * T, -1)
-        hc = self._lstm(self.feature_transform_c, x, full).reshape(B * T, -1)
+        hb, hc = self._lstm_pair(x, full)
+        hb, hc = hb.reshape(B * T, -1), hc.reshape(B * T, -1)
         pb, pc = self.feature_proj_b[0], self.feature_proj_c[0]
         hidden_b = ops.linear(hb, pb.weight, pb.bias, cache, relu=True, drop=dc.next("td.proj_b")).view(B, T, -1)
         hidden_c = ops.linear(hc, pc.weight, pc.bias, cache, relu=True, drop=dc.next("td.proj_c")).view(B, T, -1)

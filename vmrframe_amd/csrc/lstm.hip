@@ -31,9 +31,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const T* __restrict__ gx, const float* __restrict__ gh,
                                                             const int* __restrict__ len, float* __restrict__ c,
                                                             T* __restrict__ hs, T* __restrict__ act, float* __restrict__ cs,
-                                                            T* __restrict__ hp, T* __restrict__ y, int B, int Tn, int H, int s) {
+                                                            T* __restrict__ hp, T* __restrict__ y, int B, int Tn, int H, int s, int ND) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;        // (z, b, j)
-  if (idx >= (int64_t)2 * B * H) return;
+  if (idx >= (int64_t)ND * B * H) return;
   const int j = (int)(idx % H), b = (int)((idx / H) % B), z = (int)(idx / ((int64_t)H * B));
   const int64_t zb = (int64_t)z * B + b;
   const int L = len[b];
@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const T* __restrict_
   cs[(zb * Tn + s) * H + j] = cn;
   act[ga] = (T)ig; act[ga + H] = (T)fg; act[ga + 2 * H] = (T)gg; act[ga + 3 * H] = (T)og;
   hs[zb * H + j] = (T)hn;
-  const int t = z == 0 ? s : L - 1 - s;
-  y[((int64_t)b * Tn + t) * 2 * H + z * H + j] = (T)hn;
+  const int t = (z & 1) == 0 ? s : L - 1 - s;
+  y[(((int64_t)(z >> 1) * B + b) * Tn + t) * 2 * H + (z & 1) * H + j] = (T)hn;
 }
 
 // Backward of step s.  dh (f32 [2][B][H]) holds dgates_{s+1} . W_hh (the host's product; zeros at the last step), dc the
@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ cs, const int* __restrict__ len,
                                                             const float* __restrict__ dh,
                                                             float* __restrict__ dc, T* __restrict__ dg, int B, int Tn, int H,
-                                                            int s) {
+                                                            int s, int ND) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)2 * B * H) return;
+  if (idx >= (int64_t)ND * B * H) return;
   const int j = (int)(idx % H), b = (int)((idx / H) % B), z = (int)(idx / ((int64_t)H * B));
   const int64_t zb = (int64_t)z * B + b;
   const int L = len[b];
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const T* __restrict_
     dg[ga] = (T)0.f; dg[ga + H] = (T)0.f; dg[ga + 2 * H] = (T)0.f; dg[ga + 3 * H] = (T)0.f;
     return;
   }
-  const int t = z == 0 ? s : L - 1 - s;
-  const float dht = (float)dy[((int64_t)b * Tn + t) * 2 * H + z * H + j] + dh[zb * H + j];
+  const int t = (z & 1) == 0 ? s : L - 1 - s;
+  const float dht = (float)dy[(((int64_t)(z >> 1) * B + b) * Tn + t) * 2 * H + (z & 1) * H + j] + dh[zb * H + j];
   const float ig = (float)act[ga], fg = (float)act[ga + H], gg = (float)act[ga + 2 * H], og = (float)act[ga + 3 * H];
   const float cn = cs[(zb * Tn + s) * H + j];
   const float cp = s > 0 ? cs[(zb * Tn + s - 1) * H + j] : 0.f;
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const bf16_t* __rest
   cs[(zb * Tn + s) * H + j] = cn;
   act[ga] = (bf16_t)ig; act[ga + H] = (bf16_t)fg; act[ga + 2 * H] = (bf16_t)gg; act[ga + 3 * H] = (bf16_t)og;
   hnext[zb * H + j] = (bf16_t)hn;
-  const int t = z == 0 ? s : L - 1 - s;
-  y[((int64_t)b * Tn + t) * 2 * H + z * H + j] = (bf16_t)hn;
+  const int t = (z & 1) == 0 ? s : L - 1 - s;
+  y[(((int64_t)(z >> 1) * B + b) * Tn + t) * 2 * H + (z & 1) * H + j] = (bf16_t)hn;
 }
 
 template <int HH>
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const bf16_t* __rest
   const float cn = cs[(zb * Tn + s) * H + j];
   const float cpv = cs[(zb * Tn + max(s - 1, 0)) * H + j];
   const float dcv = dc[zb * H + j];
-  const int t = min(max(z == 0 ? s : L - 1 - s, 0), Tn - 1);
-  const float dyv = (float)dy[((int64_t)bc * Tn + t) * 2 * H + z * H + j];
+  const int t = min(max((z & 1) == 0 ? s : L - 1 - s, 0), Tn - 1);
+  const float dyv = (float)dy[(((int64_t)(z >> 1) * B + bc) * Tn + t) * 2 * H + (z & 1) * H + j];
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (s + 1 < Tn) {                                  // dh = dg_{s+1} . W_hh (nothing flows into the last step); wave w: gate w's K range
     bf16x8 a[KS], bw[KS];
@@ -244,33 +244,35 @@ __global__ __launch_bounds__(256) void lstm_reverse_rows_kernel(const T* __restr
 }  // namespace
 
 extern "C" int vmr_lstm_cell_fwd(const void* gx, const void* gh, const int* len, void* c, void* hs, void* act, void* cs,
-                                 void* hp, void* y, int B, int T, int H, int s, int dtype, void* stream) {
+                                 void* hp, void* y, int B, int T, int H, int s, int ndir, int dtype, void* stream) {
+  VMR_CHECK(ndir >= 2 && ndir % 2 == 0, "vmr_lstm: ndir must be 2 x the number of independent LSTMs");
   VMR_CHECK(gx && gh && len && c && hs && act && cs && hp && y, "vmr_lstm_cell_fwd: null pointer");
   VMR_CHECK(B > 0 && T > 0 && H > 0 && s >= 0 && s < T, "vmr_lstm_cell_fwd: bad shape B=%d T=%d H=%d s=%d", B, T, H, s);
   VMR_CHECK(dtype == VMR_BF16 || dtype == VMR_F32, "vmr_lstm_cell_fwd: bad dtype %d", dtype);
-  const int nblk = (int)(((int64_t)2 * B * H + 255) / 256);
+  const int nblk = (int)(((int64_t)ndir * B * H + 255) / 256);
   if (dtype == VMR_BF16)
     hipLaunchKernelGGL(lstm_cell_fwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gx,
-                       (const float*)gh, len, (float*)c, (bf16_t*)hs, (bf16_t*)act, (float*)cs, (bf16_t*)hp, (bf16_t*)y, B, T, H, s);
+                       (const float*)gh, len, (float*)c, (bf16_t*)hs, (bf16_t*)act, (float*)cs, (bf16_t*)hp, (bf16_t*)y, B, T, H, s, ndir);
   else
     hipLaunchKernelGGL(lstm_cell_fwd_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)gx,
-                       (const float*)gh, len, (float*)c, (float*)hs, (float*)act, (float*)cs, (float*)hp, (float*)y, B, T, H, s);
+                       (const float*)gh, len, (float*)c, (float*)hs, (float*)act, (float*)cs, (float*)hp, (float*)y, B, T, H, s, ndir);
   VMR_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vmr_lstm_cell_bwd(const void* dy, const void* act, const void* cs, const int* len, const void* dh,
-                                 void* dc, void* dg, int B, int T, int H, int s, int dtype, void* stream) {
+                                 void* dc, void* dg, int B, int T, int H, int s, int ndir, int dtype, void* stream) {
+  VMR_CHECK(ndir >= 2 && ndir % 2 == 0, "vmr_lstm: ndir must be 2 x the number of independent LSTMs");
   VMR_CHECK(dy && act && cs && len && dh && dc && dg, "vmr_lstm_cell_bwd: null pointer");
   VMR_CHECK(B > 0 && T > 0 && H > 0 && s >= 0 && s < T, "vmr_lstm_cell_bwd: bad shape B=%d T=%d H=%d s=%d", B, T, H, s);
   VMR_CHECK(dtype == VMR_BF16 || dtype == VMR_F32, "vmr_lstm_cell_bwd: bad dtype %d", dtype);
-  const int nblk = (int)(((int64_t)2 * B * H + 255) / 256);
+  const int nblk = (int)(((int64_t)ndir * B * H + 255) / 256);
   if (dtype == VMR_BF16)
     hipLaunchKernelGGL(lstm_cell_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                       (const bf16_t*)act, (const float*)cs, len, (const float*)dh, (float*)dc, (bf16_t*)dg, B, T, H, s);
+                       (const bf16_t*)act, (const float*)cs, len, (const float*)dh, (float*)dc, (bf16_t*)dg, B, T, H, s, ndir);
   else
     hipLaunchKernelGGL(lstm_cell_bwd_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
-                       (const float*)act, (const float*)cs, len, (const float*)dh, (float*)dc, (float*)dg, B, T, H, s);
+                       (const float*)act, (const float*)cs, len, (const float*)dh, (float*)dc, (float*)dg, B, T, H, s, ndir);
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -278,13 +280,14 @@ extern "C" int vmr_lstm_cell_bwd(const void* dy, const void* act, const void* cs
 extern "C" int vmr_lstm_step_supported(int H, int dtype) { return dtype == VMR_BF16 && (H == 256 || H == 512); }
 
 extern "C" int vmr_lstm_step_fwd(const void* gx, const void* hprev, const void* whh, const int* len, void* c, void* hnext,
-                                 void* act, void* cs, void* hp, void* y, int B, int T, int H, int s, int dtype, void* stream) {
+                                 void* act, void* cs, void* hp, void* y, int B, int T, int H, int s, int ndir, int dtype, void* stream) {
+  VMR_CHECK(ndir >= 2 && ndir % 2 == 0, "vmr_lstm: ndir must be 2 x the number of independent LSTMs");
   VMR_CHECK(gx && hprev && whh && len && c && hnext && act && cs && hp && y, "vmr_lstm_step_fwd: null pointer");
   VMR_CHECK(hprev != hnext, "vmr_lstm_step_fwd: h must ping-pong between two buffers");
   VMR_CHECK(vmr_lstm_step_supported(H, dtype), "vmr_lstm_step_fwd: unsupported H=%d dtype=%d", H, dtype);
   VMR_CHECK(B > 0 && T > 0 && s >= 0 && s < T, "vmr_lstm_step_fwd: bad shape B=%d T=%d s=%d", B, T, s);
   VMR_CHECK((((uintptr_t)hprev | (uintptr_t)whh) & 15) == 0, "vmr_lstm_step_fwd: 16-byte alignment");
-  const dim3 grid(H / 4, 2, (B + 63) / 64);
+  const dim3 grid(H / 4, ndir, (B + 63) / 64);
 #define VMR_LSTM_FWD(HH)                                                                                                      \
   hipLaunchKernelGGL(lstm_step_fwd_kernel<HH>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gx, (const bf16_t*)hprev, \
                      (const bf16_t*)whh, len, (float*)c, (bf16_t*)hnext, (bf16_t*)act, (float*)cs, (bf16_t*)hp, (bf16_t*)y, B, T, s)
@@ -295,12 +298,13 @@ extern "C" int vmr_lstm_step_fwd(const void* gx, const void* hprev, const void* 
 }
 
 extern "C" int vmr_lstm_step_bwd(const void* dy, const void* act, const void* cs, const int* len, const void* whht, void* dc,
-                                 void* dg, int B, int T, int H, int s, int dtype, void* stream) {
+                                 void* dg, int B, int T, int H, int s, int ndir, int dtype, void* stream) {
+  VMR_CHECK(ndir >= 2 && ndir % 2 == 0, "vmr_lstm: ndir must be 2 x the number of independent LSTMs");
   VMR_CHECK(dy && act && cs && len && whht && dc && dg, "vmr_lstm_step_bwd: null pointer");
   VMR_CHECK(vmr_lstm_step_supported(H, dtype), "vmr_lstm_step_bwd: unsupported H=%d dtype=%d", H, dtype);
   VMR_CHECK(B > 0 && T > 0 && s >= 0 && s < T, "vmr_lstm_step_bwd: bad shape B=%d T=%d s=%d", B, T, s);
   VMR_CHECK((((uintptr_t)dg | (uintptr_t)whht) & 15) == 0, "vmr_lstm_step_bwd: 16-byte alignment");
-  const dim3 grid(H / 16, 2, (B + 15) / 16);
+  const dim3 grid(H / 16, ndir, (B + 15) / 16);
   if (H == 256)
     hipLaunchKernelGGL(lstm_step_bwd_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)act,
                        (const float*)cs, len, (const bf16_t*)whht, (float*)dc, (bf16_t*)dg, B, T, s);
