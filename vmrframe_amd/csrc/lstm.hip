@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const bf16_t* __rest
                                                             bf16_t* __restrict__ hp, bf16_t* __restrict__ y, int B, int Tn, int s) {
   constexpr int H = HH, KS = HH / 32;
   __shared__ float tile[64][17];                     // [batch row of the workgroup][gate * 4 + unit]
+  __shared__ bf16x8 wfrag[KS][64];                   // the tile's weight fragments, shared by the four waves (8-16 KiB)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int z = blockIdx.y, u0 = blockIdx.x * 4, b0 = blockIdx.z * 64;
   const int r16 = lane & 15, kq = lane >> 4;
@@ -140,13 +141,17 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const bf16_t* __rest
   const float cprev = c[zb * H + j];
   const bf16_t hpv = hprev[zb * H + j];              // (both ping-pong buffers start zeroed: valid at s = 0 too)
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (s > 0) {                                       // (h_{-1} = 0: step 0 has no recurrent part)
-    bf16x8 a[KS], bw[KS];
+  if (s > 0) {                                       // (h_{-1} = 0: step 0 has no recurrent part; s is uniform: no divergent barrier)
+    // the four waves multiply their own 16 batch rows by the SAME 16 weight rows: each wave fetches a quarter of the
+    // weight fragments into LDS (KS/4 loads instead of KS: a wave's loads are what a step costs), all read all of them
+    bf16x8 a[KS];
     ld_frags<KS>(hprev + ((int64_t)z * B + min(b0 + w * 16 + r16, B - 1)) * H + kq * 8, a);
-    ld_frags<KS>(whh + ((int64_t)z * 4 * H + (r16 >> 2) * H + u0 + (r16 & 3)) * H + kq * 8, bw);
-    __builtin_amdgcn_sched_barrier(0);               // every fragment load in flight before the first MFMA
+    const bf16_t* wp = whh + ((int64_t)z * 4 * H + (r16 >> 2) * H + u0 + (r16 & 3)) * H + kq * 8;
 #pragma unroll
-    for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], bw[k], acc, 0, 0, 0);
+    for (int k = 0; k < KS / 4; ++k) wfrag[w * (KS / 4) + k][lane] = *reinterpret_cast<const bf16x8*>(wp + (w * (KS / 4) + k) * 32);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], wfrag[k][lane], acc, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[w * 16 + kq * 4 + r][r16] = acc[r];   // D[batch kq*4 + r][n = gate * 4 + unit]
