@@ -33,6 +33,70 @@ TRAIN_GFLOP_PER_CLIP = 58.0      # 19.34 GFLOP fwd (FlopCounter 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
+def run_ban(args, dev, rank, world):
+    """BASELINE.json configs[4] as a whole: the BAN train step (reference models/BAN.py: forward incl. the host-side proposal
+    sampler, the five losses of train_engine_BAN, backward, AdamW) at config/anet/BAN.yaml's model sizes with T = 128 -> a
+    128 x 128 score map (5376 kept cells, 80 proposals per clip), B = 64 clips per GPU, bf16.  Eager: the sampler's
+    device-to-host copy splits the step, and the optimizer is torch.optim.AdamW (the flat fused one is SeqPAN's).  N > 1 =
+    independent replicas (no gradient exchange is wired for this row yet): "replicas only"."""
+    from types import SimpleNamespace as NS
+    import vmrframe_amd as V
+    torch.manual_seed(1234 + rank)
+    B, T, Vw, E, Lq = CFG5["B"], CFG5["N"], 4000, 300, 20
+    cfg = NS(device=dev,
+             model=NS(vlen=T, topk=20, neighbor=3, negative=0, prop_num=80, sparse_sample=True, pooling_counts=CFG5["pooling"],
+                      fuse_dim=CFG5["F"], vdim=1024, dim=CFG5["F"] // 2, lstm_layer=2, query_embed_dim=E, contrast_dim=CFG5["Cd"],
+                      droprate=0.1, gcn=NS(num_blocks=2, k=80, hidden_size=CFG5["F"])),
+             loss=NS(min_iou=CFG5["min_iou"], max_iou=CFG5["max_iou"], bce=2.0, refine=1.0, td=0.1, offset=1.0, contrast=0.1))
+    rng = np.random.default_rng(1234)
+    model = V.BAN(cfg, pre_train_emb=rng.standard_normal((Vw, E)).astype(np.float32),
+                  compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, sync_timing=False).to(dev).train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01)
+    gen = torch.Generator().manual_seed(1234 + rank)
+    vl = torch.randint(T // 2, T + 1, (B,), generator=gen); vl[0] = T
+    ql = torch.randint(5, Lq + 1, (B,), generator=gen); ql[0] = Lq
+    data = {"vfeats": torch.randn(B, T, 1024, generator=gen), "words_ids": torch.randint(1, Vw + 2, (B, Lq), generator=gen),
+            "vlens": vl, "tlens": ql, "start_end_offset": torch.randn(B, T, T, 2, generator=gen),
+            "iou2ds": torch.rand(B, T, T, generator=gen), "dist_idxs": torch.rand(B, 2, T, generator=gen),
+            "map2d_contrasts": torch.rand(B, 2, T, T, generator=gen) > 0.5}
+    data = {k: v.to(dev) for k, v in data.items()}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = V.train_engine_BAN(model, data, cfg, "train")
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(max(3, args.warmup)):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        print(json.dumps({"metric": "clips/sec (train step), BAN at T=128 (128x128 score map), anet model sizes",
+                          "value": round(B * world / (ms * 1e-3), 2), "unit": "clips/sec", "n_gpus": world, "steps": args.steps,
+                          "warmup": max(3, args.warmup), "ms_per_step": round(ms, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                          "config": {"workload": "BAN (configs[4], next-row N2): B=64 clips/GPU, T=128, 20-word queries, vdim 1024, dim 256, "
+                                                 "2 LSTM layers, fuse_dim 512, 5376 map cells, 80 proposals; forward (host sampler "
+                                                 "included) + five losses + backward + torch AdamW, eager; replicas only for N > 1",
+                                     "global_batch": B * world, "parallelism": f"dp{world}"},
+                          "final_loss": round(float(loss.detach()), 4), "hipgraph": False, "roofline": None, "cpu_baseline": None}))
+    return 0
+
+
 def make_cfg(a, dtype):
     from vmrframe_amd import synth as S    # config object + synthetic batch recipe (no oracle on the product path)
     cfg = S.make_cfg(dim=a["D"], vlen=a["T"], vdim=a["V"], num_words=a["num_words"], num_chars=a["num_chars"],
@@ -206,9 +270,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of whole-step hipGraph replay")
-    ap.add_argument("--workload", default="seqpan", choices=["seqpan", "basefast", "banmap"],
+    ap.add_argument("--workload", default="seqpan", choices=["seqpan", "basefast", "banmap", "ban"],
                     help="seqpan = BASELINE configs[1] (headline); basefast = configs[3] (T=256); banmap = the BAN "
-                         "proposal-map stage of configs[4]")
+                         "proposal-map stage of configs[4]; ban = the whole BAN train step of configs[4] (eager)")
     ap.add_argument("--selftest-launcher", action="store_true", help="rendezvous + one gloo all-reduce per rank, no GPU")
     ap.add_argument("--reduce-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="wire dtype of the gradient all-reduce (N > 1); fp32 = exact sum")
@@ -235,6 +299,8 @@ def main():
     if world > 1:
         dp.init_process_group_from_env(os.environ.get("VMR_DIST_BACKEND", "nccl"))
 
+    if args.workload == "ban":
+        return run_ban(args, dev, rank, world)
     if args.workload == "banmap":
         from vmrframe_amd.synth import Cfg
         a = CFG5
