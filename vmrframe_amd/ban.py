@@ -72,7 +72,8 @@ class BAN(nn.Module):
             torch.cuda.synchronize()
         start = time.time()
         dev = data_visual.device
-        o = self._trunk(data_visual, data_text, video_seq_len, text_seq_len)
+        # (hidden_c: computed and never read by the reference's forward -- skipped here)
+        o = self._trunk(data_visual, data_text, video_seq_len, text_seq_len, need_hidden_c=False)
         r = self._pmap(o["hidden_b"], o["fuse_feature"])
         lay = self._pmap.layout
         B, N, C = data_visual.shape[0], self.vlen, lay.C

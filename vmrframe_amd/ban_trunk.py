@@ -69,16 +69,16 @@ class TemporalDifference(nn.Module):
         self.feature_proj_c = nn.Sequential(nn.Linear(2 * fuse_dim, fuse_dim), nn.ReLU(inplace=True), nn.Dropout(droprate))
         self.layer_num, self.compute_dtype = layer_num, compute_dtype
 
-    def _lstm_pair(self, x, lens):
+    def _lstm_pair(self, x, lens, need_c=True):
         """feature_transform_b and feature_transform_c (same input, same shapes, own weights).  PAIRED (VMR_LSTM_PAIR=1):
         advanced by the SAME launches (bilstm_multi, K = 2) -- half the recurrence launches; measured SLOWER at the anet
         sizes (trunk 21.3 vs 20.0 ms, whole step 42 vs 34 ms: at H = 512 a step kernel over four directions is 512-1024
         workgroups and takes twice as long, and the stacked inputs / gradients add copies), so the default runs them one
         after the other."""
         dt, mods = self.compute_dtype, (self.feature_transform_b, self.feature_transform_c)
-        if not PAIRED:
+        if not PAIRED or not need_c:
             outs = []
-            for m in mods:
+            for m in (mods if need_c else mods[:1]):
                 h = x
                 for l in range(self.layer_num):
                     w_ih = torch.stack((getattr(m, f"weight_ih_l{l}"), getattr(m, f"weight_ih_l{l}_reverse")))
@@ -87,7 +87,7 @@ class TemporalDifference(nn.Module):
                                         getattr(m, f"bias_ih_l{l}_reverse") + getattr(m, f"bias_hh_l{l}_reverse")))
                     h = bilstm(h.contiguous(), lens, w_ih.to(dt).contiguous(), w_hh.to(dt).contiguous(), bias.to(dt).contiguous())
                 outs.append(h)
-            return outs[0], outs[1]
+            return outs[0], (outs[1] if need_c else None)
         h = torch.stack((x, x))                                            # [2, B, T, I]
         for l in range(self.layer_num):
             w_ih = torch.stack([getattr(m, f"weight_ih_l{l}{sfx}") for m in mods for sfx in ("", "_reverse")])
@@ -97,15 +97,19 @@ class TemporalDifference(nn.Module):
             h = bilstm_multi(h.contiguous(), lens, w_ih.to(dt).contiguous(), w_hh.to(dt).contiguous(), bias.to(dt).contiguous())
         return h[0], h[1]
 
-    def forward(self, visual_input, dc: ops.DropCtx, cache: ops.WeightCache):
+    def forward(self, visual_input, dc: ops.DropCtx, cache: ops.WeightCache, need_c: bool = True):
+        """need_c=False skips the `hidden_c` branch (feature_transform_c + feature_proj_c): BAN.forward computes it and never
+        reads it (models/BAN.py:85-86 -- only hidden_b reaches the map); its parameters then get no gradient instead of the
+        reference's zeros."""
         B, T, F2 = visual_input.shape
         x = visual_input.to(self.compute_dtype)
         full = torch.full((B,), T, device=x.device, dtype=torch.int32)      # (the reference runs these LSTMs unpacked)
-        hb, hc = self._lstm_pair(x, full)
-        hb, hc = hb.reshape(B * T, -1), hc.reshape(B * T, -1)
+        hb, hc = self._lstm_pair(x, full, need_c)
         pb, pc = self.feature_proj_b[0], self.feature_proj_c[0]
-        hidden_b = ops.linear(hb, pb.weight, pb.bias, cache, relu=True, drop=dc.next("td.proj_b")).view(B, T, -1)
-        hidden_c = ops.linear(hc, pc.weight, pc.bias, cache, relu=True, drop=dc.next("td.proj_c")).view(B, T, -1)
+        hidden_b = ops.linear(hb.reshape(B * T, -1), pb.weight, pb.bias, cache, relu=True, drop=dc.next("td.proj_b")).view(B, T, -1)
+        hidden_c = None
+        if need_c:
+            hidden_c = ops.linear(hc.reshape(B * T, -1), pc.weight, pc.bias, cache, relu=True, drop=dc.next("td.proj_c")).view(B, T, -1)
         # temporaldifference (:146-157): squared differences to both neighbours, the sequence ends repeating themselves
         f = hidden_b.float()
         nxt = torch.cat((f[:, 1:], f[:, -1:]), dim=1)
@@ -134,7 +138,7 @@ class BANTrunk(nn.Module):
         self.drop_step = None
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
 
-    def forward(self, data_visual, data_text, video_seq_len, text_seq_len, max_qlen=None):
+    def forward(self, data_visual, data_text, video_seq_len, text_seq_len, max_qlen=None, need_hidden_c=True):
         if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
             self._calls += 1        # (a captured step replays one seed set; the device step counter varies the masks)
         self._cache.state.reset()
@@ -146,6 +150,6 @@ class BANTrunk(nn.Module):
         mask_word = torch.arange(Lq, device=word_feature.device).unsqueeze(0) < text_seq_len.to(word_feature.device).view(-1, 1)
         cat_feature = self.cqa_att(clip_feature, word_feature, mask_word, cqdc)
         _, fuse_feature = self.cross_encoder(cat_feature, video_seq_len, self.vlen)
-        hidden_b, hidden_c, td = self.boundary_aware(fuse_feature, dc, self._cache)
+        hidden_b, hidden_c, td = self.boundary_aware(fuse_feature, dc, self._cache, need_hidden_c)
         return {"video_feature": video_feature, "sentence_feature": sentence_feature, "fuse_feature": fuse_feature,
                 "hidden_b": hidden_b, "hidden_c": hidden_c, "td": td}
