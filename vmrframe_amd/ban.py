@@ -66,38 +66,57 @@ class BAN(nn.Module):
             h.train(mode)
         return self
 
-    def forward(self, data_visual, data_text, video_seq_len, text_seq_len, offset_gt):
-        sync = self.sync_timing and not torch.cuda.is_current_stream_capturing()
-        if sync:
-            torch.cuda.synchronize()
-        start = time.time()
-        dev = data_visual.device
+    # The forward in three parts, so that a training step can be captured as TWO hipGraphs around the sampler's host round
+    # trip (vmrframe_amd/ban_trainer.py); `forward` below is their composition.
+    def forward_map(self, data_visual, data_text, video_seq_len, text_seq_len, max_qlen=None):
+        """encoders -> CQ attention -> cross encoder -> TemporalDifference -> 2-D map, predictor, contrast encoder (BAN.py:75-97)"""
         # (hidden_c: computed and never read by the reference's forward -- skipped here)
-        o = self._trunk(data_visual, data_text, video_seq_len, text_seq_len, need_hidden_c=False)
+        o = self._trunk(data_visual, data_text, video_seq_len, text_seq_len, max_qlen=max_qlen, need_hidden_c=False)
         r = self._pmap(o["hidden_b"], o["fuse_feature"])
-        lay = self._pmap.layout
-        B, N, C = data_visual.shape[0], self.vlen, lay.C
-        # ---- sampling on the host (one [B, C] copy down, one [B, prop_num, 2] copy up): sigmoid(tmap) at the kept cells,
-        # in the reference's mask.nonzero() (row-major) cell order
+        return o, r
+
+    def sample(self, tmap_cells):
+        """Aaptive_Proposal_Sampling on sigmoid(tmap).detach() (BAN.py:99-105), on the HOST: one [B, C] copy down, the
+        library's vmr_ban_sample_host, the [B, prop_num, 2] (start, end + 1) result as a host int64 tensor."""
+        lay, N = self._pmap.layout, self.vlen
+        # the reference's mask.nonzero() (row-major) cell order
         rm = np.argsort(lay.ii.astype(np.int64) * N + lay.jj, kind="stable")
-        score = torch.sigmoid(r["tmap_cells"].detach().float()).cpu().numpy()[:, rm]
+        score = torch.sigmoid(tmap_cells.detach().float()).cpu().numpy()[:, rm]
         cells = np.stack([lay.ii[rm], lay.jj[rm]], axis=1)
         pse = sample_proposals(score, cells, thresh=self.sampler_thresh, topk=self.topk, neighbor=self.neighbor,
                                negative=self.negative, n_out=self.prop_num)       # vmr_ban_sample_host (C++, host threads)
-        pred_s_e = torch.from_numpy(pse).to(dev)                                     # [B, P, 2]: (start, end + 1)
+        return torch.from_numpy(pse)
+
+    def forward_head(self, o, r, pred_s_e, offset_gt, video_seq_len):
+        """gathers at the sampled cells, prop_pe -> prop_interact -> predictor2 / predictor_offset, contrast_encoder_t
+        (BAN.py:98,107-118); pred_s_e: DEVICE int64 [B, prop_num, 2]"""
+        lay = self._pmap.layout
+        B = pred_s_e.shape[0]
+        dev = pred_s_e.device
         s_idx, e_idx = pred_s_e[..., 0], pred_s_e[..., 1] - 1
         cid = lay.cell_of[s_idx, e_idx].long()                                       # compact cell of every proposal
         bidx = torch.arange(B, device=dev).unsqueeze(1).expand_as(cid)
         prop_feature = r["map2d_cells"][bidx, cid]                                   # [B, P, F]
         off_gt = offset_gt.to(dev)[bidx, s_idx, e_idx]                               # [B, P, 2]
         h = self._head(prop_feature.reshape(B * self.prop_num, -1), pred_s_e.reshape(-1, 2), o["sentence_feature"], B)
-        if sync:
-            torch.cuda.synchronize()
         return {"tmap": r["tmap"], "map2d_mask": r["map2d_mask"], "map2d_proj": r["map2d_proj"], "sen_proj": h["sen_proj"],
                 "coarse_pred": pred_s_e, "coarse_pred_round": pred_s_e, "final_pred": h["final_pred"], "offset": h["offset"],
-                "offset_gt": off_gt, "td": o["td"], "video_seq_len": video_seq_len, "consume_time": time.time() - start,
+                "offset_gt": off_gt, "td": o["td"], "video_seq_len": video_seq_len,
                 # compact tensors the losses use instead of masked selects over the dense maps
                 "tmap_cells": r["tmap_cells"], "map2d_proj_cells": r["map2d_proj_cells"]}
+
+    def forward(self, data_visual, data_text, video_seq_len, text_seq_len, offset_gt):
+        sync = self.sync_timing and not torch.cuda.is_current_stream_capturing()
+        if sync:
+            torch.cuda.synchronize()
+        start = time.time()
+        o, r = self.forward_map(data_visual, data_text, video_seq_len, text_seq_len)
+        pred_s_e = self.sample(r["tmap_cells"]).to(data_visual.device)
+        out = self.forward_head(o, r, pred_s_e, offset_gt, video_seq_len)
+        if sync:
+            torch.cuda.synchronize()
+        out["consume_time"] = time.time() - start
+        return out
 
 
 def temporal_difference_loss(td, position_mask):
@@ -128,6 +147,11 @@ def train_engine_BAN(model: BAN, data, configs, runtype="train"):
     """The five losses of reference models/BAN.py:211-258; `data` as `collate_fn_BAN` builds it (:136-206)."""
     data = {k: v.to(configs.device) for k, v in data.items()}
     out = model(data["vfeats"], data["words_ids"], data["vlens"], data["tlens"], data["start_end_offset"])
+    return ban_losses(model, out, data, configs), out
+
+
+def ban_losses(model: BAN, out, data, configs):
+    """loss_bce, loss_refine, loss_td, loss_offset, loss_contrast and their weighted sum (models/BAN.py:213-258)"""
     lay = model._pmap.layout
     ii, jj = lay.ii_t, lay.jj_t
     L = configs.loss
@@ -143,8 +167,7 @@ def train_engine_BAN(model: BAN, data, configs, runtype="train"):
     loss_offset = F.smooth_l1_loss(op[:, 0], og[:, 0]) + F.smooth_l1_loss(op[:, 1], og[:, 1])
     mc = data["map2d_contrasts"].bool()
     loss_contrast = contrast_loss(out["sen_proj"], out["map2d_proj_cells"], mc[:, 0][:, ii, jj], mc[:, 1][:, ii, jj])
-    loss = loss_bce * L.bce + loss_refine * L.refine + loss_td * L.td + loss_offset * L.offset + loss_contrast * L.contrast
-    return loss, out
+    return loss_bce * L.bce + loss_refine * L.refine + loss_td * L.td + loss_offset * L.offset + loss_contrast * L.contrast
 
 
 def infer_BAN(output, configs=None):

@@ -1,0 +1,75 @@
+"""A BAN training step as TWO hipGraphs around the proposal sampler's host round trip.
+
+    graph A   zero_grad, forward_map (encoders ... 2-D map, predictor): ~1900 launches
+    host      sigmoid(tmap) at the kept cells -> vmr_ban_sample_host -> [B, prop_num, 2] copied into a static device buffer
+    graph B   forward_head, the five losses, the WHOLE backward (it walks the autograd graph built while A was captured: the
+              two graphs share one memory pool, so A's saved tensors stay valid), AdamW: ~1900 launches
+
+The eager step issues ~2500 launches of 5-80 us from Python (14 us of host time each): 34.5 ms with 25 ms of kernel time
+(profiles/r02_ban_summary.md).  Dropout stays a fresh draw per replay: the slices' DropCtx seeds are mixed with a device
+step counter that graph A increments (as in vmrframe_amd/trainer.py).  The optimizer is torch.optim.AdamW(capturable=True).
+"""
+from __future__ import annotations
+
+import torch
+
+from .ban import BAN, ban_losses
+
+
+class GraphedBANStep:
+    def __init__(self, model: BAN, optimizer, configs, warmup: int = 3):
+        self.model, self.opt, self.cfg, self.warmup = model, optimizer, configs, max(2, warmup)
+        self.gA = self.gB = None
+        self.data = None
+        self.loss = None
+
+    def _part_a(self):
+        m, d = self.model, self.data
+        self.step_t.add_(1)
+        self.opt.zero_grad(set_to_none=False)
+        self.o, self.r = m.forward_map(d["vfeats"], d["words_ids"], d["vlens"], d["tlens"], max_qlen=self.max_qlen)
+
+    def _part_b(self):
+        m, d = self.model, self.data
+        out = m.forward_head(self.o, self.r, self.pse, d["start_end_offset"], d["vlens"])
+        self.loss = ban_losses(m, out, d, self.cfg)
+        self.loss.backward()
+        self.opt.step()
+        self.out = out
+
+    def _host(self):
+        self.pse.copy_(self.model.sample(self.r["tmap_cells"]), non_blocking=False)
+
+    def capture(self, data):
+        m = self.model
+        dev = next(m.parameters()).device
+        self.data = {k: v.to(dev).clone() for k, v in data.items()}
+        self.max_qlen = int(self.data["tlens"].max())
+        self.step_t = torch.zeros(1, device=dev, dtype=torch.int32)
+        for h in (m._trunk, m._pmap, m._head):
+            h.drop_step = self.step_t
+        self.pse = torch.zeros(self.data["vfeats"].shape[0], m.prop_num, 2, device=dev, dtype=torch.int64)
+        s = self.stream = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(self.warmup):
+                self._part_a(); self._host(); self._part_b()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.gA, self.gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gA, stream=s):
+            self._part_a()
+        with torch.cuda.stream(s):
+            self._host()
+        with torch.cuda.graph(self.gB, stream=s, pool=self.gA.pool()):
+            self._part_b()
+        return self
+
+    def __call__(self, data=None):
+        if data is not None:
+            for k, v in data.items():
+                self.data[k].copy_(v, non_blocking=True)
+        self.gA.replay()
+        self._host()
+        self.gB.replay()
+        return self.loss
