@@ -71,7 +71,9 @@ def run_ban(args, dev, rank, world):
     graphed = not args.no_graph
     if graphed:      # two hipGraphs around the sampler's host round trip (vmrframe_amd/ban_trainer.py)
         from vmrframe_amd.ban_trainer import GraphedBANStep
-        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01, capturable=True)
+        fused = os.environ.get("VMR_BAN_FUSED_ADAMW", "1") == "1"      # torch's multi-tensor AdamW (one kernel per dtype group)
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01,
+                                **(dict(fused=True, capturable=True) if fused else dict(capturable=True)))
         step = GraphedBANStep(model, opt, cfg, warmup=3).capture(data)
     for _ in range(max(3, args.warmup)):
         loss = step()
