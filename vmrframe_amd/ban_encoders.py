@@ -124,9 +124,16 @@ class _BiLSTM(torch.autograd.Function):
         dw_hh = torch.empty(Z, 4 * H, H, device=dev)
         dw_ih = torch.empty(Z, 4 * H, I, device=dev)
         dxs = torch.empty(Z, B, T, I, device=dev, dtype=dt)
+        def wgrad(a2, b2, out):      # out [4H, N] = a2^T . b2 over K = B*T: few output tiles, long K -> split-K slabs + one
+            r = ops.mm_few_tiles(a2, b2, 1, 1)     # reduce launch (bf16); the plain product otherwise (fp32, or many tiles)
+            if r is None:
+                ops.mm(a2, b2, 1, 1, out=out, out_f32=True)
+            else:
+                out.copy_(r)
+
         for z in range(Z):   # one product per weight over all steps (K = B*T); dx of each direction's step sequence
-            ops.mm(dg2[z], hp[z].view(B * T, H), 1, 1, out=dw_hh[z], out_f32=True)
-            ops.mm(dg2[z], xs[z].view(B * T, I), 1, 1, out=dw_ih[z], out_f32=True)
+            wgrad(dg2[z], hp[z].view(B * T, H), dw_hh[z])
+            wgrad(dg2[z], xs[z].view(B * T, I), dw_ih[z])
             ops.mm(dg2[z], w_ih[z], 0, 1, out=dxs[z].view(B * T, I))
         dbias = dg2.float().sum(1)
         dxs = dxs.view(K, 2, B, T, I)                                    # (the reversal is its own inverse; zero past len)
