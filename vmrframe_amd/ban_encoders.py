@@ -17,11 +17,10 @@ The reference runs `nn.LSTM(input, hidden, 1, batch_first=True, bidirectional=Tr
   * no per-sample host loop: the mean over valid steps is sum_t / len (the output is zero past len).
 
 State-dict keys are the reference's (`biLSTM.weight_ih_l0`, `..._reverse`, ...), so a BAN checkpoint's encoder
-weights load unchanged.  This is a correct, measured first version, not a tuned one: the per-step products are
-[B, 4H, H] with B = 64 rows -- launch-bound; a persistent recurrence kernel is the next step.
-NOT built: QueryEncoder's embedding front (`F.embedding` over [pad | unk | glove]) is ops.embedding's job and is
-wired in `QueryEncoder` below; everything else of BAN outside ban_map.py (CQAttention variant, TemporalDifference,
-sampling, losses) is still out.
+weights load unchanged.  The recurrence is launch-serial by construction (one fused launch per step, bf16, H = 256 / 512;
+product + cell launches otherwise); a persistent recurrence kernel is the next step.  QueryEncoder's
+embedding front (`F.embedding` over [pad | unk | glove]) is ops.embedding.  The rest of BAN: ban_trunk.py, ban_map.py,
+ban_sampler.py, ban_head.py, assembled in ban.py.
 """
 from __future__ import annotations
 

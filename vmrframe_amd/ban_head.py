@@ -7,7 +7,7 @@ proposals -- reference models/BAN.py:107-118:
     offset = predictor_offset(prop_feature)                                   # Linear-ReLU-Dropout-Linear -> [B, prop_num, 2]
 
 plus `sen_proj = contrast_encoder_t(sentence_feature)` (:98).  Parameter names are the reference's.  The sampler in front
-of it (`Aaptive_Proposal_Sampling`, a data-dependent per-sample NMS loop, models/BANlib/model.py:371-435) is NOT built.
+of it (`Aaptive_Proposal_Sampling`, models/BANlib/model.py:371-435) is ban_sampler.py (a host routine of the library).
 
 The edge-conv layer, restated.  The reference's AdaptiveGCN (models/BANlib/model.py:565-589) materialises
 feature[b, :, i, j] = [x_j - x_i | x_i] for every ordered pair of proposals -- [B, 2D, N, N], 2.7 GB in fp32 at B = 64,

@@ -3,10 +3,9 @@ names: "T=128 -> 128x128 score map").
 
 Mirrors reference models/BAN.py:87-99 (`boundary_aggregation`, `content_aggregation`, `map2d_proj`,
 `predictor`, `contrast_encoder`) with the reference's parameter names for those sub-modules, so a BAN
-`state_dict` loads into it with `strict=False`.  NOT built (and not claimed): BAN's LSTM encoders, its CQAttention
-variant, TemporalDifference, proposal sampling / interaction and the refine / offset / contrast losses
-(models/BAN.py:76-86,100-134, models/BANlib/model.py:8-214,345-684) -- this module starts from `hidden_b`
-and `fuse_feature`, the two [B, N, F] tensors that stage consumes.
+`state_dict` loads into it with `strict=False`.  The parts of BAN in front of and behind this stage live in ban_trunk.py
+(encoders, CQAttention variant, TemporalDifference), ban_sampler.py and ban_head.py, assembled in ban.py; this module
+starts from `hidden_b` and `fuse_feature`, the two [B, N, F] tensors the stage consumes.
 
 MI355X-first restatement (csrc/map2d.hip, DESIGN.md "N2"):
   * only the cells the reference's mask keeps exist, compact and cell-major ([B, C, F], C = 5376 of 16384 cells

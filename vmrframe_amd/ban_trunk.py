@@ -19,8 +19,8 @@ zero as in the reference); `TemporalDifference` (:160-218, `model_type='lstm'`) 
 length (the reference does not pack them), `Linear + ReLU + Dropout` through the fused GEMM epilogue, and the
 neighbour-difference energy `td` (a few elementwise torch ops on [B, T, F]: glue, 0.1 MB).
 
-Still NOT built: proposal sampling (`Aaptive_Proposal_Sampling`, a per-sample NMS loop), `PositionEmbeddingSine`,
-`Adaptive_Prop_Interaction` (GCN), `predictor2` / `predictor_offset`, and BAN's five losses (models/BAN.py:100-134,136-209).
+The rest of `BAN.forward` -- proposal sampling, the proposal head, the five losses -- is ban_sampler.py, ban_head.py and
+ban.py.
 """
 from __future__ import annotations
 
