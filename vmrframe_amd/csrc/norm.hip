@@ -147,14 +147,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   for (int c = 0; c < MAXC; ++c)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
+  // gamma of this lane's columns, ONCE: as loads inside the row loop (twice per row) they were the YOUNGEST requests in
+  // flight, and waiting for them (vmcnt counts in order) drained the next row's prefetch four times per row -- the
+  // prefetch overlapped nothing (found with scratch/isa_events.py)
+  float gam[MAXC][8];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * 64 + lane) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gam[c][e] = 0.f;
+    if (i < D) Vec8<float>::load(gamma + i, gam[c]);
+  }
   while (row < rows) {
+    // The next row's operands: inline-asm loads, waited for by hand AFTER this row's arithmetic (see below).  As ordinary
+    // loads they were waited for with vmcnt(0) at the first use of the loop-carried registers -- the compiler does not
+    // count across the back edge -- i.e. before the arithmetic they were meant to hide under.
     TV8 nx[MAXC], ng[MAXC], nr[MAXC];
     {
       const int64_t rc = min(row + stride, rows - 1);
 #pragma unroll
       for (int c = 0; c < MAXC; ++c) {
-        const int i = (c * 64 + lane) * 8;
-        if (i < D) {
+        const int i = min((c * 64 + lane) * 8, D - 8);           // (clamped, unconditional: the columns past D are never used)
+        if constexpr (sizeof(TV8) == 16) {                       // bf16: one 16-byte load per operand
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nx[c]) : "v"(x + rc * D + i) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ng[c]) : "v"(dy + rc * D + i) : "memory");
+          if (dres) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nr[c]) : "v"(dres + rc * D + i) : "memory");
+        } else {                                                 // fp32 (the parity path): ordinary loads
           nx[c] = *reinterpret_cast<const TV8*>(x + rc * D + i);
           ng[c] = *reinterpret_cast<const TV8*>(dy + rc * D + i);
           if (dres) nr[c] = *reinterpret_cast<const TV8*>(dres + rc * D + i);
@@ -168,8 +186,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int c = 0; c < MAXC; ++c) {
       const int i = (c * 64 + lane) * 8;
       if (i >= D) continue;
-      float g[8];
-      Vec8<float>::load(gamma + i, g);
+      const float (&g)[8] = gam[c];
       keep[c] = drop_p > 0.f ? vmr_keep8(seed, (uint64_t)row * D + i, thresh) : 0xFFu;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -185,24 +202,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
     s1 = wave_sum(s1) / (float)D;
     s2 = wave_sum(s2) / (float)D;
+    float o[MAXC][8];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       const int i = (c * 64 + lane) * 8;
       if (i >= D) continue;
-      float g[8], o[8];
-      Vec8<float>::load(gamma + i, g);
+      const float (&g)[8] = gam[c];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {   // (xhat and dxhat are recomputed rather than kept: 32 VGPRs less)
         float d = (float)cg[c][e];
         if (drop_p > 0.f) d = ((keep[c] >> e) & 1) ? d * dscale : 0.f;
         const float h = ((float)cx[c][e] - mean) * rstd;
-        o[e] = rstd * (d * g[e] - s1 - h * s2);
-        if (dres) o[e] += (float)cr[c][e];
+        o[c][e] = rstd * (d * g[e] - s1 - h * s2);
+        if (dres) o[c][e] += (float)cr[c][e];
       }
-      Vec8<T>::store(dx + row * D + i, o);
+    }
+    // the next row has had this row's arithmetic to arrive; its registers become valid HERE (before the stores below are
+    // issued, so the wait does not cover them: they fly under the next iteration)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if constexpr (sizeof(TV8) == 16) {
+        asm volatile("" : "+v"(nx[c]), "+v"(ng[c]));
+        if (dres) asm volatile("" : "+v"(nr[c]));
+      }
+      cx[c] = nx[c]; cg[c] = ng[c]; cr[c] = nr[c];
     }
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) { cx[c] = nx[c]; cg[c] = ng[c]; cr[c] = nr[c]; }
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = (c * 64 + lane) * 8;
+      if (i < D) Vec8<T>::store(dx + row * D + i, o[c]);
+    }
     row += stride;
   }
   if (!part) return;
