@@ -19,12 +19,14 @@ template <typename T, int MAXC>
 __device__ __forceinline__ void load_row(const T* __restrict__ p, int D, int lane, float (&v)[MAXC][8]) {
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
+    // unconditional, index-clamped load, zeroed afterwards by a select: as "if (i < D) load else zero" every chunk got its
+    // own branch AND its own s_waitcnt vmcnt(0) inside it -- ln_dwconv_fwd's four rows x two chunks were EIGHT dependent
+    // round trips per wave (found with scratch/isa_events.py).  D is a multiple of 8 (16-byte rows).
     const int i = (c * 64 + lane) * 8;
-    if (i < D) Vec8<T>::load(p + i, v[c]);
-    else {
+    Vec8<T>::load(p + min(i, D - 8), v[c]);
+    const float keep = i < D ? 1.f : 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
-    }
+    for (int e = 0; e < 8; ++e) v[c][e] = keep != 0.f ? v[c][e] : 0.f;
   }
 }
 
@@ -62,9 +64,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar branches
   const uint32_t thresh = vmr_drop_thresh(drop_p);
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  // gamma / beta of this lane's columns once, and every operand of a row requested together (unconditional, index-
+  // clamped): as loads behind the statistics, each under its own column guard, a row was five dependent round trips
+  float gam[MAXC][8], bet[MAXC][8];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ic = min((c * 64 + lane) * 8, D - 8);
+    Vec8<float>::load(gamma + ic, gam[c]);
+    Vec8<float>::load(beta + ic, bet[c]);
+  }
   for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
-    float v[MAXC][8];
+    float v[MAXC][8], pv[MAXC][8];
     load_row<T, MAXC>(x + row * D, D, lane, v);
+    if (pos) {
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) Vec8<T>::load(pos + (int64_t)(row % S) * D + min((c * 64 + lane) * 8, D - 8), pv[c]);
+    }
     float mean, rstd;
     row_stats<MAXC>(v, D, lane, eps, mean, rstd);
     if (lane == 0) {
@@ -75,16 +90,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     for (int c = 0; c < MAXC; ++c) {
       const int i = (c * 64 + lane) * 8;
       if (i >= D) continue;
-      float g[8], b[8], o[8];
-      Vec8<float>::load(gamma + i, g);
-      Vec8<float>::load(beta + i, b);
+      const float (&g)[8] = gam[c];
+      const float (&b)[8] = bet[c];
+      float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
       if (pos) {
-        float pv[8];
-        Vec8<T>::load(pos + (int64_t)(row % S) * D + i, pv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += pv[e];
+        for (int e = 0; e < 8; ++e) o[e] += pv[c][e];
       }
       if (drop_p > 0.f) {
         const uint32_t keep = vmr_keep8(seed, (uint64_t)row * D + i, thresh);
@@ -400,7 +413,7 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(const T* __restrict_
     for (int c = 0; c < MAXC; ++c) {
       const int i = (c * 64 + lane) * 8;
       if (i >= D) continue;
-      float g[8], bb[8];
+      float g[8], bb[8];         // (kept inside: hoisting them costs 22 VGPRs = one resident wave per SIMD: 17.5 -> 18.8 us)
       Vec8<float>::load(gamma + i, g);
       Vec8<float>::load(beta + i, bb);
 #pragma unroll
