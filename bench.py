@@ -36,9 +36,10 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 def run_ban(args, dev, rank, world):
     """BASELINE.json configs[4] as a whole: the BAN train step (reference models/BAN.py: forward incl. the host-side proposal
     sampler, the five losses of train_engine_BAN, backward, AdamW) at config/anet/BAN.yaml's model sizes with T = 128 -> a
-    128 x 128 score map (5376 kept cells, 80 proposals per clip), B = 64 clips per GPU, bf16.  Eager: the sampler's
-    device-to-host copy splits the step, and the optimizer is torch.optim.AdamW (the flat fused one is SeqPAN's).  N > 1 =
-    independent replicas (no gradient exchange is wired for this row yet): "replicas only"."""
+    128 x 128 score map (5376 kept cells, 80 proposals per clip), B = 64 clips per GPU; --dtype fp16 is configs[4]'s dtype
+    (dynamic loss scale carried on the device by FlatAdamW), bf16 / fp32 the others.  The optimizer is the flat fused AdamW
+    (VMR_BAN_TORCH_ADAMW=1: torch.optim.AdamW, no loss scale -> bf16 / fp32 only).  N > 1 = independent replicas (no gradient
+    exchange is wired for this row yet): "replicas only"."""
     from types import SimpleNamespace as NS
     import vmrframe_amd as V
     torch.manual_seed(1234 + rank)
@@ -50,8 +51,15 @@ def run_ban(args, dev, rank, world):
              loss=NS(min_iou=CFG5["min_iou"], max_iou=CFG5["max_iou"], bce=2.0, refine=1.0, td=0.1, offset=1.0, contrast=0.1))
     rng = np.random.default_rng(1234)
     model = V.BAN(cfg, pre_train_emb=rng.standard_normal((Vw, E)).astype(np.float32),
-                  compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, sync_timing=False).to(dev).train()
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01)
+                  compute_dtype={"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype],
+                  sync_timing=False).to(dev).train()
+    torch_opt = os.environ.get("VMR_BAN_TORCH_ADAMW", "0") == "1"
+    assert not (torch_opt and args.dtype == "fp16"), "fp16 needs the loss scale FlatAdamW carries"
+    from vmrframe_amd.optim import FlatAdamW
+    if torch_opt:
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01)
+    else:
+        opt = FlatAdamW(model, lr=1e-4, weight_decay=0.01, max_norm=1.0)
     gen = torch.Generator().manual_seed(1234 + rank)
     vl = torch.randint(T // 2, T + 1, (B,), generator=gen); vl[0] = T
     ql = torch.randint(5, Lq + 1, (B,), generator=gen); ql[0] = Lq
@@ -62,18 +70,24 @@ def run_ban(args, dev, rank, world):
     data = {k: v.to(dev) for k, v in data.items()}
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        if torch_opt:
+            opt.zero_grad(set_to_none=True)
+        else:
+            opt.zero_grad()
         loss, _ = V.train_engine_BAN(model, data, cfg, "train")
-        loss.backward()
+        if torch_opt:
+            loss.backward()
+        else:
+            opt.backward(loss)
         opt.step()
         return loss
 
     graphed = not args.no_graph
     if graphed:      # two hipGraphs around the sampler's host round trip (vmrframe_amd/ban_trainer.py)
         from vmrframe_amd.ban_trainer import GraphedBANStep
-        fused = os.environ.get("VMR_BAN_FUSED_ADAMW", "1") == "1"      # torch's multi-tensor AdamW (one kernel per dtype group)
-        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01,
-                                **(dict(fused=True, capturable=True) if fused else dict(capturable=True)))
+        if torch_opt:
+            opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01,
+                                    fused=True, capturable=True)
         step = GraphedBANStep(model, opt, cfg, warmup=3).capture(data)
     for _ in range(max(3, args.warmup)):
         loss = step()
@@ -98,8 +112,9 @@ def run_ban(args, dev, rank, world):
                           "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                           "config": {"workload": "BAN (configs[4], next-row N2): B=64 clips/GPU, T=128, 20-word queries, vdim 1024, dim 256, "
                                                  "2 LSTM layers, fuse_dim 512, 5376 map cells, 80 proposals; forward (host sampler "
-                                                 "included) + five losses + backward + torch AdamW; two hipGraphs around the "
-                                                 "sampler unless --no-graph; replicas only for N > 1",
+                                                 "included) + five losses + backward + clip + AdamW (" +
+                                                 ("torch.optim" if torch_opt else "flat fused, loss scale %g" % opt.loss_scale()) +
+                                                 "); two hipGraphs around the sampler unless --no-graph; replicas only for N > 1",
                                      "global_batch": B * world, "parallelism": f"dp{world}"},
                           "final_loss": round(float(loss.detach()), 4), "hipgraph": graphed, "roofline": None, "cpu_baseline": None}))
     return 0
@@ -275,7 +290,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)      # ~1.8 s of timed region at cfg2
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="compute dtype (fp32 masters either way); fp16 = BASELINE configs[4]'s dtype, wired for --workload ban / banmap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of whole-step hipGraph replay")
     ap.add_argument("--workload", default="seqpan", choices=["seqpan", "basefast", "banmap", "ban"],

@@ -14,9 +14,18 @@
  *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and
  *     returns without synchronising: 0 on success, negative on error
  *     (vmr_last_error() gives a thread-local message).
- *   - tensors are row-major, last dim contiguous. `dtype` is VMR_F32 or
- *     VMR_BF16 for activations; statistics, biases, LayerNorm affine
+ *   - tensors are row-major, last dim contiguous. `dtype` is VMR_F32,
+ *     VMR_BF16 or VMR_F16 for activations; statistics, biases, LayerNorm affine
  *     parameters, losses and weight gradients are always fp32.
+ *   - VMR_F16 (IEEE half; BASELINE configs[4] "BAN ... fp16"): same kernels and
+ *     layouts as VMR_BF16 (v_mfma_f32_16x16x32_f16 has the bf16 rate).  The
+ *     reference's -1e30 masks (models/layers.py:9-12) never exist in the
+ *     activation dtype: every masked softmax / pool applies them in fp32 inside
+ *     the kernel, so nothing overflows half's +-65504.  Activation GRADIENTS in
+ *     half need a loss scale: the caller multiplies the loss by S, weight
+ *     gradients (always fp32) come out scaled by S and vmr_adamw divides by S
+ *     (its `grad_scale`); a non-finite gradient norm makes vmr_adamw skip the
+ *     update, which is what a dynamic scaler keys on (vmrframe_amd/optim.py).
  */
 #ifndef VMR_HIP_H
 #define VMR_HIP_H
@@ -28,6 +37,7 @@ extern "C" {
 
 #define VMR_F32 0
 #define VMR_BF16 1
+#define VMR_F16 2
 
 #define VMR_NEG_INF_MASK (-1e30f) /* models/layers.py:9 mask_value */
 
@@ -503,17 +513,25 @@ int vmr_resample_pad(const float* arena, const int64_t* row_off, const int* seg,
 /* --------------------------------------------------------------- optimizer
  * fused AdamW over a flat fp32 parameter arena (utils/utils.py:87-97:
  * AdamW, weight_decay 0.01 except names containing bias/layer_norm) with the
- * clip_grad_norm_ scale (main.py:95) folded in; also refreshes the bf16
- * compute copy of the weights.  decay: per-element 0/1 mask as uint8. */
+ * clip_grad_norm_ scale (main.py:95) folded in; also refreshes the 16-bit
+ * compute copy of the weights (p16: bf16 or f16 per p16_dtype, nullable).
+ * decay: per-element 0/1 mask as uint8.
+ * loss_scale (nullable, device float[1] = S): g and gnorm_sq were produced from
+ * S * loss; the kernel divides both by S, and a non-finite norm SKIPS the whole
+ * update.  vmr_loss_scale_update then keeps the dynamic scaler's state
+ * {S, clean streak} on the device: overflow -> S /= 2 (>= min_scale), the step
+ * counter holds; else step_dev += 1 and S *= 2 every growth_interval clean steps. */
 int vmr_sumsq(const float* g, float* out /*[1], accumulated*/, int64_t n, void* stream);
-int vmr_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay, void* p_bf16,
+int vmr_loss_scale_update(float* state /*[2]*/, const float* gnorm_sq, int* step_dev /*nullable*/, int growth_interval,
+                          float min_scale, void* stream);
+int vmr_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay, void* p16, int p16_dtype,
               const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
               float wd, int step,
               const int* step_dev /*nullable: 0-based step count on the device, overrides step*/,
               float warmup_steps, float total_steps /* with step_dev and total_steps > 0: lr is scaled
               by transformers' linear warm-up/decay multiplier of step_dev[0] (utils/utils.py:95-96),
               evaluated on the device so a captured hipGraph replays the schedule */,
-              int64_t n, void* stream);
+              const float* loss_scale /*nullable*/, int64_t n, void* stream);
 
 /* ------------------------------------------------ BAN 2-D proposal map (N2)
  * Replaces the diagonal loops of SparseMaxPool / DenseMaxPool (models/BANlib/model.py:226-290) and

@@ -26,7 +26,15 @@ def _ints(rows, cols, dt, dev):
     return torch.randint(-3, 4, (rows, cols), device=dev).to(dt)
 
 
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+DT16 = [torch.bfloat16, torch.float16]     # the two 16-bit element types share every kernel (VMR_BF16 / VMR_F16)
+
+
+def _code(dt):
+    from vmrframe_amd import _lib as L
+    return {torch.bfloat16: L.BF16, torch.float16: L.F16, torch.float32: L.F32}[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 192), (200, 136, 72), (70, 50, 33), (8, 8, 8),
                                    (1, 1, 5), (130, 4, 1024), (60, 96, 400), (300, 20, 24)])
 def test_gemm_exact_integer_all_layouts(dev, dt, shape):
@@ -44,9 +52,10 @@ def test_gemm_exact_integer_all_layouts(dev, dt, shape):
             assert torch.equal(out, ref), (dt, shape, ta, tb)
 
 
+@pytest.mark.parametrize("dt", DT16)
 @pytest.mark.parametrize("shape", [(512, 256, 128), (768, 384, 192), (9472, 1024, 128), (1024, 1024, 2368),
                                    (9472, 2048, 192)])
-def test_gemm_lds_dma_kernels_exact(dev, shape):
+def test_gemm_lds_dma_kernels_exact(dev, shape, dt):
     """The interior LDS-DMA kernels (128x128 / 160x128 tiles, all four layouts, and the 512-thread 320x128 tile the
     cost model picks for the two-round [9472 x 2048] x.W^T product), including the ragged last row tile at
     M = 9472 and fused epilogues with dropout."""
@@ -54,7 +63,7 @@ def test_gemm_lds_dma_kernels_exact(dev, shape):
     from vmrframe_amd import _lib as L
     M, N, K = shape
     torch.manual_seed(M + N + K)
-    dt = torch.bfloat16
+    DC = _code(dt)
     for ta in (0, 1):
         for tb in (0, 1):
             A = _ints(K, M, dt, dev) if ta else _ints(M, K, dt, dev)
@@ -66,13 +75,13 @@ def test_gemm_lds_dma_kernels_exact(dev, shape):
     res = _ints(M, N, dt, dev)
     rs = torch.rand(M, device=dev)
     o32 = torch.empty(M, N, device=dev)
-    ops.gemm(A, B, o32, M, N, K, 0, 0, K, K, N, dtype=L.BF16, residual=res, ldr=N, rowscale=rs,
+    ops.gemm(A, B, o32, M, N, K, 0, 0, K, K, N, dtype=DC, residual=res, ldr=N, rowscale=rs,
              flags=L.EPI_DROPOUT | L.EPI_OUT_F32 | L.EPI_RESIDUAL | L.EPI_ROWSCALE, drop=(0.25, 5, None))
     mask = ops.dropout_mask(M * N, 0.25, 5, dev).view(M, N)
     ref = ((A.float() @ B.float().t()) * mask + res.float()) * rs[:, None]
     assert torch.allclose(o32, ref, atol=1e-3, rtol=1e-5)
     acc = torch.ones(M, N, device=dev)
-    ops.gemm(A, B, acc, M, N, K, 0, 0, K, K, N, dtype=L.BF16, flags=L.EPI_ACCUM, splitk=2 if K >= 256 else 1)
+    ops.gemm(A, B, acc, M, N, K, 0, 0, K, K, N, dtype=DC, flags=L.EPI_ACCUM, splitk=2 if K >= 256 else 1)
     assert torch.equal(acc - 1, A.float() @ B.float().t())
     # the register-direct bf16 epilogue (and, at [9472 x 1024], the 160-row tile with its ragged last
     # row tile): bias + ReLU + dropout + aux + residual, both B layouts
@@ -81,7 +90,7 @@ def test_gemm_lds_dma_kernels_exact(dev, shape):
     for tb, Bm in ((0, B), (1, B.t().contiguous())):
         out = torch.empty(M, N, device=dev, dtype=dt)
         aux = torch.empty_like(out)
-        ops.gemm(A, Bm, out, M, N, K, 0, tb, K, Bm.stride(0), N, dtype=L.BF16, bias=bias, residual=res, aux=aux, ldr=N,
+        ops.gemm(A, Bm, out, M, N, K, 0, tb, K, Bm.stride(0), N, dtype=DC, bias=bias, residual=res, aux=aux, ldr=N,
                  flags=L.EPI_BIAS | L.EPI_RELU | L.EPI_DROPOUT | L.EPI_RESIDUAL | L.EPI_AUX, drop=(0.25, 9, None))
         h = torch.relu(A.float() @ B.float().t() + bias) * mask
         assert torch.equal(aux, h.to(dt)), (shape, tb)
@@ -89,13 +98,13 @@ def test_gemm_lds_dma_kernels_exact(dev, shape):
     # the same epilogue with the mask kept as a bit matrix (VMR_EPI_AUX_BITS), and the backward kernel that reads it
     d = L.GemmDesc()
     d.A, d.B, d.C, d.bias, d.residual = A.data_ptr(), B.data_ptr(), out.data_ptr(), bias.data_ptr(), res.data_ptr()
-    d.lda, d.ldb, d.ldc, d.ldr, d.M, d.N, d.K, d.dtype = K, K, N, N, M, N, K, L.BF16
+    d.lda, d.ldb, d.ldc, d.ldr, d.M, d.N, d.K, d.dtype = K, K, N, N, M, N, K, DC
     d.flags = L.EPI_BIAS | L.EPI_RELU | L.EPI_DROPOUT | L.EPI_RESIDUAL
     d.Z1 = d.Z2 = d.splitk = 1
     assert L.lib().vmr_gemm_aux_bits_supported(C.byref(d)) == 1
     bits = torch.zeros(M, N // 8, device=dev, dtype=torch.uint8)
     out2 = torch.empty(M, N, device=dev, dtype=dt)
-    ops.gemm(A, B, out2, M, N, K, 0, 0, K, K, N, dtype=L.BF16, bias=bias, residual=res, aux=bits, ldr=N,
+    ops.gemm(A, B, out2, M, N, K, 0, 0, K, K, N, dtype=DC, bias=bias, residual=res, aux=bits, ldr=N,
              flags=L.EPI_BIAS | L.EPI_RELU | L.EPI_DROPOUT | L.EPI_RESIDUAL | L.EPI_AUX | L.EPI_AUX_BITS, drop=(0.25, 9, None))
     assert torch.equal(out2, (h + res.float()).to(dt))
     want = (h.to(dt) != 0).view(M, N // 8, 8).to(torch.int32)
@@ -105,25 +114,27 @@ def test_gemm_lds_dma_kernels_exact(dev, shape):
     dz1, dz3 = torch.empty_like(dy), torch.empty_like(dy)
     db1, db3 = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
     st = L.stream_ptr()
-    L.check(L.lib().vmr_relu_bwd_bias(1, dy.data_ptr(), aux.data_ptr(), dz1.data_ptr(), db1.data_ptr(), M, N, N, 2.0, L.BF16,
+    L.check(L.lib().vmr_relu_bwd_bias(1, dy.data_ptr(), aux.data_ptr(), dz1.data_ptr(), db1.data_ptr(), M, N, N, 2.0, DC,
                                       0.0, 0, None, None, 1.0, st), "mode 1")
-    L.check(L.lib().vmr_relu_bwd_bias(3, dy.data_ptr(), bits.data_ptr(), dz3.data_ptr(), db3.data_ptr(), M, N, N, 2.0, L.BF16,
+    L.check(L.lib().vmr_relu_bwd_bias(3, dy.data_ptr(), bits.data_ptr(), dz3.data_ptr(), db3.data_ptr(), M, N, N, 2.0, DC,
                                       0.0, 0, None, None, 1.0, st), "mode 3")
     assert torch.equal(dz1, dz3) and torch.allclose(db1, db3, rtol=1e-6, atol=1e-3)
 
 
-def test_gemm_every_ring_variant_exact(dev):
-    """vmr_gemm under each operand-ring variant of the LDS-DMA kernels (vmr_debug_set_gemm_dma 1, 2, 3; 0 = the register-
-    staged kernel): all four operand layouts, K = 128 .. 1088 (1 .. 34 ring steps, odd counts included), the fused
-    epilogue and a split-K slab product, bit-exact on small integers.  (Variant 1's BK = 32 loop dropped its first K
-    step until round 2 -- no test selected it.)"""
+@pytest.mark.parametrize("dt", DT16)
+def test_gemm_dma_on_and_off_exact(dev, dt):
+    """vmr_gemm with the LDS-DMA kernels on (vmr_debug_set_gemm_dma 1, the default) and off (0 = the register-staged
+    kernel): all four operand layouts, K = 128 .. 1088 (2 .. 17 ring steps, odd counts included), the fused epilogue and
+    a split-K slab product, bit-exact on small integers.  (Round 2's extra ring variants -- BK = 32 x 3 / 4 stages -- are
+    no longer in the library; the switch refuses anything but 0 / 1.)"""
     ops = _ops()
     from vmrframe_amd import _lib as L
-    dt = torch.bfloat16
+    DC = _code(dt)
     lib = L.lib()
+    assert lib.vmr_debug_set_gemm_dma(3) != 0 and lib.vmr_debug_set_gemm_dma(2) != 0
     try:
-        for mode in (1, 3, 2, 0):
-            lib.vmr_debug_set_gemm_dma(mode)
+        for mode in (1, 0):
+            assert lib.vmr_debug_set_gemm_dma(mode) == 0
             for (M, N, K) in [(256, 128, 128), (384, 256, 192), (1280, 384, 1088), (128, 128, 320)]:
                 for ta, tb in ((0, 0), (1, 1), (0, 1), (1, 0)):
                     torch.manual_seed(M + N + K + 2 * ta + tb)
@@ -137,7 +148,7 @@ def test_gemm_every_ring_variant_exact(dev):
             bias, res = torch.randn(N, device=dev), _ints(M, N, dt, dev)
             out = torch.empty(M, N, device=dev, dtype=dt)
             aux = torch.empty_like(out)
-            ops.gemm(A, B, out, M, N, K, 0, 0, K, K, N, dtype=L.BF16, bias=bias, residual=res, aux=aux, ldr=N,
+            ops.gemm(A, B, out, M, N, K, 0, 0, K, K, N, dtype=DC, bias=bias, residual=res, aux=aux, ldr=N,
                      flags=L.EPI_BIAS | L.EPI_RELU | L.EPI_DROPOUT | L.EPI_RESIDUAL | L.EPI_AUX, drop=(0.25, 9, None))
             mask = ops.dropout_mask(M * N, 0.25, 9, dev).view(M, N)
             h = torch.relu(ref + bias) * mask
@@ -145,19 +156,20 @@ def test_gemm_every_ring_variant_exact(dev):
             M, N, K, sk = 256, 384, 1152, 3
             A, B = _ints(K, M, dt, dev), _ints(K, N, dt, dev)
             ws = torch.empty(sk, M, N, device=dev)
-            ops.gemm(A, B, ws, M, N, K, 1, 1, M, N, N, dtype=L.BF16, flags=L.EPI_SLAB, splitk=sk)
+            ops.gemm(A, B, ws, M, N, K, 1, 1, M, N, N, dtype=DC, flags=L.EPI_SLAB, splitk=sk)
             assert torch.equal(ws.sum(0), A.float().t() @ B.float()), mode
     finally:
         lib.vmr_debug_set_gemm_dma(-1)
 
 
-def test_gemm_8phase_kernel_exact(dev):
+@pytest.mark.parametrize("dt", DT16)
+def test_gemm_8phase_kernel_exact(dev, dt):
     """The 256 x 256 8-phase kernel (gemm_p8_body), forced wherever the shape allows: K-contiguous operands (plain,
     ragged last row tile, fused epilogue with 16-byte permuted stores) and the transposed-operand split-K slab layout,
     bit-exact on small integers; then the default policy on a shape the rounds model gives to it."""
     ops = _ops()
     from vmrframe_amd import _lib as L
-    dt = torch.bfloat16
+    DC = _code(dt)
     lib = L.lib()
     try:
         lib.vmr_debug_set_gemm_p8(2)
@@ -171,7 +183,7 @@ def test_gemm_8phase_kernel_exact(dev):
             res = _ints(M, N, dt, dev)
             out = torch.empty(M, N, device=dev, dtype=dt)
             aux = torch.empty_like(out)
-            ops.gemm(A, B, out, M, N, K, 0, 0, K, K, N, dtype=L.BF16, bias=bias, residual=res, aux=aux, ldr=N,
+            ops.gemm(A, B, out, M, N, K, 0, 0, K, K, N, dtype=DC, bias=bias, residual=res, aux=aux, ldr=N,
                      flags=L.EPI_BIAS | L.EPI_RELU | L.EPI_DROPOUT | L.EPI_RESIDUAL | L.EPI_AUX, drop=(0.25, 9, None))
             mask = ops.dropout_mask(M * N, 0.25, 9, dev).view(M, N)
             h = torch.relu(ref + bias) * mask
@@ -184,7 +196,7 @@ def test_gemm_8phase_kernel_exact(dev):
                 out = ops.mm(A, B, 1, 1, out_f32=True)
             else:
                 ws = torch.empty(sk, M, N, device=dev)
-                ops.gemm(A, B, ws, M, N, K, 1, 1, M, N, N, dtype=L.BF16, flags=L.EPI_SLAB, splitk=sk)
+                ops.gemm(A, B, ws, M, N, K, 1, 1, M, N, N, dtype=DC, flags=L.EPI_SLAB, splitk=sk)
                 out = ws.sum(0)
             assert torch.equal(out, ref), (M, N, K, sk)
     finally:
@@ -194,19 +206,19 @@ def test_gemm_8phase_kernel_exact(dev):
     assert torch.equal(ops.mm(A, B, 0, 0, out_f32=True), A.float() @ B.float().t())
 
 
+@pytest.mark.parametrize("dt", DT16)
 @pytest.mark.parametrize("shape", [(1024, 1024, 2112, 8), (256, 128, 1024, 4), (1024, 1024, 8192, 8)])
-def test_gemm_splitk_slabs_colsum(dev, shape):
+def test_gemm_splitk_slabs_colsum(dev, shape, dt):
     """Weight-gradient shape: dW = A^T.B with split-K slabs (plain fp32 partials + vmr_splitk_reduce) and the
     bias gradient (column sums of A^T) riding on the product."""
     ops = _ops()
     from vmrframe_amd import _lib as L
     M, N, K, sk = shape
     torch.manual_seed(K)
-    dt = torch.bfloat16
     A, B = _ints(K, M, dt, dev), _ints(K, N, dt, dev)
     ws = torch.empty(sk, M, N, device=dev)
     cs = torch.ones(M, device=dev)
-    ops.gemm(A, B, ws, M, N, K, 1, 1, M, N, N, dtype=L.BF16, flags=L.EPI_SLAB, splitk=sk, a_colsum=cs)
+    ops.gemm(A, B, ws, M, N, K, 1, 1, M, N, N, dtype=_code(dt), flags=L.EPI_SLAB, splitk=sk, a_colsum=cs)
     dst = torch.ones(M, N, device=dev)
     L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), dst.data_ptr(), sk, M * N, N, N, L.stream_ptr()), "reduce")
     assert torch.equal(dst - 1, A.float().t() @ B.float())
@@ -220,9 +232,10 @@ def test_gemm_splitk_slabs_colsum(dev, shape):
         assert torch.equal(dst2 - 1, (A.float().t() @ B.float())[:, :kf])
 
 
+@pytest.mark.parametrize("dt", DT16)
 @pytest.mark.parametrize("shape", [(512, 256, 256, 256, 256, 1024, 4), (9472, 1024, 128, 1024, 1024, 1024, 4),
                                    (8192, 1024, 192, 1024, 1024, 2048, 8), (200, 256, 256, 256, 256, 1024, 4)])
-def test_gemm2_reduce_exact(dev, shape):
+def test_gemm2_reduce_exact(dev, shape, dt):
     """vmr_gemm2_reduce: an x.W^T product (with bias + residual epilogue), a transposed-operand split-K slab product
     (with the bias-gradient column sums) and the slab reduction of an EARLIER product in ONE launch -- all three
     bit-exact on small-integer operands, for both tile heights; the last shape (M not a multiple of 8 x 16) takes the
@@ -231,7 +244,6 @@ def test_gemm2_reduce_exact(dev, shape):
     from vmrframe_amd import _lib as L
     M1, N1, K1, M2, N2, K2, sk = shape
     torch.manual_seed(M1 + K2)
-    dt = torch.bfloat16
     A1, B1 = _ints(M1, K1, dt, dev), _ints(N1, K1, dt, dev)
     bias = torch.randint(-2, 3, (N1,), device=dev).float()
     res = _ints(M1, N1, dt, dev)
@@ -244,11 +256,11 @@ def test_gemm2_reduce_exact(dev, shape):
     d1 = L.GemmDesc(); d2 = L.GemmDesc()
     d1.A, d1.B, d1.C, d1.bias, d1.residual = A1.data_ptr(), B1.data_ptr(), C1.data_ptr(), bias.data_ptr(), res.data_ptr()
     d1.lda, d1.ldb, d1.ldc, d1.ldr = K1, K1, N1, N1
-    d1.M, d1.N, d1.K, d1.transA, d1.transB, d1.dtype = M1, N1, K1, 0, 0, L.BF16
+    d1.M, d1.N, d1.K, d1.transA, d1.transB, d1.dtype = M1, N1, K1, 0, 0, _code(dt)
     d1.flags, d1.alpha, d1.Z1, d1.Z2, d1.splitk = L.EPI_BIAS | L.EPI_RESIDUAL, 1.0, 1, 1, 1
     d2.A, d2.B, d2.C = A2.data_ptr(), B2.data_ptr(), slabs.data_ptr()
     d2.lda, d2.ldb, d2.ldc = M2, N2, N2
-    d2.M, d2.N, d2.K, d2.transA, d2.transB, d2.dtype = M2, N2, K2, 1, 1, L.BF16
+    d2.M, d2.N, d2.K, d2.transA, d2.transB, d2.dtype = M2, N2, K2, 1, 1, _code(dt)
     d2.flags, d2.alpha, d2.Z1, d2.Z2, d2.splitk, d2.a_colsum = L.EPI_SLAB, 1.0, 1, 1, sk, cs.data_ptr()
     L.check(L.lib().vmr_gemm2_reduce(C.byref(d1), C.byref(d2), old.data_ptr(), dst.data_ptr(), 3, 96 * 64, 64, 128,
                                       L.stream_ptr()), "vmr_gemm2_reduce")
@@ -260,7 +272,7 @@ def test_gemm2_reduce_exact(dev, shape):
     assert torch.equal(dst, ref)
 
 
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
 def test_gemm_epilogue_splitk_dropout(dev, dt):
     ops = _ops()
     from vmrframe_amd import _lib as L
@@ -273,7 +285,7 @@ def test_gemm_epilogue_splitk_dropout(dev, dt):
     ops.gemm(A, B, out, M, N, K, 0, 0, K, K, N, dtype=L.dtype_code(A), bias=bias, residual=res, aux=aux, ldr=N,
              flags=L.EPI_BIAS | L.EPI_RELU | L.EPI_RESIDUAL | L.EPI_AUX)
     h = torch.relu(A.float() @ B.float().t() + bias)
-    tol = 1.0 if dt == torch.bfloat16 else 1e-4   # bf16 output rounding of values up to ~200
+    tol = 1.0 if dt in DT16 else 1e-4   # bf16 output rounding of values up to ~200
     assert (aux.float() - h).abs().max() <= tol
     assert (out.float() - (h + res.float())).abs().max() <= tol
     acc = torch.ones(M, N, device=dev)
@@ -314,7 +326,7 @@ def test_linear_fwd_bwd(dev):
     _close(gx, rx, 1e-4, "dx"); _close(gW, rW, 1e-4, "dW"); _close(gb, rb, 1e-4, "db"); _close(gr, rr, 1e-5, "dres")
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2), (torch.float16, 3e-2)])
 def test_layernorm_fwd_bwd(dev, dt, tol):
     ops = _ops()
     torch.manual_seed(1)
@@ -335,7 +347,7 @@ def test_layernorm_fwd_bwd(dev, dt, tol):
     _close(gx, rx, tol, "ln dx"); _close(gg, rg, tol, "dgamma"); _close(gb, rb, tol, "dbeta"); _close(gp, rp, tol, "dpos")
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2), (torch.float16, 3e-2)])
 @pytest.mark.parametrize("segs", [[(3, 16), (3, 6)], [(2, 128), (2, 20)], [(1, 1), (2, 3)], [(2, 70)], [(2, 40), (3, 9), (1, 130)]])
 def test_ln_dwconv_fwd_bwd(dev, dt, tol, segs):
     ops = _ops()
@@ -351,7 +363,7 @@ def test_ln_dwconv_fwd_bwd(dev, dt, tol, segs):
     outs, r = [], 0
     for (B, S) in segs:
         n = torch.nn.functional.layer_norm(xr[r:r + B * S].view(B, S, D), (D,), gamma, beta, 1e-6)
-        if dt == torch.bfloat16:
+        if dt in DT16:
             n = n + (n.to(dt).float() - n).detach()    # the kernel stages LN(x) in bf16
         c = torch.nn.functional.conv1d(n.transpose(1, 2), w, padding=3, groups=D).transpose(1, 2)
         outs.append(c.reshape(B * S, D)); r += B * S
@@ -382,7 +394,7 @@ def _ref_dual(qkv, kv, vmask, tmask, B, T, Lq, H):
     return torch.cat(so), torch.cat(xo)
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 4e-2), (torch.float16, 4e-2)])
 @pytest.mark.parametrize("dims", [(3, 16, 6, 32, 4), (2, 128, 20, 256, 4), (2, 128, 20, 1024, 4), (3, 70, 20, 512, 4),
                                   (2, 40, 33, 512, 4), (2, 1, 1, 256, 2)])
 def test_dual_attention_fwd_bwd(dev, dt, tol, dims):
@@ -406,7 +418,7 @@ def test_dual_attention_fwd_bwd(dev, dt, tol, dims):
     _close(gq, rq, tol, "dqkv"); _close(gk, rk, tol, "dkv")
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 4e-2), (torch.float16, 4e-2)])
 @pytest.mark.parametrize("dims", [(5, 12, 64, 4), (64, 9, 512, 2), (37, 5, 512, 4), (70, 3, 256, 1)])
 def test_batch_axis_attention_matches_torch_mha(dev, dt, tol, dims):
     """Against nn.MultiheadAttention itself, fed exactly like the reference
@@ -516,7 +528,7 @@ def test_fused_attention_rejects_unsupported_shapes(dev):
     assert lib.vmr_attention_bwd_supported(64, 20, 20, 1) == 0
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 2e-2)])
 @pytest.mark.parametrize("dims", [(5, 20, 64), (3, 1, 8), (2, 300, 1024)])
 def test_weighted_pool_fwd_bwd(dev, dt, tol, dims):
     """vmr_weighted_pool_fwd/bwd against the reference formulation (models/layers.py:440-453)."""
@@ -539,7 +551,7 @@ def test_weighted_pool_fwd_bwd(dev, dt, tol, dims):
     _close(gx, rx, tol, "dx"); _close(gw, rw, tol, "dw")
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2), (torch.float16, 3e-2)])
 def test_linear_column_slices_and_row_broadcast_residual(dev, dt, tol):
     """Conv1D(cat([a, pooled.expand], -1)) (reference CQConcatenate, layers.py:462-468) as two GEMMs on
     column slices of the one weight, the pooled half broadcast over each clip's rows by the epilogue."""
@@ -557,7 +569,7 @@ def test_linear_column_slices_and_row_broadcast_residual(dev, dt, tol):
     Wr, br = W.detach().clone().requires_grad_(True), bias.detach().clone().requires_grad_(True)
     cat = torch.cat([ar.view(B, T, D), pr[:, None, :].expand(B, T, D)], 2).reshape(B * T, 2 * D)
     Wm = Wr.view(N, 2 * D)
-    if dt == torch.bfloat16:
+    if dt in DT16:
         Wm = Wm + (Wm.to(dt).float() - Wm).detach()
     ref = cat @ Wm.t() + br
     _close(y, ref, tol, "y")
@@ -567,7 +579,7 @@ def test_linear_column_slices_and_row_broadcast_residual(dev, dt, tol):
     _close(ga, ra, tol, "da"); _close(gp, rp, tol, "dpooled"); _close(gW, rW, tol, "dW"); _close(gb, rb, tol, "db")
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2), (torch.float16, 2e-2)])
 @pytest.mark.parametrize("dims", [(8192, 1, 1024), (8192, 4, 1024), (50, 8, 32), (3, 3, 2048), (129, 1, 8)])
 def test_narrow_linear_fwd_bwd(dev, dt, tol, dims):
     """The N <= 8 output heads (match N=4, start/end N=1) on the matrix-vector kernels vs torch."""
@@ -636,7 +648,7 @@ def test_gumbel_softmax_and_match_loss(dev):
     assert (wins - 0.25).abs().max().item() < 0.01
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 2e-2)])
 def test_scale_shift_fwd_bwd(dev, dt, tol):
     ops = _ops()
     torch.manual_seed(31)
@@ -655,7 +667,7 @@ def test_scale_shift_fwd_bwd(dev, dt, tol):
     _close(gx, rx, tol, "dx"); _close(ga, ra, tol, "da"); _close(gb, rb, tol, "db")
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2), (torch.float16, 3e-2)])
 @pytest.mark.parametrize("dims", [(7, 5, 16, 12), (64 * 20, 8, 100, 60), (33, 16, 24, 9)])
 def test_char_cnn_fwd_bwd(dev, dt, tol, dims):
     """csrc/charcnn.hip against the reference formulation of CharacterEmbedding (models/layers.py:51-75):
@@ -675,7 +687,7 @@ def test_char_cnn_fwd_bwd(dev, dt, tol, dims):
     wr = [w.detach().clone().requires_grad_(True) for w in ws]
     br = [b.detach().clone().requires_grad_(True) for b in bs]
     ce = torch.nn.functional.embedding(ids, tr, padding_idx=0)                      # [W, C, CD]
-    if dt == torch.bfloat16:                                                         # operands rounded like the kernel's
+    if dt in DT16:                                                         # operands rounded like the kernel's
         ce = ce + (ce.to(dt).float() - ce).detach()
     x = ce.permute(1 - 1, 2, 1).unsqueeze(2)                                        # [W, CD, 1, C]
     feats = []
@@ -745,13 +757,13 @@ def _ceil8(v):
 
 @pytest.mark.parametrize("dims", [(64, 128, 20, 1024), (3, 70, 9, 256), (2, 128, 32, 512), (2, 1, 1, 256)])
 @pytest.mark.parametrize("orient", [0, 1])
-def test_cq_score_kernel_matches_composed_path(dev, dims, orient):
+@pytest.mark.parametrize("dt", DT16)
+def test_cq_score_kernel_matches_composed_path(dev, dims, orient, dt):
     """csrc/cqscore.hip (score + both softmaxes, one launch) against the three-launch path (batched GEMM +
     vmr_cq_softmax_fwd) and against torch, forward and backward, both orientations of CQAttention."""
     ops = _ops()
     B, Ll, Ls, D = dims
     torch.manual_seed(47)
-    dt = torch.bfloat16
     lng = (torch.randn(B, Ll, D, device=dev) / math.sqrt(D) * 4).to(dt).requires_grad_(True)
     sht = torch.randn(B, Ls, D, device=dev).to(dt).requires_grad_(True)
     term = torch.randn(B, Ls, device=dev, requires_grad=True)
@@ -785,7 +797,8 @@ def test_cq_score_kernel_matches_composed_path(dev, dims, orient):
 
 @pytest.mark.parametrize("dims", [(64, 128, 20, 1024), (3, 70, 9, 256), (2, 128, 32, 512), (2, 33, 1, 256), (5, 128, 17, 768)])
 @pytest.mark.parametrize("orient", [0, 1])
-def test_fused_cq_block_matches_torch(dev, dims, orient):
+@pytest.mark.parametrize("dt", DT16)
+def test_fused_cq_block_matches_torch(dev, dims, orient, dt):
     """csrc/cqapply.hip + cqscore.hip: the whole CQAttention core (trilinear score, both masked softmaxes, c2q,
     q2c = S_.(S_t^T.C), the 4-way concat; reference models/layers.py:417-424) forward and backward against fp32 torch
     autograd on the same bf16 inputs, both directions (context = video / context = query), ragged lengths, and the
@@ -793,7 +806,6 @@ def test_fused_cq_block_matches_torch(dev, dims, orient):
     ops = _ops()
     B, Ll, Ls, D = dims
     torch.manual_seed(53)
-    dt = torch.bfloat16
     lng = (torch.randn(B, Ll, D, device=dev) / math.sqrt(D) * 4).to(dt).requires_grad_(True)     # the score operands
     sht = torch.randn(B, Ls, D, device=dev).to(dt).requires_grad_(True)
     term = torch.randn(B, Ls, device=dev, requires_grad=True)
@@ -836,7 +848,7 @@ def test_fused_cq_block_matches_torch(dev, dims, orient):
         _close(a, b, 6e-2, name + " fused vs composed")   # (composed: bf16 probabilities; fused: fp32)
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_text_embed_matches_torch(dev, dt):
     """ops.text_embed (vmr_word_embedding_fwd/bwd + vmr_char_cnn_fwd/bwd into one [words, ldo] matrix) against the
     reference's WordEmbedding + CharacterEmbedding composed in torch (models/layers.py:28-75), dropout off: the word
@@ -862,15 +874,15 @@ def test_text_embed_matches_torch(dev, dt):
     ce = torch.nn.functional.embedding(cid, table, padding_idx=0).permute(0, 3, 1, 2)          # [B, CD, L, C]
     feats = [torch.relu(torch.nn.functional.conv2d(ce, w, b)).amax(dim=3).permute(0, 2, 1) for w, b in zip(ws, bs)]
     ref_c = torch.cat(feats, 2).reshape(B * Lq, 100)
-    _close(out[:, wd:400], ref_c, 2e-2 if dt == torch.bfloat16 else 1e-4, "char features")
+    _close(out[:, wd:400], ref_c, 2e-2 if dt in DT16 else 1e-4, "char features")
     g = torch.randn(B * Lq, ldo, device=dev).to(dt)
     ga = torch.autograd.grad(out, [unk, table, *ws, *bs], g)
     ref = torch.cat([ref_w, ref_c], 1)
     gb = torch.autograd.grad(ref, [unk, table, *ws, *bs], g[:, :400].float())
     for a, b, n in zip(ga, gb, ["unk", "table"] + [f"w{k}" for k in range(4)] + [f"b{k}" for k in range(4)]):
-        if dt == torch.bfloat16 and n != "unk":
+        if dt in DT16 and n != "unk":
             continue      # (the bf16 CNN stages bf16-rounded rows / weights: covered, with a rounding-aware reference, by test_char_cnn_fwd_bwd)
-        _close(a, b, 1e-2 if dt == torch.bfloat16 else 1e-3, n)
+        _close(a, b, 1e-2 if dt in DT16 else 1e-3, n)
     # dropout on: the counter mask is regenerated identically in the backward (same keep pattern as the forward)
     d = (0.3, 4242, None)
     o2 = ops.text_embed(wid, cid, pad, unk, glove, table, ws, bs, d, ops.NO_DROP, torch.float32, 400)
@@ -904,7 +916,7 @@ def test_product_path_rejects_cpu_tensors(dev):
         ops.soft_ce(torch.zeros(2, 4), torch.zeros(2, 4), torch.zeros(2, 4), torch.zeros(2, 4))
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 2e-2)])
 @pytest.mark.parametrize("dims", [(3, 16, 6), (2, 128, 20), (2, 20, 128), (1, 1, 1), (2, 7, 300), (2, 300, 3)])
 def test_cq_softmax_fwd_bwd(dev, dt, tol, dims):
     """The two masked softmaxes of CQAttention (models/layers.py:419-421) incl. fully masked rows/columns."""
@@ -933,7 +945,7 @@ def test_cq_softmax_fwd_bwd(dev, dt, tol, dims):
         _close(a, b, 5 * tol, n)
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 2e-2)])
 def test_fused_elementwise_programs(dev, dt, tol):
     """cross gate, sigmoid gate, 4-way CQ concat (models/layers.py:374,380,424) vs torch, fwd + bwd."""
     ops = _ops()
@@ -982,7 +994,7 @@ def test_embedding_gather_scatter(dev):
     assert float(a[0].abs().max()) == 0.0       # padding_idx row gets no gradient
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_add_pos_matches_torch(dev, dt):
     """ops.add_pos (FeatureEncoderPredict's positional add, reference layers.py:626-631): forward against torch on the
     fp32 table, backward = the incoming gradient for x and its per-position batch sum for the table."""
@@ -1002,7 +1014,7 @@ def test_add_pos_matches_torch(dev, dt):
     assert torch.allclose(pos.grad, want, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_label_fuse_matches_torch(dev, dt):
     """ops.label_fuse: (fuse + match_score . label_embs^T) * vmask (reference models/SeqPAN.py:80-82), forward and the
     three gradients (residual, probabilities, label embeddings) against torch fp32."""

@@ -236,7 +236,8 @@ class SeqPAN(nn.Module):
         self.droprate = float(_cfg_get(m, "droprate", 0.0))
         self.word_dim, self.char_dim = int(_cfg_get(m, "word_dim", 300)), int(_cfg_get(m, "char_dim", 100))
         cd = _cfg_get(m, "compute_dtype", "bf16")
-        self.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32}[str(cd)]
+        self.compute_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16, "fp32": torch.float32,
+                              "f32": torch.float32}[str(cd)]
         assert self.dim % 8 == 0 and self.dim % self.num_heads == 0
         shapes = seqpan_param_shapes(self.dim, self.vdim, self.vlen, int(configs.num_words), int(configs.num_chars),
                                      self.word_dim, self.char_dim, self.ENC_LAYERS)

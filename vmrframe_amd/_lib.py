@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede the CDLL: loads libamdhip64)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvmr_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2          # == VMR_F32 / VMR_BF16 / VMR_F16
 LN_BWD_MAX_BLOCKS = 8192   # == VMR_LN_BWD_MAX_BLOCKS
 MATCH_LOSS_SCRATCH = 512   # == VMR_MATCH_LOSS_SCRATCH
 
@@ -147,7 +147,8 @@ SIGNATURES = {
     "vmr_debug_set_gemm_p8": [_I],
     "vmr_debug_set_gemm_dma": [_I],
     "vmr_gemm_aux_bits_supported": [_P],
-    "vmr_adamw": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P, _F, _F, _L, _P],
+    "vmr_adamw": [_P, _P, _P, _P, _P, _P, _I, _P, _F, _F, _F, _F, _F, _F, _I, _P, _F, _F, _P, _L, _P],
+    "vmr_loss_scale_update": [_P, _P, _P, _I, _F, _P],
 }
 
 
@@ -184,7 +185,14 @@ def dtype_code(t: torch.Tensor) -> int:
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:
+        return F16
     raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def is_16bit(dtype) -> bool:
+    """the two 16-bit compute dtypes the kernels take (same layouts; v_mfma_f32_16x16x32_{bf16,f16})"""
+    return dtype in (torch.bfloat16, torch.float16)
 
 
 def require_gpu(*tensors):

@@ -33,6 +33,28 @@ from .ban_sampler import sample_proposals
 from .ban_trunk import BANTrunk
 
 
+class _Caches:
+    """The three slices' compute-dtype weight caches behind the one `model._cache` handle optim.FlatAdamW and the trainers
+    use (clear() after an optimizer step that rewrote the masters without touching their version counters; state.reset() at
+    zero_grad)."""
+
+    class _State:
+        def __init__(self, caches):
+            self.caches = caches
+
+        def reset(self):
+            for c in self.caches:
+                c.state.reset()
+
+    def __init__(self, caches):
+        self.caches = list(caches)
+        self.state = _Caches._State(self.caches)
+
+    def clear(self):
+        for c in self.caches:
+            c.clear()
+
+
 class BAN(nn.Module):
     def __init__(self, cfg, pre_train_emb=None, compute_dtype=torch.bfloat16, sync_timing=True):
         super().__init__()
@@ -57,6 +79,8 @@ class BAN(nn.Module):
         object.__setattr__(self, "_trunk", trunk)
         object.__setattr__(self, "_pmap", pmap)
         object.__setattr__(self, "_head", head)
+        object.__setattr__(self, "_cache", _Caches([trunk._cache, pmap._cache, head._cache]))
+        self.compute_dtype = compute_dtype                           # (optim.FlatAdamW keys its 16-bit mirror / loss scale on it)
         self.sampler_thresh = 0.7                                    # models/BAN.py:40
         self.sync_timing = sync_timing
 

@@ -271,7 +271,7 @@ static int cc_wpb(int dtype) {
     v = e ? atoi(e) : 8;
     if (v != 4 && v != 8) v = 8;
   }
-  return dtype == VMR_BF16 ? v : 4;
+  return vmr_dtype_16(dtype) ? v : 4;
 }
 
 extern "C" int vmr_char_cnn_ws_floats(int W, int CD, const int* oc, int dtype) {
@@ -289,7 +289,7 @@ extern "C" int vmr_char_cnn_fwd(const int64_t* char_ids, const float* table, con
   if (W == 0) return 0;
   CharCnnArgs a;
   fill_args(a, char_ids, table, w, b, oc, W, C, CD, drop_p, drop_seed, drop_step);
-  const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = cc_wpb(dtype);
+  const int esz = vmr_dtype_size(dtype), wpb = cc_wpb(dtype);
   const int cp = C <= 8 ? 8 : 16;
   const size_t lds = ((size_t)a.wtot * esz + 15) / 16 * 16 + (size_t)wpb * cp * CD * 4;
   VMR_CHECK(lds <= 160 * 1024, "vmr_char_cnn_fwd: operands do not fit LDS (%zu B)", lds);
@@ -302,9 +302,8 @@ extern "C" int vmr_char_cnn_fwd(const int64_t* char_ids, const float* table, con
     hipLaunchKernelGGL((char_cnn_fwd_kernel<TT, WPBV, CMV>), grid, dim3(1024), lds, (hipStream_t)stream, a, (TT*)out, ldo,  \
                        amax);                                                                                              \
   } while (0)
-  if (dtype == VMR_BF16 && wpb == 8) { if (C <= 8) VMR_CC_FWD(bf16_t, 8, 8); else VMR_CC_FWD(bf16_t, 8, 16); }
-  else if (dtype == VMR_BF16) { if (C <= 8) VMR_CC_FWD(bf16_t, 4, 8); else VMR_CC_FWD(bf16_t, 4, 16); }
-  else { if (C <= 8) VMR_CC_FWD(float, 4, 8); else VMR_CC_FWD(float, 4, 16); }
+  if (vmr_dtype_16(dtype) && wpb == 8) VMR_DISPATCH16(dtype, E, { if (C <= 8) VMR_CC_FWD(E, 8, 8); else VMR_CC_FWD(E, 8, 16); });
+  else VMR_DISPATCH(dtype, T, { if (C <= 8) VMR_CC_FWD(T, 4, 8); else VMR_CC_FWD(T, 4, 16); });
 #undef VMR_CC_FWD
   VMR_LAUNCH_CHECK();
   return 0;
@@ -319,7 +318,7 @@ extern "C" int vmr_char_cnn_bwd(const void* dout, const void* out, int64_t ldo, 
   if (W == 0) return 0;
   CharCnnArgs a;
   fill_args(a, char_ids, table, w, b, oc, W, C, CD, drop_p, drop_seed, drop_step);
-  const int esz = dtype == VMR_BF16 ? 2 : 4, wpb = cc_wpb(dtype), cp = C <= 8 ? 8 : 16;
+  const int esz = vmr_dtype_size(dtype), wpb = cc_wpb(dtype), cp = C <= 8 ? 8 : 16;
   const size_t lds = ((size_t)a.wtot * esz + 15) / 16 * 16 + (size_t)wpb * cp * CD * 4 + (size_t)wpb * a.OT * 8;
   VMR_CHECK(lds <= 160 * 1024, "vmr_char_cnn_bwd: operands do not fit LDS (%zu B)", lds);
   const int nblk = (W + wpb - 1) / wpb;
@@ -331,9 +330,8 @@ extern "C" int vmr_char_cnn_bwd(const void* dout, const void* out, int64_t ldo, 
     hipLaunchKernelGGL((char_cnn_bwd_kernel<TT, WPBV, CPV>), dim3(nblk), dim3(1024), lds, (hipStream_t)stream, a,          \
                        (const TT*)dout, (const TT*)out, ldo, amax, workspace, dtable);                                    \
   } while (0)
-  if (dtype == VMR_BF16 && wpb == 8) { if (cp == 8) VMR_CC_BWD(bf16_t, 8, 8); else VMR_CC_BWD(bf16_t, 8, 16); }
-  else if (dtype == VMR_BF16) { if (cp == 8) VMR_CC_BWD(bf16_t, 4, 8); else VMR_CC_BWD(bf16_t, 4, 16); }
-  else { if (cp == 8) VMR_CC_BWD(float, 4, 8); else VMR_CC_BWD(float, 4, 16); }
+  if (vmr_dtype_16(dtype) && wpb == 8) VMR_DISPATCH16(dtype, E, { if (cp == 8) VMR_CC_BWD(E, 8, 8); else VMR_CC_BWD(E, 8, 16); });
+  else VMR_DISPATCH(dtype, T, { if (cp == 8) VMR_CC_BWD(T, 4, 8); else VMR_CC_BWD(T, 4, 16); });
 #undef VMR_CC_BWD
   VMR_LAUNCH_CHECK();
   CcDst d;

@@ -10,6 +10,9 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;   // IEEE half: the second 16-bit activation type (VMR_F16; BASELINE configs[4] runs BAN in fp16)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -64,9 +67,44 @@ __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }  // v_cvt_
 template <typename T> __device__ __forceinline__ float to_f(T x);
 template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t x) { return (float)x; }
+template <> __device__ __forceinline__ float to_f<f16_t>(f16_t x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f(float x);
 template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return (bf16_t)x; }
+template <> __device__ __forceinline__ f16_t from_f<f16_t>(float x) { return (f16_t)x; }   // v_cvt_f16_f32 (RNE; |x| > 65504 -> inf)
+
+// The 16-bit element types share every data path (LDS images, DMA, fragment registers): kernels carry fragments as raw
+// bf16x8 BIT containers and name the element type only where bits meet arithmetic -- the MFMA and the float conversions.
+template <typename E> struct is_f16 { static constexpr bool value = false; };
+template <> struct is_f16<f16_t> { static constexpr bool value = true; };
+template <typename E> __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {   // 16x16x32, fp32 accumulate
+  if constexpr (is_f16<E>::value)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// low / high 16-bit element of a packed pair, as float
+template <typename E> __device__ __forceinline__ float e16_lo(uint32_t w) {
+  if constexpr (is_f16<E>::value) return (float)__builtin_bit_cast(f16_t, (uint16_t)(w & 0xFFFFu));
+  else return __uint_as_float(w << 16);
+}
+template <typename E> __device__ __forceinline__ float e16_hi(uint32_t w) {
+  if constexpr (is_f16<E>::value) return (float)__builtin_bit_cast(f16_t, (uint16_t)(w >> 16));
+  else return __uint_as_float(w & 0xFFFF0000u);
+}
+// one element of a raw fragment <-> float
+template <typename E> __device__ __forceinline__ float frag_get(const bf16x8& f, int i) {
+  if constexpr (is_f16<E>::value) return (float)__builtin_bit_cast(f16x8, f)[i];
+  else return (float)f[i];
+}
+template <typename E> __device__ __forceinline__ bf16_t bits_from_f(float x) {   // the element's bits, carried as bf16_t
+  if constexpr (is_f16<E>::value) return __builtin_bit_cast(bf16_t, (f16_t)x);
+  else return (bf16_t)x;
+}
+template <typename E> __device__ __forceinline__ float bits_to_f(bf16_t b) {
+  if constexpr (is_f16<E>::value) return (float)__builtin_bit_cast(f16_t, b);
+  else return (float)b;
+}
 
 // 8-element vector load/store of T as floats (16 B for bf16, 2x16 B for f32)
 template <typename T> struct Vec8;
@@ -81,6 +119,19 @@ template <> struct Vec8<bf16_t> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = (bf16_t)v[i];
     *reinterpret_cast<bf16x8*>(p) = x;
+  }
+};
+template <> struct Vec8<f16_t> {
+  static __device__ __forceinline__ void load(const f16_t* p, float (&v)[8]) {
+    f16x8 x = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)x[i];
+  }
+  static __device__ __forceinline__ void store(f16_t* p, const float (&v)[8]) {
+    f16x8 x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (f16_t)v[i];
+    *reinterpret_cast<f16x8*>(p) = x;
   }
 };
 template <> struct Vec8<float> {
@@ -115,6 +166,19 @@ template <> struct Vec4<bf16_t> {
     *reinterpret_cast<bf16x4*>(p) = x;
   }
 };
+template <> struct Vec4<f16_t> {
+  static __device__ __forceinline__ void load(const f16_t* p, float (&v)[4]) {
+    f16x4 x = *reinterpret_cast<const f16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)x[i];
+  }
+  static __device__ __forceinline__ void store(f16_t* p, const float (&v)[4]) {
+    f16x4 x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = (f16_t)v[i];
+    *reinterpret_cast<f16x4*>(p) = x;
+  }
+};
 template <> struct Vec4<float> {
   static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
     f32x4 a = *reinterpret_cast<const f32x4*>(p);
@@ -139,6 +203,17 @@ template <> struct Vec2<bf16_t> {
   static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[2]) {
     bf16x2 x; x[0] = (bf16_t)v[0]; x[1] = (bf16_t)v[1];
     *reinterpret_cast<bf16x2*>(p) = x;
+  }
+};
+template <> struct Vec2<f16_t> {
+  typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+  static __device__ __forceinline__ void load(const f16_t* p, float (&v)[2]) {
+    f16x2 x = *reinterpret_cast<const f16x2*>(p);
+    v[0] = (float)x[0]; v[1] = (float)x[1];
+  }
+  static __device__ __forceinline__ void store(f16_t* p, const float (&v)[2]) {
+    f16x2 x; x[0] = (f16_t)v[0]; x[1] = (f16_t)v[1];
+    *reinterpret_cast<f16x2*>(p) = x;
   }
 };
 template <> struct Vec2<float> {
@@ -211,3 +286,20 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// dtype codes: VMR_F32 = 0, VMR_BF16 = 1, VMR_F16 = 2
+static inline bool vmr_dtype_ok(int dt) { return dt == VMR_F32 || dt == VMR_BF16 || dt == VMR_F16; }
+static inline bool vmr_dtype_16(int dt) { return dt == VMR_BF16 || dt == VMR_F16; }
+static inline int vmr_dtype_size(int dt) { return dt == VMR_F32 ? 4 : 2; }
+// runs `...` with `T` bound to the element type of `dtype` (the caller has checked vmr_dtype_ok)
+#define VMR_DISPATCH(dtype, T, ...)                                  \
+  do {                                                               \
+    if ((dtype) == VMR_BF16) { typedef bf16_t T; __VA_ARGS__; }      \
+    else if ((dtype) == VMR_F16) { typedef f16_t T; __VA_ARGS__; }   \
+    else { typedef float T; __VA_ARGS__; }                           \
+  } while (0)
+#define VMR_DISPATCH16(dtype, T, ...)                                \
+  do {                                                               \
+    if ((dtype) == VMR_F16) { typedef f16_t T; __VA_ARGS__; }        \
+    else { typedef bf16_t T; __VA_ARGS__; }                          \
+  } while (0)

@@ -38,23 +38,28 @@ struct ApplyArgs {
   int Lc, Lq, D, LcP, LqP;
 };
 
-__device__ __forceinline__ void st2(bf16_t* p, float a, float b) { const float v[2] = {a, b}; Vec2<bf16_t>::store(p, v); }
+// E = the 16-bit element type (bf16_t / f16_t).  Pointers are carried as raw 16-bit (bf16_t-typed) bits; E names the
+// conversions only.
+template <typename E> __device__ __forceinline__ void st2(bf16_t* p, float a, float b) {
+  const float v[2] = {a, b};
+  Vec2<E>::store(reinterpret_cast<E*>(p), v);
+}
 __device__ __forceinline__ uint32_t ldw(const bf16_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
-__device__ __forceinline__ float lo16(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float hi16(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+template <typename E> __device__ __forceinline__ float lo16(uint32_t w) { return e16_lo<E>(w); }
+template <typename E> __device__ __forceinline__ float hi16(uint32_t w) { return e16_hi<E>(w); }
 // NB rows of one channel pair, unconditional (row index clamped: a conditional load gets its own s_waitcnt)
 __device__ __forceinline__ void ld_rows(const bf16_t* base, int64_t ld, int r0, int rlast, uint32_t (&v)[NB]) {
 #pragma unroll
   for (int j = 0; j < NB; ++j) v[j] = ldw(base + (int64_t)min(r0 + j, rlast) * ld);
 }
 // the short stream's rows of this thread's channel pair -> registers (rows past `n`: zero)
-template <int SP>
+template <typename E, int SP>
 __device__ __forceinline__ void ld_short(const bf16_t* base, int64_t ld, int n, float (&r)[SP][2]) {
   uint32_t w[SP];
 #pragma unroll
   for (int s = 0; s < SP; ++s) w[s] = ldw(base + (int64_t)min(s, n - 1) * ld);
 #pragma unroll
-  for (int s = 0; s < SP; ++s) { r[s][0] = s < n ? lo16(w[s]) : 0.f; r[s][1] = s < n ? hi16(w[s]) : 0.f; }
+  for (int s = 0; s < SP; ++s) { r[s][0] = s < n ? lo16<E>(w[s]) : 0.f; r[s][1] = s < n ? hi16<E>(w[s]) : 0.f; }
 }
 
 // A row of SP probabilities is loaded ONCE per wave as one coalesced vector load -- lane s holds p[s] -- in the same
@@ -111,7 +116,7 @@ __device__ __forceinline__ void red_get(const float* __restrict__ red, float (&r
 // =====================================================================================================================
 // forward, context = LONG stream (query short): A1[c][q] = S_, A2[c][q] = S_t
 // =====================================================================================================================
-template <int SP>
+template <typename E, int SP>
 __global__ __launch_bounds__(256) void cq_apply_fwd_clong(ApplyArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem);          // [4][SP][DS]
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_clong(ApplyArgs a) {
   const float* A1 = a.A1 + (int64_t)b * a.Lc * SP;
   const float* A2 = a.A2 + (int64_t)b * a.Lc * SP;
   float Qr[SP][2], mid[SP][2];
-  ld_short<SP>(a.Q + (int64_t)b * a.Lq * D + d0, D, a.Lq, Qr);
+  ld_short<E, SP>(a.Q + (int64_t)b * a.Lq * D + d0, D, a.Lq, Qr);
 #pragma unroll
   for (int q = 0; q < SP; ++q) mid[q][0] = mid[q][1] = 0.f;
   for (int c0 = w * NB; c0 < a.Lc; c0 += 4 * NB) {      // mid = S_t^T . C over this wave's rows
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_clong(ApplyArgs a) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const float ok = c0 + j < a.Lc ? 1.f : 0.f;
-      axpy_rows<SP>(p2[j], ok * lo16(cr[j]), ok * hi16(cr[j]), mid);
+      axpy_rows<SP>(p2[j], ok * lo16<E>(cr[j]), ok * hi16<E>(cr[j]), mid);
     }
   }
   red_put<SP>(red, w, mid, lane);
@@ -148,15 +153,15 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_clong(ApplyArgs a) {
     for (int j = 0; j < NB; ++j) {
       const int c = c0 + j;
       float x0, x1, y0, y1;
-      const float c0f = lo16(cr[j]), c1f = hi16(cr[j]);
+      const float c0f = lo16<E>(cr[j]), c1f = hi16<E>(cr[j]);
       dot_rows<SP>(p1[j], Qr, x0, x1);                  // c2q
       dot_rows<SP>(p1[j], mid, y0, y1);                 // q2c
       if (c < a.Lc) {
         bf16_t* o = ob + (int64_t)c * 4 * D;
         *reinterpret_cast<uint32_t*>(o) = cr[j];
-        st2(o + D, x0, x1);
-        st2(o + 2 * D, c0f * x0, c1f * x1);
-        st2(o + 3 * D, c0f * y0, c1f * y1);
+        st2<E>(o + D, x0, x1);
+        st2<E>(o + 2 * D, c0f * x0, c1f * x1);
+        st2<E>(o + 3 * D, c0f * y0, c1f * y1);
       }
     }
   }
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_clong(ApplyArgs a) {
 // =====================================================================================================================
 // forward, context = SHORT stream (query long): A1[q][c] = S_[c,q], A2[q][c] = S_t[c,q]
 // =====================================================================================================================
-template <int SP>
+template <typename E, int SP>
 __global__ __launch_bounds__(256) void cq_apply_fwd_cshort(ApplyArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem);          // [2][4][SP][DS]
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_cshort(ApplyArgs a) {
   const float* A1 = a.A1 + (int64_t)b * a.Lq * SP;
   const float* A2 = a.A2 + (int64_t)b * a.Lq * SP;
   float Cr[SP][2], a1[SP][2], a2[SP][2];
-  ld_short<SP>(Cb, D, a.Lc, Cr);
+  ld_short<E, SP>(Cb, D, a.Lc, Cr);
 #pragma unroll
   for (int c = 0; c < SP; ++c) a1[c][0] = a1[c][1] = a2[c][0] = a2[c][1] = 0.f;
   for (int q0 = w * NB; q0 < a.Lq; q0 += 4 * NB) {
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_cshort(ApplyArgs a) {
       const float ok = q0 + j < a.Lq ? 1.f : 0.f;
       float m0, m1;
       dot_rows<SP>(p2[j], Cr, m0, m1);                                  // mid[q] = sum_c S_t[c,q] C[c]
-      axpy_rows<SP>(p1[j], ok * lo16(qr[j]), ok * hi16(qr[j]), a1);     // c2q[c] += S_[c,q] Q[q]
+      axpy_rows<SP>(p1[j], ok * lo16<E>(qr[j]), ok * hi16<E>(qr[j]), a1);     // c2q[c] += S_[c,q] Q[q]
       axpy_rows<SP>(p1[j], ok * m0, ok * m1, a2);                       // q2c[c] += S_[c,q] mid[q]
     }
   }
@@ -205,9 +210,9 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_cshort(ApplyArgs a) {
     red_row<SP>(red + 4 * SP * DS, c, lane, y0, y1);
     bf16_t* o = ob + (int64_t)c * 4 * D;
     *reinterpret_cast<uint32_t*>(o) = cw;
-    st2(o + D, x0, x1);
-    st2(o + 2 * D, lo16(cw) * x0, hi16(cw) * x1);
-    st2(o + 3 * D, lo16(cw) * y0, hi16(cw) * y1);
+    st2<E>(o + D, x0, x1);
+    st2<E>(o + 2 * D, lo16<E>(cw) * x0, hi16<E>(cw) * x1);
+    st2<E>(o + 3 * D, lo16<E>(cw) * y0, hi16<E>(cw) * y1);
   }
 }
 
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_cshort(ApplyArgs a) {
 // =====================================================================================================================
 __device__ __forceinline__ bf16x8 ldfrag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
+template <typename E>
 __device__ __forceinline__ void mfma_phase(const ApplyArgs& a, int b, int slice, const bf16_t* midI, const bf16_t* dmidI, int lane,
                                            int w) {
   const int D = a.D, mt_n = a.LqP / 16, nt_n = a.LcP / 16;
@@ -245,13 +251,13 @@ __device__ __forceinline__ void mfma_phase(const ApplyArgs& a, int b, int slice,
       bf16x8 dc2q, dq2c;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float cf = (float)c8[e];
-        dc2q[e] = (bf16_t)((float)g2[e] + (float)g3[e] * cf);
-        dq2c[e] = (bf16_t)((float)g4[e] * cf);
+        const float cf = frag_get<E>(c8, e);
+        dc2q[e] = bits_from_f<E>(frag_get<E>(g2, e) + frag_get<E>(g3, e) * cf);
+        dq2c[e] = bits_from_f<E>(frag_get<E>(g4, e) * cf);
       }
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, dc2q, acc1, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm, dq2c, acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd, c8, acc2, 0, 0, 0);
+      acc1 = mfma16<E>(fq, dc2q, acc1);
+      acc1 = mfma16<E>(fm, dq2c, acc1);
+      acc2 = mfma16<E>(fd, c8, acc2);
     }
     const int q0 = mt * 16 + (lane >> 4) * 4;
     float* p1 = pb + (int64_t)crow * a.LqP + q0;
@@ -263,7 +269,7 @@ __device__ __forceinline__ void mfma_phase(const ApplyArgs& a, int b, int slice,
 // =====================================================================================================================
 // backward, context = LONG stream
 // =====================================================================================================================
-template <int SP>
+template <typename E, int SP>
 __global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem);                   // [2][4][SP][DS]
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
   const float* A1 = a.A1 + (int64_t)b * a.Lc * SP;
   const float* A2 = a.A2 + (int64_t)b * a.Lc * SP;
   float Qr[SP][2], mid[SP][2];
-  ld_short<SP>(a.Q + (int64_t)b * a.Lq * D + d0, D, a.Lq, Qr);
+  ld_short<E, SP>(a.Q + (int64_t)b * a.Lq * D + d0, D, a.Lq, Qr);
   for (int i = threadIdx.x; i < 2 * a.LqP * IMG_LD; i += 256) midI[i] = (bf16_t)0.f;
 #pragma unroll
   for (int q = 0; q < SP; ++q) mid[q][0] = mid[q][1] = 0.f;
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const float ok = c0 + j < a.Lc ? 1.f : 0.f;
-      axpy_rows<SP>(p2[j], ok * lo16(cr[j]), ok * hi16(cr[j]), mid);
+      axpy_rows<SP>(p2[j], ok * lo16<E>(cr[j]), ok * hi16<E>(cr[j]), mid);
     }
   }
   red_put<SP>(red, w, mid, lane);
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
   if (w == 0) {
 #pragma unroll
     for (int q = 0; q < SP; ++q)
-      if (q < a.Lq) st2(midI + q * IMG_LD + 2 * lane, mid[q][0], mid[q][1]);
+      if (q < a.Lq) st2<E>(midI + q * IMG_LD + 2 * lane, mid[q][0], mid[q][1]);
   }
   __syncthreads();                                      // everyone has read the mid partials: the slots are re-used below
   // ---- dQ = S_^T . dc2q, dmid = S_^T . dq2c over this wave's rows
@@ -315,8 +321,8 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const float ok = c0 + j < a.Lc ? 1.f : 0.f;
-      axpy_rows<SP>(p1[j], ok * (lo16(r2[j]) + lo16(r3[j]) * lo16(cr[j])), ok * (hi16(r2[j]) + hi16(r3[j]) * hi16(cr[j])), dQa);
-      axpy_rows<SP>(p1[j], ok * lo16(r4[j]) * lo16(cr[j]), ok * hi16(r4[j]) * hi16(cr[j]), dMa);
+      axpy_rows<SP>(p1[j], ok * (lo16<E>(r2[j]) + lo16<E>(r3[j]) * lo16<E>(cr[j])), ok * (hi16<E>(r2[j]) + hi16<E>(r3[j]) * hi16<E>(cr[j])), dQa);
+      axpy_rows<SP>(p1[j], ok * lo16<E>(r4[j]) * lo16<E>(cr[j]), ok * hi16<E>(r4[j]) * hi16<E>(cr[j]), dMa);
     }
   }
   red_put<SP>(red, w, dQa, lane);
@@ -326,13 +332,13 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
   for (int q = w; q < a.Lq; q += 4) {
     float x0, x1;
     red_row<SP>(red, q, lane, x0, x1);
-    st2(dQb + (int64_t)q * D, x0, x1);
+    st2<E>(dQb + (int64_t)q * D, x0, x1);
   }
   red_get<SP>(red + 4 * SP * DS, dMa, lane);
   if (w == 0) {
 #pragma unroll
     for (int q = 0; q < SP; ++q)
-      if (q < a.Lq) st2(dmidI + q * IMG_LD + 2 * lane, dMa[q][0], dMa[q][1]);
+      if (q < a.Lq) st2<E>(dmidI + q * IMG_LD + 2 * lane, dMa[q][0], dMa[q][1]);
   }
   // ---- dC = g1 + g3*c2q + g4*q2c + S_t . dmid
   bf16_t* dCb = a.dC + (int64_t)b * a.Lc * D + d0;
@@ -352,18 +358,18 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
       dot_rows<SP>(p1[j], mid, y0, y1);
       dot_rows<SP>(p2[j], dMa, z0, z1);
       if (c < a.Lc)
-        st2(dCb + (int64_t)c * D, lo16(r1[j]) + lo16(r3[j]) * x0 + lo16(r4[j]) * y0 + z0,
-            hi16(r1[j]) + hi16(r3[j]) * x1 + hi16(r4[j]) * y1 + z1);
+        st2<E>(dCb + (int64_t)c * D, lo16<E>(r1[j]) + lo16<E>(r3[j]) * x0 + lo16<E>(r4[j]) * y0 + z0,
+            hi16<E>(r1[j]) + hi16<E>(r3[j]) * x1 + hi16<E>(r4[j]) * y1 + z1);
     }
   }
   __syncthreads();                                      // the dmid image is complete
-  mfma_phase(a, b, slice, midI, dmidI, lane, w);
+  mfma_phase<E>(a, b, slice, midI, dmidI, lane, w);
 }
 
 // =====================================================================================================================
 // backward, context = SHORT stream
 // =====================================================================================================================
-template <int SP>
+template <typename E, int SP>
 __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem);                   // [4][SP][DS], used for three reductions in turn
@@ -377,8 +383,8 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
   const float* A1 = a.A1 + (int64_t)b * a.Lq * SP;
   const float* A2 = a.A2 + (int64_t)b * a.Lq * SP;
   for (int r = a.Lq + w; r < a.LqP; r += 4) {           // image rows past Lq feed padded tile rows: zero
-    st2(midI + r * IMG_LD + 2 * lane, 0.f, 0.f);
-    st2(dmidI + r * IMG_LD + 2 * lane, 0.f, 0.f);
+    st2<E>(midI + r * IMG_LD + 2 * lane, 0.f, 0.f);
+    st2<E>(dmidI + r * IMG_LD + 2 * lane, 0.f, 0.f);
   }
   __syncthreads();
   bf16_t* dQb = a.dQ + (int64_t)b * a.Lq * D + d0;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
   float xr[RW][2], yr[RW][2], zr[RW][2];
   {   // pass A: forward quantities (c2q, q2c accumulators; the mid image)
     float Cr[SP][2], a1[SP][2], a2[SP][2];
-    ld_short<SP>(Cb, D, a.Lc, Cr);
+    ld_short<E, SP>(Cb, D, a.Lc, Cr);
 #pragma unroll
     for (int c = 0; c < SP; ++c) a1[c][0] = a1[c][1] = a2[c][0] = a2[c][1] = 0.f;
     for (int q0 = w * NB; q0 < a.Lq; q0 += 4 * NB) {
@@ -400,8 +406,8 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
         const float ok = q0 + j < a.Lq ? 1.f : 0.f;
         float m0, m1;
         dot_rows<SP>(p2[j], Cr, m0, m1);
-        if (q0 + j < a.Lq) st2(midI + (q0 + j) * IMG_LD + 2 * lane, m0, m1);
-        axpy_rows<SP>(p1[j], ok * lo16(qr[j]), ok * hi16(qr[j]), a1);
+        if (q0 + j < a.Lq) st2<E>(midI + (q0 + j) * IMG_LD + 2 * lane, m0, m1);
+        axpy_rows<SP>(p1[j], ok * lo16<E>(qr[j]), ok * hi16<E>(qr[j]), a1);
         axpy_rows<SP>(p1[j], ok * m0, ok * m1, a2);
       }
     }
@@ -424,8 +430,8 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
       const bf16_t* gr = gb + (int64_t)cc * 4 * D;
       const uint32_t cv = ldw(Cb + (int64_t)cc * D), g2 = ldw(gr + D), g3 = ldw(gr + 2 * D), g4 = ldw(gr + 3 * D);
       const float ok = c < a.Lc ? 1.f : 0.f;
-      X1[c][0] = ok * (lo16(g2) + lo16(g3) * lo16(cv)); X1[c][1] = ok * (hi16(g2) + hi16(g3) * hi16(cv));
-      X2[c][0] = ok * (lo16(g4) * lo16(cv)); X2[c][1] = ok * (hi16(g4) * hi16(cv));
+      X1[c][0] = ok * (lo16<E>(g2) + lo16<E>(g3) * lo16<E>(cv)); X1[c][1] = ok * (hi16<E>(g2) + hi16<E>(g3) * hi16<E>(cv));
+      X2[c][0] = ok * (lo16<E>(g4) * lo16<E>(cv)); X2[c][1] = ok * (hi16<E>(g4) * hi16<E>(cv));
       a3[c][0] = a3[c][1] = 0.f;
     }
     for (int q0 = w * NB; q0 < a.Lq; q0 += 4 * NB) {
@@ -440,8 +446,8 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
         dot_rows<SP>(p1[j], X1, x0, x1);                 // dQ[q] = sum_c S_[c,q] dc2q[c]
         dot_rows<SP>(p1[j], X2, m0, m1);                 // dmid[q] = sum_c S_[c,q] dq2c[c]
         if (q < a.Lq) {
-          st2(dQb + (int64_t)q * D, x0, x1);
-          st2(dmidI + q * IMG_LD + 2 * lane, m0, m1);
+          st2<E>(dQb + (int64_t)q * D, x0, x1);
+          st2<E>(dmidI + q * IMG_LD + 2 * lane, m0, m1);
         }
         axpy_rows<SP>(p2[j], ok * m0, ok * m1, a3);      // dC_mid[c] += S_t[c,q] dmid[q]
       }
@@ -458,11 +464,11 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
     if (c < a.Lc) {
       const bf16_t* gr = gb + (int64_t)c * 4 * D;
       const uint32_t g1 = ldw(gr), g3 = ldw(gr + 2 * D), g4 = ldw(gr + 3 * D);
-      st2(dCb + (int64_t)c * D, lo16(g1) + lo16(g3) * xr[k][0] + lo16(g4) * yr[k][0] + zr[k][0],
-          hi16(g1) + hi16(g3) * xr[k][1] + hi16(g4) * yr[k][1] + zr[k][1]);
+      st2<E>(dCb + (int64_t)c * D, lo16<E>(g1) + lo16<E>(g3) * xr[k][0] + lo16<E>(g4) * yr[k][0] + zr[k][0],
+          hi16<E>(g1) + hi16<E>(g3) * xr[k][1] + hi16<E>(g4) * yr[k][1] + zr[k][1]);
     }
   }
-  mfma_phase(a, b, slice, midI, dmidI, lane, w);
+  mfma_phase<E>(a, b, slice, midI, dmidI, lane, w);
 }
 
 // =====================================================================================================================
@@ -579,7 +585,7 @@ struct ScoreBwdArgs {
   int Ll, Ls, D;
 };
 
-template <int SP>
+template <typename E, int SP>
 __global__ __launch_bounds__(256) void cq_score_bwd_kernel(ScoreBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem);          // [4][SP][DS]
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(256) void cq_score_bwd_kernel(ScoreBwdArgs a) {
   const bf16_t* Lb = a.lng + (int64_t)b * a.Ll * D + d0;
   bf16_t* dLb = a.dlng + (int64_t)b * a.Ll * D + d0;
   float Sreg[SP][2], acc[SP][2];
-  ld_short<SP>(a.sht + (int64_t)b * a.Ls * D + d0, D, a.Ls, Sreg);
+  ld_short<E, SP>(a.sht + (int64_t)b * a.Ls * D + d0, D, a.Ls, Sreg);
 #pragma unroll
   for (int s = 0; s < SP; ++s) acc[s][0] = acc[s][1] = 0.f;
   for (int r0 = w * NB; r0 < a.Ll; r0 += 4 * NB) {
@@ -603,8 +609,8 @@ __global__ __launch_bounds__(256) void cq_score_bwd_kernel(ScoreBwdArgs a) {
       const float ok = r < a.Ll ? 1.f : 0.f;
       float x0, x1;
       dot_rows<SP>(pd[j], Sreg, x0, x1);                // d(long)[r] = sum_s dS[r,s] short[s]
-      if (r < a.Ll) st2(dLb + (int64_t)r * D, x0, x1);
-      axpy_rows<SP>(pd[j], ok * lo16(lr[j]), ok * hi16(lr[j]), acc);   // d(short)[s] += dS[r,s] long[r]
+      if (r < a.Ll) st2<E>(dLb + (int64_t)r * D, x0, x1);
+      axpy_rows<SP>(pd[j], ok * lo16<E>(lr[j]), ok * hi16<E>(lr[j]), acc);   // d(short)[s] += dS[r,s] long[r]
     }
   }
   red_put<SP>(red, w, acc, lane);
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(256) void cq_score_bwd_kernel(ScoreBwdArgs a) {
   for (int s = w; s < a.Ls; s += 4) {
     float x0, x1;
     red_row<SP>(red, s, lane, x0, x1);
-    st2(dSh + (int64_t)s * D, x0, x1);
+    st2<E>(dSh + (int64_t)s * D, x0, x1);
   }
 }
 
@@ -630,18 +636,21 @@ int set_lds(const void* fn, size_t bytes, const char* what) {
 
 // the fused apply kernels take: bf16, D a multiple of 128, one stream <= 32 rows, the other <= 256
 extern "C" int vmr_cq_apply_supported(int Lc, int Lq, int D, int dtype) {
-  if (dtype != VMR_BF16 || D % DS != 0 || Lc < 1 || Lq < 1) return 0;
+  if (!vmr_dtype_16(dtype) || D % DS != 0 || Lc < 1 || Lq < 1) return 0;
   const int shorter = Lc < Lq ? Lc : Lq, longer = Lc < Lq ? Lq : Lc;
   return shorter <= 32 && longer <= 256;
 }
 
-#define CQ_DISPATCH_SP(SPV, KERNEL, ...)                                                              \
+#define CQ_DISPATCH_SP1(E, SPV, KERNEL, ...)                                                          \
   switch (SPV) {                                                                                       \
-    case 8: { auto fn = KERNEL<8>; __VA_ARGS__ } break;                                                \
-    case 16: { auto fn = KERNEL<16>; __VA_ARGS__ } break;                                              \
-    case 24: { auto fn = KERNEL<24>; __VA_ARGS__ } break;                                              \
-    default: { auto fn = KERNEL<32>; __VA_ARGS__ } break;                                              \
+    case 8: { auto fn = KERNEL<E, 8>; __VA_ARGS__ } break;                                             \
+    case 16: { auto fn = KERNEL<E, 16>; __VA_ARGS__ } break;                                           \
+    case 24: { auto fn = KERNEL<E, 24>; __VA_ARGS__ } break;                                           \
+    default: { auto fn = KERNEL<E, 32>; __VA_ARGS__ } break;                                           \
   }
+#define CQ_DISPATCH_SP(SPV, KERNEL, ...)                                                              \
+  if (dtype == VMR_F16) { CQ_DISPATCH_SP1(f16_t, SPV, KERNEL, __VA_ARGS__) }                           \
+  else { CQ_DISPATCH_SP1(bf16_t, SPV, KERNEL, __VA_ARGS__) }
 
 extern "C" int vmr_cq_apply_fwd(const void* ctx, const void* qry, const float* S_lm, const float* St_lm, void* out, int B, int Lc,
                                 int Lq, int D, int dtype, void* stream) {
@@ -729,7 +738,7 @@ extern "C" int vmr_cq_softmax_bwd_parts(float* parts, const float* S_lm, const f
 extern "C" int vmr_cq_score_bwd(const void* lng, const void* sht, const float* dS_lm, void* dlng, void* dsht, int B, int Ll, int Ls,
                                 int D, int dtype, void* stream) {
   VMR_CHECK(lng && sht && dS_lm && dlng && dsht, "vmr_cq_score_bwd: null pointer");
-  VMR_CHECK(dtype == VMR_BF16 && D % DS == 0 && Ls >= 1 && Ls <= 32 && Ll >= 1 && ((uintptr_t)dS_lm & 15) == 0,
+  VMR_CHECK(vmr_dtype_16(dtype) && D % DS == 0 && Ls >= 1 && Ls <= 32 && Ll >= 1 && ((uintptr_t)dS_lm & 15) == 0,
             "vmr_cq_score_bwd: unsupported shape Ll=%d Ls=%d D=%d", Ll, Ls, D);
   if (B == 0) return 0;
   ScoreBwdArgs a;

@@ -31,7 +31,8 @@ struct CqArgs {
 // pulls its 320 KB through ONE CU at the per-CU HBM fetch rate, ~25 GB/s: 64 active CUs = 15 us for 21 MB): the softmax
 // over the long index then leaves exp(s - local max) in Pv32 and the local (max, sum) pairs in cstat; cq_colnorm_kernel
 // rescales.
-template <int NKS, int NW>
+// E = the 16-bit element type (bf16_t / f16_t): CqArgs carries its pointers as raw 16-bit (bf16_t-typed) bits
+template <typename E, int NKS, int NW>
 __global__ __launch_bounds__(NW * 64) void cq_score_kernel(CqArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int D = NKS * 32, RB = D * 2, CPRW = RB / 16;  // bytes / 16-B chunks per short-operand row
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(NW * 64) void cq_score_kernel(CqArgs a) {
         const int row = j * 16 + (lane & 15);
         const int c = ks * 4 + (lane >> 4);
         const bf16x8 sf = *reinterpret_cast<const bf16x8*>(Ss + row * RB + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4));
-        st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, fr[u], st[j], 0, 0, 0);   // C[t][v]
+        st[j] = mfma16<E>(sf, fr[u], st[j]);   // C[t][v]
       }
       if (ks + RG < NKS) fr[u] = *reinterpret_cast<const bf16x8*>(lrow + (ks + RG) * 32);
     }
@@ -191,15 +192,15 @@ __global__ __launch_bounds__(NW * 64) void cq_score_kernel(CqArgs a) {
     if (!a.Srow) continue;
     if (a.orient == 0) {
       if (t0 < a.ldP) {
-        Vec4<bf16_t>::store(a.Srow + ((int64_t)b * a.Ll + v) * a.ldP + t0, pt);
-        Vec4<bf16_t>::store(a.Scol + ((int64_t)b * a.Ll + v) * a.ldP + t0, pv);
+        Vec4<E>::store(reinterpret_cast<E*>(a.Srow) + ((int64_t)b * a.Ll + v) * a.ldP + t0, pt);
+        Vec4<E>::store(reinterpret_cast<E*>(a.Scol) + ((int64_t)b * a.Ll + v) * a.ldP + t0, pv);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (t0 + r < a.Ls) {
-          a.Srow[((int64_t)b * a.Ls + t0 + r) * a.ldP + v] = (bf16_t)pv[r];
-          a.Scol[((int64_t)b * a.Ls + t0 + r) * a.ldP + v] = (bf16_t)pt[r];
+          a.Srow[((int64_t)b * a.Ls + t0 + r) * a.ldP + v] = bits_from_f<E>(pv[r]);
+          a.Scol[((int64_t)b * a.Ls + t0 + r) * a.ldP + v] = bits_from_f<E>(pt[r]);
         }
     }
   }
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void cq_pad_zero_kernel(bf16_t* __restrict__ A
 }  // namespace
 
 extern "C" int vmr_cq_score_supported(int Ll, int Ls, int D, int dtype) {
-  return dtype == VMR_BF16 && Ll >= 1 && Ll <= 128 && Ls >= 1 && Ls <= 32 && D % 256 == 0 && D >= 256 && D <= 2048;
+  return vmr_dtype_16(dtype) && Ll >= 1 && Ll <= 128 && Ls >= 1 && Ls <= 32 && D % 256 == 0 && D >= 256 && D <= 2048;
 }
 
 static int g_split = -1;   // VMR_CQ_SPLIT / vmr_debug_set_cq_split
@@ -277,10 +278,12 @@ extern "C" int vmr_cq_score_fwd_ws(const void* lng, const void* sht, const float
   if (smem > 64 * 1024) {
     static thread_local bool done = false;
     if (!done) {
-      for (const void* f : {(const void*)cq_score_kernel<32, 8>, (const void*)cq_score_kernel<40, 8>, (const void*)cq_score_kernel<48, 8>,
-                            (const void*)cq_score_kernel<56, 8>, (const void*)cq_score_kernel<64, 8>, (const void*)cq_score_kernel<32, 2>,
-                            (const void*)cq_score_kernel<40, 2>, (const void*)cq_score_kernel<48, 2>, (const void*)cq_score_kernel<56, 2>,
-                            (const void*)cq_score_kernel<64, 2>}) {
+#define VMR_CQ_FNS(E) (const void*)cq_score_kernel<E, 32, 8>, (const void*)cq_score_kernel<E, 40, 8>, (const void*)cq_score_kernel<E, 48, 8>, \
+                      (const void*)cq_score_kernel<E, 56, 8>, (const void*)cq_score_kernel<E, 64, 8>, (const void*)cq_score_kernel<E, 32, 2>, \
+                      (const void*)cq_score_kernel<E, 40, 2>, (const void*)cq_score_kernel<E, 48, 2>, (const void*)cq_score_kernel<E, 56, 2>, \
+                      (const void*)cq_score_kernel<E, 64, 2>
+      for (const void* f : {VMR_CQ_FNS(bf16_t), VMR_CQ_FNS(f16_t)}) {
+#undef VMR_CQ_FNS
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return vmr_fail(-5, "vmr_cq_score_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
       }
@@ -290,7 +293,7 @@ extern "C" int vmr_cq_score_fwd_ws(const void* lng, const void* sht, const float
   if (split) {
     const int nsplit = (Ll + 31) / 32;
     switch (D / 256) {
-#define VMR_CQ_CASE(n) case n: hipLaunchKernelGGL((cq_score_kernel<n * 8, 2>), dim3(B, nsplit), dim3(128), smem, (hipStream_t)stream, a); break
+#define VMR_CQ_CASE(n) case n: VMR_DISPATCH16(dtype, E, hipLaunchKernelGGL((cq_score_kernel<E, n * 8, 2>), dim3(B, nsplit), dim3(128), smem, (hipStream_t)stream, a)); break
       VMR_CQ_CASE(1); VMR_CQ_CASE(2); VMR_CQ_CASE(3); VMR_CQ_CASE(4); VMR_CQ_CASE(5); VMR_CQ_CASE(6); VMR_CQ_CASE(7); VMR_CQ_CASE(8);
 #undef VMR_CQ_CASE
       default: return vmr_fail(-2, "vmr_cq_score_fwd: unsupported D %d", D);
@@ -301,7 +304,7 @@ extern "C" int vmr_cq_score_fwd_ws(const void* lng, const void* sht, const float
     return 0;
   }
   switch (D / 256) {
-#define VMR_CQ_CASE(n) case n: hipLaunchKernelGGL((cq_score_kernel<n * 8, 8>), dim3(B), dim3(512), smem, (hipStream_t)stream, a); break
+#define VMR_CQ_CASE(n) case n: VMR_DISPATCH16(dtype, E, hipLaunchKernelGGL((cq_score_kernel<E, n * 8, 8>), dim3(B), dim3(512), smem, (hipStream_t)stream, a)); break
     VMR_CQ_CASE(1); VMR_CQ_CASE(2); VMR_CQ_CASE(3); VMR_CQ_CASE(4); VMR_CQ_CASE(5); VMR_CQ_CASE(6); VMR_CQ_CASE(7); VMR_CQ_CASE(8);
 #undef VMR_CQ_CASE
     default: return vmr_fail(-2, "vmr_cq_score_fwd: unsupported D %d", D);

@@ -168,8 +168,7 @@ extern "C" int vmr_eltwise(int op, const void* a, const void* b, const void* c, 
   if (rows == 0) return 0;
   const int64_t total = rows * (D / 8);
   dim3 grid((unsigned)min((int64_t)8192, (total + 255) / 256));
-  if (dtype == VMR_BF16) launch_elt<bf16_t>(op, grid, (hipStream_t)stream, a, b, c, d, e, rowmask, o0, o1, o2, o3, rows, D);
-  else launch_elt<float>(op, grid, (hipStream_t)stream, a, b, c, d, e, rowmask, o0, o1, o2, o3, rows, D);
+  VMR_DISPATCH(dtype, T, launch_elt<T>(op, grid, (hipStream_t)stream, a, b, c, d, e, rowmask, o0, o1, o2, o3, rows, D));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -199,16 +198,12 @@ extern "C" int vmr_splitk_reduce_cast(const float* slab, int nsplit, int64_t row
                                reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(addend)) & 7) == 0 &&
                 (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0,
             "vmr_splitk_reduce_cast: cols %% 4 == 0, 16-byte aligned slabs / bias, 8-byte aligned out / addend");
-  VMR_CHECK(dtype == VMR_BF16 || dtype == VMR_F32, "vmr_splitk_reduce_cast: bad dtype");
+  VMR_CHECK(vmr_dtype_ok(dtype), "vmr_splitk_reduce_cast: bad dtype");
   const int64_t n4 = rows * cols / 4;
   if (n4 == 0) return 0;
   const dim3 grid((unsigned)min((int64_t)4096, (n4 + 255) / 256));
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(splitk_reduce_cast_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, slab, nsplit, n4, cols / 4, bias,
-                       (const bf16_t*)addend, (bf16_t*)out);
-  else
-    hipLaunchKernelGGL(splitk_reduce_cast_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, slab, nsplit, n4, cols / 4, bias,
-                       (const float*)addend, (float*)out);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(splitk_reduce_cast_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, slab, nsplit, n4, cols / 4, bias,
+                       (const T*)addend, (T*)out));
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -81,8 +81,6 @@ __device__ __forceinline__ int perm_row128(int rho) {   // LDS row of the [128][
 
 // residual values of the lane, as loaded: 8 bytes per (i, j) quad; with PERM quads 2k and 2k+1 came as one 16-byte load
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
-__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
 
 __device__ __forceinline__ TileCoord tile_coord(const vmr_gemm_t& g, int tiles_m, int tiles_n) {
   return tile_coord(g, tiles_m, tiles_n, blockIdx.x, blockIdx.z, gridDim.z);
@@ -349,8 +347,8 @@ template <int BK> struct Geom16 {
   static constexpr int SMEM = STAGES_BYTES > CST_BYTES ? STAGES_BYTES : CST_BYTES;
 };
 
-template <bool TA, bool TB, bool ALIGNED, int BK>
-__global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_bf16_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
+template <typename E, bool TA, bool TB, bool ALIGNED, int BK>
+__global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_e16_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int OPB = Geom16<BK>::OP_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -404,7 +402,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_bf16_kernel(vmr_
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<E>(fa[i], fb[j], acc[i][j]);
     }
     if (more) {
       store_operand<!TA, BK>(nxt, ra);
@@ -412,12 +410,10 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_bf16_kernel(vmr_
     }
     __syncthreads();
   }
-  epilogue<bf16_t, ALIGNED>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
-                            (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM))
-                                ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
-                                : reinterpret_cast<bf16_t*>(g.C) + coff,
-                            reinterpret_cast<const bf16_t*>(g.residual) + coff,
-                            reinterpret_cast<bf16_t*>(g.aux) + coff);
+  epilogue<E, ALIGNED>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
+                       (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM)) ? reinterpret_cast<E*>(reinterpret_cast<float*>(g.C) + coff)
+                                                                     : reinterpret_cast<E*>(g.C) + coff,
+                       reinterpret_cast<const E*>(g.residual) + coff, reinterpret_cast<E*>(g.aux) + coff);
 }
 
 // ------------------------------------------------------- bf16 LDS-DMA kernel
@@ -483,10 +479,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // bias / residual / aux / C move as 8-byte accesses straight from the accumulators -- no LDS staging,
 // no workgroup barrier (a wave's stores overlap the other waves' and the co-resident workgroup's
 // MFMAs), and one dropout hash serves exactly the lane's 4 elements.
-template <int MT, bool PERM>
+template <typename E, int MT, bool PERM>
 __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4 (&acc)[MT][4], int wm, int wn, int lane,
-                                                int m0, int n0, int zb, bf16_t* __restrict__ C,
-                                                const u32x2 (&rres)[MT][4], bf16_t* __restrict__ Aux) {
+                                                int m0, int n0, int zb, E* __restrict__ C,
+                                                const u32x2 (&rres)[MT][4], E* __restrict__ Aux) {
   const int flags = g.flags;
   const int rbase = m0 + wm * (MT * 16) + (lane & 15);
   const int q = lane >> 4;
@@ -513,7 +509,7 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int gn = cw + quad_col<PERM>(j, q);
-      const float r4[4] = {bf16_lo(rres[i][j][0]), bf16_hi(rres[i][j][0]), bf16_lo(rres[i][j][1]), bf16_hi(rres[i][j][1])};
+      const float r4[4] = {e16_lo<E>(rres[i][j][0]), e16_hi<E>(rres[i][j][0]), e16_lo<E>(rres[i][j][1]), e16_hi<E>(rres[i][j][1])};
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -554,7 +550,7 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
         const int gn = cw + quad_col<PERM>(2 * k, q);
         const float o8[8] = {out[2 * k][0], out[2 * k][1], out[2 * k][2], out[2 * k][3],
                              out[2 * k + 1][0], out[2 * k + 1][1], out[2 * k + 1][2], out[2 * k + 1][3]};
-        Vec8<bf16_t>::store(C + (int64_t)gm * g.ldc + gn, o8);
+        Vec8<E>::store(C + (int64_t)gm * g.ldc + gn, o8);
         if (flags & VMR_EPI_AUX) {
           const float a8[8] = {ax[2 * k][0], ax[2 * k][1], ax[2 * k][2], ax[2 * k][3],
                                ax[2 * k + 1][0], ax[2 * k + 1][1], ax[2 * k + 1][2], ax[2 * k + 1][3]};
@@ -564,7 +560,7 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
             for (int e = 0; e < 8; ++e) bits |= (a8[e] != 0.f ? 1u : 0u) << e;
             reinterpret_cast<unsigned char*>(g.aux)[((int64_t)zb * g.M + gm) * (g.N >> 3) + (gn >> 3)] = (unsigned char)bits;
           } else {
-            Vec8<bf16_t>::store(Aux + (int64_t)gm * g.ldr + gn, a8);
+            Vec8<E>::store(Aux + (int64_t)gm * g.ldr + gn, a8);
           }
         }
       }
@@ -572,8 +568,8 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int gn = cw + quad_col<PERM>(j, q);
-        Vec4<bf16_t>::store(C + (int64_t)gm * g.ldc + gn, out[j]);
-        if (flags & VMR_EPI_AUX) Vec4<bf16_t>::store(Aux + (int64_t)gm * g.ldr + gn, ax[j]);
+        Vec4<E>::store(C + (int64_t)gm * g.ldc + gn, out[j]);
+        if (flags & VMR_EPI_AUX) Vec4<E>::store(Aux + (int64_t)gm * g.ldr + gn, ax[j]);
       }
     }
   }
@@ -586,7 +582,7 @@ __device__ __forceinline__ void epilogue_direct(const vmr_gemm_t& g, const f32x4
 // 320x128 (MT = 5) workgroup per CU.  The K loop is bound by the L2 -> LDS fill (measured: the loop without
 // MFMAs takes 90 % of the full time, ~60 GB/s per CU), so bytes per flop decide: one wide tile per CU
 // fetches (256 + 128) rows per K-step where two 128x128 tiles fetch 2 x (128 + 128).
-template <bool TA, bool TB, int BK, int NST, int MT = 4, int WM = 2>
+template <typename E, bool TA, bool TB, int BK, int NST, int MT = 4, int WM = 2>
 __device__ __forceinline__ void gemm_dma_body(const vmr_gemm_t& g, int tiles_m, int tiles_n, unsigned char* smem, int bid_x,
                                               int bid_z, int grid_z) {
   static_assert(MT == 4 || (!TA && BK == 64), "tall tile: A row-major, BK = 64");
@@ -666,18 +662,18 @@ __device__ __forceinline__ void gemm_dma_body(const vmr_gemm_t& g, int tiles_m, 
   const bool colsum = TA && g.a_colsum != nullptr && tc.tn == 0 && wn == 0;   // wave-uniform
   bf16x8 ones;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+  for (int e = 0; e < 8; ++e) ones[e] = bits_from_f<E>(1.0f);
   auto mma = [&](int buf) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0);  // C^T tile
+        acc[i][j] = mfma16<E>(fb[buf][j], fa[buf][i], acc[i][j]);  // C^T tile
     if constexpr (TA) {
       if (colsum) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) accdb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[buf][i], accdb[i], 0, 0, 0);
+        for (int i = 0; i < MT; ++i) accdb[i] = mfma16<E>(ones, fa[buf][i], accdb[i]);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -746,132 +742,26 @@ __device__ __forceinline__ void gemm_dma_body(const vmr_gemm_t& g, int tiles_m, 
     }
   }
   if (direct) {
-    epilogue_direct<MT, PERM>(g, acc, wm, wn, lane, m0, n0, tc.zb,
-                    (g.flags & VMR_EPI_OUT_F32) ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
-                                                : reinterpret_cast<bf16_t*>(g.C) + coff,
-                    rres, reinterpret_cast<bf16_t*>(g.aux) + coff);
+    epilogue_direct<E, MT, PERM>(g, acc, wm, wn, lane, m0, n0, tc.zb,
+                                 (g.flags & VMR_EPI_OUT_F32) ? reinterpret_cast<E*>(reinterpret_cast<float*>(g.C) + coff)
+                                                             : reinterpret_cast<E*>(g.C) + coff,
+                                 rres, reinterpret_cast<E*>(g.aux) + coff);
     return;
   }
   if constexpr (MT == 4 && WM == 2) {
-  __syncthreads();
-  epilogue<bf16_t, true, true, true, PERM>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
-                         (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM))
-                             ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
-                             : reinterpret_cast<bf16_t*>(g.C) + coff,
-                         reinterpret_cast<const bf16_t*>(g.residual) + coff,
-                         reinterpret_cast<bf16_t*>(g.aux) + coff);
+    __syncthreads();
+    epilogue<E, true, true, true, PERM>(g, reinterpret_cast<float*>(smem), acc, wm, wn, lane, m0, n0, tc.zb,
+                                        (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM))
+                                            ? reinterpret_cast<E*>(reinterpret_cast<float*>(g.C) + coff)
+                                            : reinterpret_cast<E*>(g.C) + coff,
+                                        reinterpret_cast<const E*>(g.residual) + coff, reinterpret_cast<E*>(g.aux) + coff);
   }
 }
 
-template <bool TA, bool TB, int BK, int NST, int MT = 4, int WM = 2>
-__global__ __launch_bounds__(WM * 128, (WM == 2 ? (BK == 32 && NST == 3 ? 3 : 2) : (MT == 2 ? 2 : 1))) void gemm_bf16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
+template <typename E, bool TA, bool TB, int MT = 4, int WM = 2>
+__global__ __launch_bounds__(WM * 128, (WM == 2 ? 2 : 1)) void gemm_e16_dma_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  gemm_dma_body<TA, TB, BK, NST, MT, WM>(g, tiles_m, tiles_n, smem, blockIdx.x, blockIdx.z, gridDim.z);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// One 512-thread workgroup per CU, (64 * MT) x 128 tile (MT = 4: 256 rows, MT = 5: 320 rows), x.W^T layout only, with
-// the operand rings sized by what bounds this loop: the L2 -> LDS fill (~65 GB/s per CU whatever the schedule).
-//   * bytes per flop: 320x128 fetches 448 rows per K-step for 5.2 MFLOP -- 0.70 of what two co-resident 160x128
-//     tiles fetch -- so a fill-bound loop gets 1.4x faster, PROVIDED the fill queue never runs dry;
-//   * with two stages (the WM = 4 instantiation of gemm_dma_body) it does run dry: a stage can only be re-requested
-//     after the barrier that frees it, so every K-step pays one L2 round trip (~1 us) with nothing in flight -- the
-//     reason that variant lost on single-round grids;
-//   * here the A operand (40 of a stage's 56 KiB) has THREE buffers and is requested two K-steps ahead, the weight
-//     operand TWO buffers and one step ahead: 3 x 40 + 2 x 16 = 152 KiB of the 160.  Issue order inside a step is
-//     W(kt+1) then A(kt+2), so the counted wait at the top of step kt+1 -- "everything but the last A request" --
-//     retires exactly A(kt+1) and W(kt+1) (vmcnt counts in issue order).
-// Same LDS images, fragment reads, swapped-operand MFMAs and register-direct 16-byte epilogue as gemm_dma_body.
-template <int MT, int NSB = (MT == 5 ? 2 : 3)>
-__device__ __forceinline__ void gemm_dma_a3b2_body(const vmr_gemm_t& g, int tiles_m, int tiles_n, unsigned char* smem) {
-  constexpr int BK = 64, NW = 8, TBM = MT * 64;
-  constexpr int OPA = TBM * BK * 2, OPB = 128 * BK * 2;
-  constexpr int LPA = OPA / 1024 / NW;       // A loads per wave per K-step (4 or 5); the weight tile: 2
-  constexpr int LPB = OPB / 1024 / NW;
-  unsigned char* ringA = smem;               // 3 x OPA
-  unsigned char* ringB = smem + 3 * OPA;     // NSB x OPB (3 where the tile leaves room: W two steps ahead as well)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
-  const TileCoord tc = tile_coord(g, tiles_m, tiles_n, blockIdx.x, 0, 1);
-  const int m0 = tc.tm * TBM, n0 = tc.tn * BN;
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int nk = g.K / BK;
-  u32x2 rres[MT][4];
-  if (g.flags & VMR_EPI_RESIDUAL) {          // oldest in the vmcnt order: hidden under the whole K loop
-    const bf16_t* Rsd = reinterpret_cast<const bf16_t*>(g.residual);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const bf16_t* rrow = Rsd + (int64_t)(min(m0 + wm * (MT * 16) + (lane & 15) + i * 16, g.M - 1) / g.res_div) * g.ldr +
-                           n0 + wn * 64;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const uint4 w = *reinterpret_cast<const uint4*>(rrow + quad_col<true>(2 * k, lane >> 4));
-        rres[i][2 * k] = (u32x2){w.x, w.y};
-        rres[i][2 * k + 1] = (u32x2){w.z, w.w};
-      }
-    }
-  }
-  auto issueA = [&](int kt) { dma_operand<true, BK, TBM, NW>(A, g.lda, m0, kt * BK, ringA + (kt % 3) * OPA, wid, lane, g.M - 1); };
-  auto issueB = [&](int kt) { dma_operand<true, BK, 128, NW, true>(B, g.ldb, n0, kt * BK, ringB + (kt % NSB) * OPB, wid, lane); };
-  issueA(0);
-  issueB(0);
-  if (nk > 1) {
-    if (NSB == 3) issueB(1);
-    issueA(1);
-  }
-  bf16x8 fa[2][MT], fb[2][4];
-  auto mma = [&](int buf) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0);  // C^T tile
-    __builtin_amdgcn_s_setprio(0);
-  };
-  for (int kt = 0; kt < nk; ++kt) {
-    // A(kt), W(kt) of this wave have landed; only the request(s) of step kt+1 issued last may still be in flight
-    if (kt + 1 < nk) wait_vmcnt<(NSB == 3 ? LPA + LPB : LPA)>();
-    else wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of step kt-1 are complete
-    __builtin_amdgcn_s_barrier();                         // every wave's part of step kt is in LDS; step kt-1's buffers are free
-    if (NSB == 3) {
-      if (kt + 2 < nk) { issueB(kt + 2); issueA(kt + 2); }
-    } else {
-      if (kt + 1 < nk) issueB(kt + 1);
-      if (kt + 2 < nk) issueA(kt + 2);
-    }
-    const unsigned char* curA = ringA + (kt % 3) * OPA;
-    const unsigned char* curB = ringB + (kt % NSB) * OPB;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int buf = kk & 1;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) fa[buf][i] = read_frag<true, BK>(curA, wm * MT + i, kk, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[buf][j] = read_frag<true, BK>(curB, wn * 4 + j, kk, lane);
-      if (kk > 0) mma(0);
-      else if (kt > 0) mma(1);
-    }
-  }
-  if (nk > 0) mma(1);
-  epilogue_direct<MT, true>(g, acc, wm, wn, lane, m0, n0, 0,
-                            (g.flags & VMR_EPI_OUT_F32) ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C))
-                                                        : reinterpret_cast<bf16_t*>(g.C),
-                            rres, reinterpret_cast<bf16_t*>(g.aux));
-}
-
-template <int MT>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  gemm_dma_a3b2_body<MT>(g, tiles_m, tiles_n, smem);
+  gemm_dma_body<E, TA, TB, 64, 2, MT, WM>(g, tiles_m, tiles_n, smem, blockIdx.x, blockIdx.z, gridDim.z);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -902,9 +792,9 @@ template <int N> __device__ __forceinline__ void p8_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <bool TR, bool PERM>
-__device__ __forceinline__ void gemm_p8_body(const vmr_gemm_t& g, int tiles_m, int tiles_n, unsigned char* smem, int bid,
-                                             int dbg = 0) {
+template <typename E, bool TR, bool PERM>
+__device__ __forceinline__ void gemm_p8_body(const vmr_gemm_t& g, int tiles_m, int tiles_n, unsigned char* smem, int bid) {
+  constexpr int dbg = 0;   // (ablation bits of the round-2 study: 1 = no LDS-DMA in the loop, 2 = no MFMAs, 4 = no fragment reads)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 2, wn = wid & 3;
@@ -996,7 +886,7 @@ __device__ __forceinline__ void gemm_p8_body(const vmr_gemm_t& g, int tiles_m, i
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[ih * 4 + i][jh * 2 + j] =
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);  // C^T tile
+                mfma16<E>(fb[j][kk], fa[i][kk], acc[ih * 4 + i][jh * 2 + j]);  // C^T tile
       __builtin_amdgcn_s_setprio(0);
     };
     for (int t = 0; t < nk; ++t) {
@@ -1084,21 +974,16 @@ __device__ __forceinline__ void gemm_p8_body(const vmr_gemm_t& g, int tiles_m, i
       }
     }
   }
-  epilogue_direct<8, PERM>(g, acc, wm, wn, lane, m0, n0, 0,
-                           (g.flags & VMR_EPI_OUT_F32) ? reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(g.C) + coff)
-                                                       : reinterpret_cast<bf16_t*>(g.C) + coff,
-                           rres, reinterpret_cast<bf16_t*>(g.aux) + coff);
+  epilogue_direct<E, 8, PERM>(g, acc, wm, wn, lane, m0, n0, 0,
+                              (g.flags & VMR_EPI_OUT_F32) ? reinterpret_cast<E*>(reinterpret_cast<float*>(g.C) + coff)
+                                                          : reinterpret_cast<E*>(g.C) + coff,
+                              rres, reinterpret_cast<E*>(g.aux) + coff);
 }
 
-template <bool TR>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
+template <typename E, bool TR>
+__global__ __launch_bounds__(512, 1) void gemm_e16_p8_kernel(vmr_gemm_t g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  gemm_p8_body<TR, !TR>(g, tiles_m, tiles_n, smem, blockIdx.x);
-}
-template <bool TR>   // ablation build: dbg bit 0 = no LDS-DMA requests inside the K loop, bit 1 = no MFMAs, bit 2 = no fragment reads
-__global__ __launch_bounds__(512, 1) void gemm_bf16_p8_dbg_kernel(vmr_gemm_t g, int tiles_m, int tiles_n, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  gemm_p8_body<TR, !TR>(g, tiles_m, tiles_n, smem, blockIdx.x, dbg);
+  gemm_p8_body<E, TR, !TR>(g, tiles_m, tiles_n, smem, blockIdx.x);
 }
 
 // Two independent products in ONE launch: workgroups [0, nblk2) run problem 2 (a split-K weight-gradient product
@@ -1112,8 +997,8 @@ struct ReduceJob {   // dst[i] += sum_k slab[k][i] in 16-byte quads (the split-K
   int64_t n4, ld4;
 };
 
-template <int MT1>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_dma2_kernel(vmr_gemm_t g1, int tm1, int tn1, vmr_gemm_t g2, int tm2, int tn2,
+template <typename E, int MT1>
+__global__ __launch_bounds__(256, 2) void gemm_e16_dma2_kernel(vmr_gemm_t g1, int tm1, int tn1, vmr_gemm_t g2, int tm2, int tn2,
                                                                 int nblk2, int nblk12, ReduceJob rj) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // the split-K weight-gradient workgroups go first (measured: 9.32 vs 9.37 ms/step the other way round; alternating
@@ -1121,8 +1006,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma2_kernel(vmr_gemm_t g1, i
   // the slab reduction of the PREVIOUS layer's weight gradient takes the first workgroup ids (measured: first 9.08-9.10,
   // last 9.21 ms/step; 256-384 reduction workgroups, 128 or 512+ are slower)
   const int bid = (int)blockIdx.x < rj.nblocks ? nblk12 + (int)blockIdx.x : (int)blockIdx.x - rj.nblocks;
-  if (bid < nblk2) gemm_dma_body<true, true, 64, 2, 4, 2>(g2, tm2, tn2, smem, bid, 0, 1);
-  else if (bid < nblk12) gemm_dma_body<false, false, 64, 2, MT1, 2>(g1, tm1, tn1, smem, bid - nblk2, 0, 1);
+  if (bid < nblk2) gemm_dma_body<E, true, true, 64, 2, 4, 2>(g2, tm2, tn2, smem, bid, 0, 1);
+  else if (bid < nblk12) gemm_dma_body<E, false, false, 64, 2, MT1, 2>(g1, tm1, tn1, smem, bid - nblk2, 0, 1);
   else {
     const f32x4* s4 = reinterpret_cast<const f32x4*>(rj.slab);
     f32x4* d4 = reinterpret_cast<f32x4*>(rj.dst);
@@ -1273,68 +1158,101 @@ struct Pick {
   int smem;
 };
 
-template <bool TA, bool TB, bool AL>
-Pick pick_dtype(int dtype, int bk) {
-  if (dtype != VMR_BF16) return {(gemm_fn)gemm_f32_kernel<TA, TB, AL>, SMEM_F32};
-  if (bk == 32) return {(gemm_fn)gemm_bf16_kernel<TA, TB, AL, 32>, Geom16<32>::SMEM};
-  return {(gemm_fn)gemm_bf16_kernel<TA, TB, AL, 64>, Geom16<64>::SMEM};
+// ------------------------------------------------------------------------------------------------ library switches
+// Read ONCE, at the first GEMM call (or set through vmr_debug_set_gemm_*; tests flip them between calls).  Every switch
+// selects between kernels that implement the SAME flag set, except `dma == 0`, which turns the LDS-DMA kernels off:
+// VMR_EPI_AUX_BITS is then refused by vmr_gemm (vmr_gemm_aux_bits_supported says so first).  The round-2 A/B variants
+// that measured as dead ends (BK = 32 rings, 8-wave 128^2 tiles, one-workgroup 256/320 x 128 rings, the ablation build of
+// the 8-phase kernel: DESIGN.md 3.1, 3.1d) are no longer in the library.
+struct GemmCfg {
+  int dma;     // VMR_GEMM_DMA    1 (default): LDS-DMA kernels where the shape allows; 0: register-staged kernels only
+  int p8;      // VMR_GEMM_P8     0 never, 1 (default) where 256 x 256 tiles fill >= 85 % of every round, 2 wherever allowed
+  int tall;    // VMR_GEMM_TALL   160 x 128 tiles when they save a (partial) round (default 1)
+  int wide;    // VMR_GEMM_WIDE   320 x 128 one-workgroup-per-CU tiles for multi-round x.W^T products (default 1)
+  int merge;   // VMR_GEMM_MERGE  vmr_gemm2: both products in one launch (default 1)
+};
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+GemmCfg& cfg() {
+  static GemmCfg c = {env_int("VMR_GEMM_DMA", 1) != 0 ? 1 : 0, env_int("VMR_GEMM_P8", 1), env_int("VMR_GEMM_TALL", 1),
+                      env_int("VMR_GEMM_WIDE", 1), env_int("VMR_GEMM_MERGE", 1)};
+  return c;
+}
+
+template <typename E, bool AL>
+Pick pick_reg16(int ta, int tb) {
+  constexpr int sm = Geom16<32>::SMEM;
+  if (!ta && !tb) return {(gemm_fn)gemm_e16_kernel<E, false, false, AL, 32>, sm};
+  if (!ta && tb) return {(gemm_fn)gemm_e16_kernel<E, false, true, AL, 32>, sm};
+  if (ta && !tb) return {(gemm_fn)gemm_e16_kernel<E, true, false, AL, 32>, sm};
+  return {(gemm_fn)gemm_e16_kernel<E, true, true, AL, 32>, sm};
 }
 template <bool AL>
-Pick pick_trans(int ta, int tb, int dtype, int bk) {
-  if (!ta && !tb) return pick_dtype<false, false, AL>(dtype, bk);
-  if (!ta && tb) return pick_dtype<false, true, AL>(dtype, bk);
-  if (ta && !tb) return pick_dtype<true, false, AL>(dtype, bk);
-  return pick_dtype<true, true, AL>(dtype, bk);
+Pick pick_reg32(int ta, int tb) {
+  if (!ta && !tb) return {(gemm_fn)gemm_f32_kernel<false, false, AL>, SMEM_F32};
+  if (!ta && tb) return {(gemm_fn)gemm_f32_kernel<false, true, AL>, SMEM_F32};
+  if (ta && !tb) return {(gemm_fn)gemm_f32_kernel<true, false, AL>, SMEM_F32};
+  return {(gemm_fn)gemm_f32_kernel<true, true, AL>, SMEM_F32};
+}
+Pick pick_reg(int dtype, int ta, int tb, bool al) {
+  if (dtype == VMR_F32) return al ? pick_reg32<true>(ta, tb) : pick_reg32<false>(ta, tb);
+  if (dtype == VMR_F16) return al ? pick_reg16<f16_t, true>(ta, tb) : pick_reg16<f16_t, false>(ta, tb);
+  return al ? pick_reg16<bf16_t, true>(ta, tb) : pick_reg16<bf16_t, false>(ta, tb);
 }
 
-int g_p8 = -1;        // VMR_GEMM_P8 / vmr_debug_set_gemm_p8: 256 x 256 8-phase kernel 0 never, 1 (default) by the rounds model, 2 wherever allowed
-int g_gemm_bk = 0;   // 0 = not read yet; VMR_GEMM_BK=32|64 selects the bf16 K-step of the register-staged path
-int g_gemm_dma = -1;  // VMR_GEMM_DMA / vmr_debug_set_gemm_dma: 0 off (register-staged kernel only), 1: BK=32 x 4 stages, 2 (default): BK=64 x 2 stages, 3: BK=32 x 3 stages, three workgroups per CU
-
-template <int BK, int NST>
-gemm_fn pick_dma_t(int ta, int tb) {
-  if (!ta && !tb) return (gemm_fn)gemm_bf16_dma_kernel<false, false, BK, NST>;
-  if (!ta && tb) return (gemm_fn)gemm_bf16_dma_kernel<false, true, BK, NST>;
-  if (ta && !tb) return (gemm_fn)gemm_bf16_dma_kernel<true, false, BK, NST>;
-  return (gemm_fn)gemm_bf16_dma_kernel<true, true, BK, NST>;
-}
+// LDS-DMA kernels: BK = 64 x 2 stages.  64 KiB of stages; 67,584 B so the atomic-accumulate epilogue can stage the whole
+// fp32 tile in one pass (still 2 / CU)
+constexpr int DMA_SMEM = 128 * CST_LD * 4;
 constexpr int TALL_SMEM = 2 * (160 * 64 * 2 + 128 * 64 * 2);   // 73,728 B: two workgroups per CU
-gemm_fn pick_tall(int tb) {
-  return tb ? (gemm_fn)gemm_bf16_dma_kernel<false, true, 64, 2, 5> : (gemm_fn)gemm_bf16_dma_kernel<false, false, 64, 2, 5>;
+constexpr int WIDE_SMEM = 2 * (320 + 128) * 128;               // one 512-thread workgroup per CU
+template <typename E>
+gemm_fn pick_dma_e(int ta, int tb) {
+  if (!ta && !tb) return (gemm_fn)gemm_e16_dma_kernel<E, false, false>;
+  if (!ta && tb) return (gemm_fn)gemm_e16_dma_kernel<E, false, true>;
+  if (ta && !tb) return (gemm_fn)gemm_e16_dma_kernel<E, true, false>;
+  return (gemm_fn)gemm_e16_dma_kernel<E, true, true>;
 }
+gemm_fn pick_dma(int dtype, int ta, int tb) { return dtype == VMR_F16 ? pick_dma_e<f16_t>(ta, tb) : pick_dma_e<bf16_t>(ta, tb); }
+template <typename E>
+gemm_fn pick_tall_e(int tb) {
+  return tb ? (gemm_fn)gemm_e16_dma_kernel<E, false, true, 5> : (gemm_fn)gemm_e16_dma_kernel<E, false, false, 5>;
+}
+gemm_fn pick_tall(int dtype, int tb) { return dtype == VMR_F16 ? pick_tall_e<f16_t>(tb) : pick_tall_e<bf16_t>(tb); }
 // one 512-thread workgroup per CU: 320x128 tiles (A row-major, ragged M allowed)
-gemm_fn pick_wide_tall() { return (gemm_fn)gemm_bf16_dma_kernel<false, false, 64, 2, 5, 4>; }
-inline int set_smem_once(gemm_fn fn, int smem) {   // > 64 KiB of dynamic LDS must be opted into once per kernel
-  static thread_local const void* done[48];
+gemm_fn pick_wide_tall(int dtype) {
+  return dtype == VMR_F16 ? (gemm_fn)gemm_e16_dma_kernel<f16_t, false, false, 5, 4> : (gemm_fn)gemm_e16_dma_kernel<bf16_t, false, false, 5, 4>;
+}
+gemm_fn pick_p8(int dtype, int tr) {
+  if (dtype == VMR_F16) return tr ? (gemm_fn)gemm_e16_p8_kernel<f16_t, true> : (gemm_fn)gemm_e16_p8_kernel<f16_t, false>;
+  return tr ? (gemm_fn)gemm_e16_p8_kernel<bf16_t, true> : (gemm_fn)gemm_e16_p8_kernel<bf16_t, false>;
+}
+
+inline int set_smem_once(const void* fn, int smem) {   // > 64 KiB of dynamic LDS must be opted into once per kernel
+  if (smem <= 64 * 1024) return 0;
+  static thread_local const void* done[64];
   static thread_local int ndone = 0;
   for (int i = 0; i < ndone; ++i)
-    if (done[i] == reinterpret_cast<const void*>(fn)) return 0;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (done[i] == fn) return 0;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   if (e != hipSuccess) return vmr_fail(-5, "vmr_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-  if (ndone < 48) done[ndone++] = reinterpret_cast<const void*>(fn);
+  if (ndone < 64) done[ndone++] = fn;
   return 0;
 }
+inline int set_smem_once(gemm_fn fn, int smem) { return set_smem_once(reinterpret_cast<const void*>(fn), smem); }
 // rounds of the 512 resident workgroups (2 per CU) a grid needs, in units of one full 128x128 round:
 // a last round that leaves every CU at most one workgroup runs about twice as fast
 inline double rounds_cost(int64_t tiles, double tile_weight) {
   const int64_t full = tiles / 512, rem = tiles % 512;
   return ((double)full + (rem == 0 ? 0.0 : (rem <= 256 ? 0.5 : 1.0))) * tile_weight;
 }
-Pick pick_dma(int ta, int tb, int variant, int flags = 0) {
-  // 64 KiB of stages; 67,584 B so the epilogue can stage the whole fp32 tile in one pass (still 2 / CU)
-  if (variant == 2) return {pick_dma_t<64, 2>(ta, tb), 128 * CST_LD * 4};
-  // variant 3: BK = 32 x 3 stages = 48 KiB and <= 170 VGPRs: THREE workgroups (12 waves) per CU -- the operand fill of a
-  // CU follows the number of waves issuing loads.  The atomic-accumulate epilogue stages the fp32 tile
-  // through LDS and keeps the two-per-CU footprint.
-  if (variant == 3) return {pick_dma_t<32, 3>(ta, tb), (flags & VMR_EPI_ACCUM) ? 128 * CST_LD * 4 : 3 * 16384};
-  return {pick_dma_t<32, 4>(ta, tb), 128 * CST_LD * 4};
-}
 
 inline bool mult(int64_t v, int64_t m) { return (v % m) == 0; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 bool gemm_aligned(const vmr_gemm_t& g) {   // 16-byte accesses everywhere
-  const int v = g.dtype == VMR_BF16 ? 8 : 4;  // elements per 16 B
+  const int v = vmr_dtype_16(g.dtype) ? 8 : 4;  // elements per 16 B
   bool al = aligned16(g.A) && aligned16(g.B) && aligned16(g.C) && mult(g.lda, v) && mult(g.ldb, v) &&
             mult(g.ldc, 8) && mult(g.sA1, v) && mult(g.sA2, v) && mult(g.sB1, v) && mult(g.sB2, v) &&
             mult(g.sC1, 8) && mult(g.sC2, 8);
@@ -1345,16 +1263,19 @@ bool gemm_aligned(const vmr_gemm_t& g) {   // 16-byte accesses everywhere
   }
   return al;
 }
+inline bool bias_ok(const vmr_gemm_t& g) {   // the direct epilogue loads bias as float4
+  return !(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2));
+}
 
-// shapes the 8-phase kernel takes: bf16, both operands K-contiguous (ragged M allowed) or both stored [K][rows]
-// (M, N multiples of 256), N a multiple of 256, K-ranges of whole 64-deep tiles, plain or slab / fp32 stores
+// shapes the 8-phase kernel takes: 16-bit elements, both operands K-contiguous (ragged M allowed) or both stored
+// [K][rows] (M, N multiples of 256), N a multiple of 256, K-ranges of whole 64-deep tiles, plain or slab / fp32 stores
 bool p8_ok(const vmr_gemm_t& g, int64_t Z) {
-  if (g.dtype != VMR_BF16 || Z != 1 || g.transA != g.transB || !gemm_aligned(g)) return false;
+  if (!vmr_dtype_16(g.dtype) || Z != 1 || g.transA != g.transB || !gemm_aligned(g)) return false;
   if (g.N % 256 != 0 || g.K % 64 != 0 || g.M % 8 != 0 || g.M < 256) return false;
   if (g.transA && g.M % 256 != 0) return false;
-  if (g.flags & VMR_EPI_ACCUM) return false;
+  if (g.flags & (VMR_EPI_ACCUM | VMR_EPI_AUX_BITS)) return false;
   if (g.a_colsum) return false;
-  if ((g.flags & VMR_EPI_BIAS) && !(aligned16(g.bias) && aligned16(g.bias2))) return false;
+  if (!bias_ok(g)) return false;
   const int sk = g.splitk > 1 ? g.splitk : 1;
   if (sk > 1 && !(g.flags & VMR_EPI_SLAB)) return false;
   int64_t chunk = (g.K + sk - 1) / sk;
@@ -1368,20 +1289,60 @@ bool p8_ok(const vmr_gemm_t& g, int64_t Z) {
 // Measured (scratch/p8_bench.py, same box, us): [9472,3072,1024] 69 vs 84 (320x128 tiles), 4096^3 113 vs 158, 8192^3 827
 // vs 1092 -- but [9472,1024,1024] 33 vs 31, [9472,2048,1024] 60 vs 58, [8192,1024,4096] 87 vs 79: 256 x 256 tiles pay only
 // when they fill at least 85 % of the CUs of every round (148 tiles of 256 CUs do not).
-// true when vmr_gemm will take a row-major-weight LDS-DMA kernel with the register-direct 16-byte epilogue (the only
-// one that can write VMR_EPI_AUX_BITS): mirrors the dispatch below
-bool gemm_perm_direct(const vmr_gemm_t& g) {
-  const int dma = g_gemm_dma < 0 ? 2 : g_gemm_dma;
-  const int64_t Z = (int64_t)(g.Z1 > 0 ? g.Z1 : 1) * (g.Z2 > 0 ? g.Z2 : 1);
-  // (dma == 2: only the BK = 64 kernels permute the weight rows)
-  return dma == 2 && g.dtype == VMR_BF16 && !g.transB && Z == 1 && g.splitk <= 1 && gemm_aligned(g) && g.M % BM == 0 &&
-         g.N % BN == 0 && g.K % 64 == 0 && g.K >= 128 && !(g.flags & (VMR_EPI_ACCUM | VMR_EPI_OUT_F32 | VMR_EPI_SLAB)) &&
-         (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));
-}
-bool p8_wins(const vmr_gemm_t& g, int64_t tiles) {
-  (void)g;
+bool p8_wins(int64_t tiles) {
   const int64_t rounds = (tiles + 255) / 256;
   return (double)tiles / (double)(rounds * 256) >= 0.85;
+}
+// the interior shapes of the LDS-DMA kernels (128 x 128 tiles)
+bool dma_shape_ok(const vmr_gemm_t& g) {
+  return cfg().dma && vmr_dtype_16(g.dtype) && gemm_aligned(g) && g.M % BM == 0 && g.N % BN == 0 && g.K % 64 == 0 &&
+         g.K >= 128 * (g.splitk > 1 ? g.splitk : 1) && bias_ok(g);
+}
+// 160-row tiles: A row-major, ragged M allowed
+bool tall_shape_ok(const vmr_gemm_t& g) {
+  return cfg().dma && cfg().tall && vmr_dtype_16(g.dtype) && gemm_aligned(g) && !g.transA && g.N % BN == 0 && g.K % 64 == 0 &&
+         g.K >= 128 && g.splitk <= 1 && !(g.flags & VMR_EPI_ACCUM) && g.M % 8 == 0 && bias_ok(g);
+}
+// true when vmr_gemm will take a row-major-weight LDS-DMA kernel with the register-direct 16-byte epilogue -- the only
+// one that writes VMR_EPI_AUX_BITS (the weight rows are permuted on their way into LDS so that a lane owns 8 consecutive
+// columns = one byte of the bit matrix): the 128 / 160 / 320 x 128 tiles of gemm_dma_body with !TB.  The 8-phase kernel
+// does not take products with this flag (p8_ok).
+bool gemm_perm_direct(const vmr_gemm_t& g) {
+  const int64_t Z = (int64_t)(g.Z1 > 0 ? g.Z1 : 1) * (g.Z2 > 0 ? g.Z2 : 1);
+  return cfg().dma && vmr_dtype_16(g.dtype) && !g.transA && !g.transB && Z == 1 && g.splitk <= 1 && gemm_aligned(g) &&
+         g.M % BM == 0 && g.N % BN == 0 && g.K % 64 == 0 && g.K >= 128 &&
+         !(g.flags & (VMR_EPI_ACCUM | VMR_EPI_OUT_F32 | VMR_EPI_SLAB)) && bias_ok(g);
+}
+
+int normalise(vmr_gemm_t& g, const char* who) {
+  VMR_CHECK(vmr_dtype_ok(g.dtype), "%s: bad dtype %d", who, g.dtype);
+  VMR_CHECK(g.M >= 0 && g.N >= 0 && g.K >= 0, "%s: negative dim", who);
+  VMR_CHECK(g.A && g.B && g.C, "%s: null operand", who);
+  if (g.Z1 <= 0) g.Z1 = 1;
+  if (g.Z2 <= 0) g.Z2 = 1;
+  if (g.splitk <= 0) g.splitk = 1;
+  VMR_CHECK(g.splitk == 1 || (g.flags & (VMR_EPI_ACCUM | VMR_EPI_SLAB)), "%s: splitk>1 needs VMR_EPI_ACCUM or VMR_EPI_SLAB", who);
+  if (g.flags & VMR_EPI_SLAB) g.flags |= VMR_EPI_OUT_F32;
+  VMR_CHECK(!(g.flags & VMR_EPI_BIAS) || g.bias, "%s: bias flag without pointer", who);
+  if (g.bias_scale == 0.f) g.bias_scale = 1.f;
+  if (g.res_div <= 0) g.res_div = 1;
+  VMR_CHECK(!g.a_colsum || (g.transA && g.Z1 * g.Z2 == 1), "%s: a_colsum needs transA and Z1*Z2 == 1", who);
+  VMR_CHECK(g.res_div == 1 || !(g.flags & VMR_EPI_AUX), "%s: res_div with aux (aux shares ldr) is not supported", who);
+  VMR_CHECK(!(g.flags & VMR_EPI_RESIDUAL) || g.residual, "%s: residual flag without pointer", who);
+  VMR_CHECK(!(g.flags & VMR_EPI_RES_PRE) || (g.flags & VMR_EPI_RESIDUAL), "%s: VMR_EPI_RES_PRE needs VMR_EPI_RESIDUAL", who);
+  VMR_CHECK(!(g.flags & VMR_EPI_AUX) || g.aux, "%s: aux flag without pointer", who);
+  VMR_CHECK(!(g.flags & VMR_EPI_ROWSCALE) || g.rowscale, "%s: rowscale flag without pointer", who);
+  VMR_CHECK(!(g.flags & VMR_EPI_DROPOUT) || (g.drop_p >= 0.f && g.drop_p < 1.f), "%s: bad drop_p", who);
+  // the bit-matrix aux store exists in ONE kernel family; anything else would write bf16 tiles into a 16x smaller buffer
+  VMR_CHECK(!(g.flags & VMR_EPI_AUX_BITS) || ((g.flags & VMR_EPI_AUX) && gemm_perm_direct(g)),
+            "%s: VMR_EPI_AUX_BITS on a product without the register-direct epilogue (ask vmr_gemm_aux_bits_supported)", who);
+  const int64_t Z = (int64_t)g.Z1 * g.Z2 * g.splitk;
+  VMR_CHECK(Z <= 65535, "%s: too many batches (%lld)", who, (long long)Z);
+  VMR_CHECK(g.M == 0 || g.N == 0 ||
+                (g.lda >= (g.transA ? g.M : g.K) && g.ldb >= (g.transB ? g.N : g.K) && g.ldc >= g.N),
+            "%s: leading dimension too small (lda %lld ldb %lld ldc %lld)", who, (long long)g.lda, (long long)g.ldb,
+            (long long)g.ldc);
+  return 0;
 }
 
 }  // namespace
@@ -1389,201 +1350,68 @@ bool p8_wins(const vmr_gemm_t& g, int64_t tiles) {
 extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   VMR_CHECK(gp != nullptr, "vmr_gemm: null descriptor");
   vmr_gemm_t g = *gp;
-  VMR_CHECK(g.dtype == VMR_F32 || g.dtype == VMR_BF16, "vmr_gemm: bad dtype %d", g.dtype);
-  VMR_CHECK(g.M >= 0 && g.N >= 0 && g.K >= 0, "vmr_gemm: negative dim");
-  VMR_CHECK(g.A && g.B && g.C, "vmr_gemm: null operand");
-  if (g.Z1 <= 0) g.Z1 = 1;
-  if (g.Z2 <= 0) g.Z2 = 1;
-  if (g.splitk <= 0) g.splitk = 1;
-  VMR_CHECK(g.splitk == 1 || (g.flags & (VMR_EPI_ACCUM | VMR_EPI_SLAB)), "vmr_gemm: splitk>1 needs VMR_EPI_ACCUM or VMR_EPI_SLAB");
-  if (g.flags & VMR_EPI_SLAB) g.flags |= VMR_EPI_OUT_F32;
-  VMR_CHECK(!(g.flags & VMR_EPI_BIAS) || g.bias, "vmr_gemm: bias flag without pointer");
-  if (g.bias_scale == 0.f) g.bias_scale = 1.f;
-  if (g.res_div <= 0) g.res_div = 1;
-  VMR_CHECK(!g.a_colsum || (g.transA && g.Z1 * g.Z2 == 1), "vmr_gemm: a_colsum needs transA and Z1*Z2 == 1");
-  VMR_CHECK(g.res_div == 1 || !(g.flags & VMR_EPI_AUX), "vmr_gemm: res_div with aux (aux shares ldr) is not supported");
-  VMR_CHECK(!(g.flags & VMR_EPI_RESIDUAL) || g.residual, "vmr_gemm: residual flag without pointer");
-  VMR_CHECK(!(g.flags & VMR_EPI_RES_PRE) || (g.flags & VMR_EPI_RESIDUAL), "vmr_gemm: VMR_EPI_RES_PRE needs VMR_EPI_RESIDUAL");
-  VMR_CHECK(!(g.flags & VMR_EPI_AUX) || g.aux, "vmr_gemm: aux flag without pointer");
-  VMR_CHECK(!(g.flags & VMR_EPI_ROWSCALE) || g.rowscale, "vmr_gemm: rowscale flag without pointer");
-  VMR_CHECK(!(g.flags & VMR_EPI_DROPOUT) || (g.drop_p >= 0.f && g.drop_p < 1.f), "vmr_gemm: bad drop_p");
-  if (g_gemm_dma < 0) {
-    const char* e = getenv("VMR_GEMM_DMA");
-    g_gemm_dma = e ? atoi(e) : 2;
-  }
-  VMR_CHECK(!(g.flags & VMR_EPI_AUX_BITS) || ((g.flags & VMR_EPI_AUX) && gemm_perm_direct(g)),
-            "vmr_gemm: VMR_EPI_AUX_BITS on a product without the register-direct epilogue (ask vmr_gemm_aux_bits_supported)");
-  const int64_t Z = (int64_t)g.Z1 * g.Z2 * g.splitk;
-  VMR_CHECK(Z <= 65535, "vmr_gemm: too many batches (%lld)", (long long)Z);
+  if (int rc = normalise(g, "vmr_gemm")) return rc;
   if (g.M == 0 || g.N == 0) return 0;
-  VMR_CHECK(g.lda >= (g.transA ? g.M : g.K) && g.ldb >= (g.transB ? g.N : g.K) && g.ldc >= g.N,
-            "vmr_gemm: leading dimension too small (lda %lld ldb %lld ldc %lld)", (long long)g.lda,
-            (long long)g.ldb, (long long)g.ldc);
-  const int v = g.dtype == VMR_BF16 ? 8 : 4;  // elements per 16 B
-  const int vc = (g.flags & (VMR_EPI_OUT_F32 | VMR_EPI_ACCUM)) ? 4 : v;
-  (void)vc;
-  bool al = gemm_aligned(g);
+  const GemmCfg& c = cfg();
+  const int64_t Z = (int64_t)g.Z1 * g.Z2 * g.splitk;
+  const bool al = gemm_aligned(g);
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
-  if (g_gemm_bk == 0) {
-    const char* e = getenv("VMR_GEMM_BK");
-    g_gemm_bk = (e && atoi(e) == 64) ? 64 : 32;
+  const bool dma_ok = dma_shape_ok(g);
+  const bool tall_ok = tall_shape_ok(g);
+  hipStream_t st = (hipStream_t)stream;
+
+  // (1) 256 x 256 tiles, 8-phase schedule (gemm_p8_body)
+  if (c.dma && c.p8 && p8_ok(g, (int64_t)g.Z1 * g.Z2)) {
+    const int tm = cdiv(g.M, 256), tn = g.N / 256;
+    const int64_t tiles = (int64_t)tm * tn * g.splitk;
+    if (c.p8 >= 2 || p8_wins(tiles)) {
+      gemm_fn pf = pick_p8(g.dtype, g.transA);
+      if (int rc = set_smem_once(pf, P8_SMEM)) return rc;
+      hipLaunchKernelGGL(pf, dim3((unsigned)tiles), dim3(512), P8_SMEM, st, g, tm, tn);
+      VMR_LAUNCH_CHECK();
+      return 0;
+    }
   }
-  if (g_gemm_dma < 0) {
-    const char* e = getenv("VMR_GEMM_DMA");
-    g_gemm_dma = e ? atoi(e) : 2;
-  }
-  Pick pk = al ? pick_trans<true>(g.transA, g.transB, g.dtype, g_gemm_bk)
-               : pick_trans<false>(g.transA, g.transB, g.dtype, g_gemm_bk);
-  const bool dma_ok = g_gemm_dma && al && g.dtype == VMR_BF16 && g.M % BM == 0 && g.N % BN == 0 && g.K % 64 == 0 &&
-                      g.K >= 128 * g.splitk &&
-                      (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));   // the direct epilogue loads bias as float4
-  if (dma_ok) pk = pick_dma(g.transA, g.transB, g_gemm_dma == 3 ? 3 : (g_gemm_dma >= 2 ? 2 : 1), g.flags);
   // 160-row tiles when they save a (partial) round: e.g. [9472 x 1024]: 592 tiles = 1.16 rounds of 128x128
   // -> 480 tiles = one round of 160x128
-  static int g_tall = -1;
-  if (g_tall < 0) {
-    const char* e = getenv("VMR_GEMM_TALL");
-    g_tall = e ? atoi(e) : 1;
-  }
-  // wide tiles (ONE 512-thread 320x128 workgroup per CU, 256 per round): 22 % fewer L2 -> LDS bytes per flop than two
+  const double c128 = dma_ok ? rounds_cost((int64_t)tiles_m * tiles_n * Z, 1.0) : 1e30;
+  const double c160 = tall_ok ? rounds_cost((int64_t)cdiv(g.M, 160) * tiles_n * Z, 1.25) : 1e30;
+  // (2) wide tiles (ONE 512-thread 320x128 workgroup per CU, 256 per round): 22 % fewer L2 -> LDS bytes per flop than two
   // 160x128 workgroups.  Measured (scratch/gemm_ksweep.py): a win only for row-major x.W^T products that need two or
   // more rounds ([9472 x 2048 x 1024]: 65 -> 59 us); single-round grids and transposed-operand layouts lose 3-15 %
   // (one workgroup per CU leaves nothing to run while its 8 waves sit at the K-step barrier), so they never take it.
-  static int g_wide = -1;
-  if (g_wide < 0) {
-    const char* e = getenv("VMR_GEMM_WIDE");
-    g_wide = e ? atoi(e) : 1;
-  }
-  const bool tall_ok = g_tall && g_gemm_dma == 2 && al && g.dtype == VMR_BF16 && !g.transA && g.N % BN == 0 && g.K % 64 == 0 &&
-                       g.K >= 128 && g.splitk == 1 && !(g.flags & VMR_EPI_ACCUM) && g.M % 8 == 0 &&
-                       (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)));
-  const double c128 = dma_ok ? rounds_cost((int64_t)tiles_m * tiles_n * Z, 1.0) : 1e30;
-  const double c160 = (tall_ok && dma_ok) ? rounds_cost((int64_t)cdiv(g.M, 160) * tiles_n * Z, 1.25) : 1e30;
-  // big tiles, one workgroup per CU (gemm_dma_a3b2_body): VMR_GEMM_BIG = 0 (default) off, 1 where the rounds model
-  // says so, 2 wherever the shape allows.  Measured (scratch/gemm_big_ab.py, graph-timed, rotating operands): within
-  // +-5 % of the two-per-CU tiles on every shape of the step ([8192,1024,1024] 25.6 vs 24.6 us, [9472,3072,1024] 82.8 vs
-  // 83.3, K = 4096 77.2 vs 77.6) although it fetches 25-30 % fewer bytes per flop: with one barrier per K-step the MFMA,
-  // LDS-read and fill phases of a workgroup do not overlap well enough for the fill rate to be what binds.  The vendor
-  // BLAS on the same shapes (scratch/gemm_vs_blas.py): 24.8 us at [9472,1024,1024] (ours 27.5), 57 us at
-  // [9472,3072,1024] (ours 80) -- the K = 1024 products of this model are prologue / epilogue bound for everybody.
-  static int g_big = -1;
-  if (g_big < 0) {
-    const char* e = getenv("VMR_GEMM_BIG");
-    g_big = e ? atoi(e) : 0;
-  }
-  // 256 x 256 tiles, 8-phase schedule (gemm_p8_body): VMR_GEMM_P8 = 0 off, 1 where the rounds model says so, 2 wherever
-  // the shape allows
-  if (g_p8 < 0) {
-    const char* e = getenv("VMR_GEMM_P8");
-    g_p8 = e ? atoi(e) : 1;
-  }
-  if (g_p8 && p8_ok(g, (int64_t)g.Z1 * g.Z2)) {
-    const int tm = cdiv(g.M, 256), tn = g.N / 256;
-    const int64_t tiles = (int64_t)tm * tn * g.splitk;
-    if (g_p8 >= 2 || p8_wins(g, tiles)) {
-      static int g_p8dbg = -1;
-      if (g_p8dbg < 0) {
-        const char* e = getenv("VMR_P8_DBG");
-        g_p8dbg = e ? atoi(e) : 0;
-      }
-      if (g_p8dbg) {
-        auto df = g.transA ? gemm_bf16_p8_dbg_kernel<true> : gemm_bf16_p8_dbg_kernel<false>;
-        if (int rc = set_smem_once((gemm_fn)(void*)df, P8_SMEM)) return rc;
-        hipLaunchKernelGGL(df, dim3((unsigned)tiles), dim3(512), P8_SMEM, (hipStream_t)stream, g, tm, tn, g_p8dbg);
-        VMR_LAUNCH_CHECK();
-        return 0;
-      }
-      gemm_fn pf = g.transA ? (gemm_fn)gemm_bf16_p8_kernel<true> : (gemm_fn)gemm_bf16_p8_kernel<false>;
-      if (int rc = set_smem_once(pf, P8_SMEM)) return rc;
-      hipLaunchKernelGGL(pf, dim3((unsigned)tiles), dim3(512), P8_SMEM, (hipStream_t)stream, g, tm, tn);
-      VMR_LAUNCH_CHECK();
-      return 0;
-    }
-  }
-  if (g_big && tall_ok && dma_ok && !g.transB && Z == 1 && g.K >= 192 && g.M >= 256 && !(g.flags & VMR_EPI_SLAB)) {
-    // one round of <= 256 tiles, or whole rounds of 256-row tiles; otherwise the 2-per-CU kernels keep the shape
-    const int t4 = cdiv(g.M, 256) * tiles_n, t5 = cdiv(g.M, 320) * tiles_n;
-    const double r4 = (double)((t4 + 255) / 256) * 256.0, r5 = (double)((t5 + 255) / 256) * 320.0;   // rows of work per CU
-    const int mt = r5 < r4 ? 5 : 4;
-    const int64_t tiles = mt == 5 ? t5 : t4;
-    const double waste = (double)(((tiles + 255) / 256) * 256) / (double)tiles;   // idle CU share of the last round
-    if (g_big >= 2 || waste <= 1.10) {
-      const int tm = cdiv(g.M, mt * 64);
-      const int smem = 3 * (mt * 64) * 128 + (mt == 5 ? 2 : 3) * 128 * 128;
-      gemm_fn bf = mt == 5 ? (gemm_fn)gemm_bf16_big_kernel<5> : (gemm_fn)gemm_bf16_big_kernel<4>;
-      if (int rc = set_smem_once(bf, smem)) return rc;
-      hipLaunchKernelGGL(bf, dim3((unsigned)(tm * tiles_n)), dim3(512), smem, (hipStream_t)stream, g, tm, tiles_n);
-      VMR_LAUNCH_CHECK();
-      return 0;
-    }
-  }
-  if (g_wide && tall_ok && dma_ok && !g.transB && g.M >= 320) {
+  if (c.wide && tall_ok && dma_ok && !g.transB && g.M >= 320) {
     const int tm = cdiv(g.M, 320);
     const int64_t rounds = ((int64_t)tm * tiles_n * Z + 255) / 256;
     if (rounds >= 2 && (double)rounds * 1.25 * 0.9 < (c128 < c160 ? c128 : c160) - 1e-9) {
-      gemm_fn wf = pick_wide_tall();
-      const int smem = 2 * (320 + 128) * 128;
-      if (int rc = set_smem_once(wf, smem)) return rc;
-      hipLaunchKernelGGL(wf, dim3((unsigned)(tm * tiles_n), 1, (unsigned)Z), dim3(512), smem, (hipStream_t)stream, g, tm, tiles_n);
+      gemm_fn wf = pick_wide_tall(g.dtype);
+      if (int rc = set_smem_once(wf, WIDE_SMEM)) return rc;
+      hipLaunchKernelGGL(wf, dim3((unsigned)(tm * tiles_n), 1, (unsigned)Z), dim3(512), WIDE_SMEM, st, g, tm, tiles_n);
       VMR_LAUNCH_CHECK();
       return 0;
     }
   }
-  if (g_tall && g_gemm_dma >= 2 && al && g.dtype == VMR_BF16 && !g.transA && g.N % BN == 0 && g.K % 64 == 0 && g.K >= 128 &&
-      g.splitk == 1 && !(g.flags & VMR_EPI_ACCUM) && g.M % 8 == 0 &&
-      (!(g.flags & VMR_EPI_BIAS) || (aligned16(g.bias) && aligned16(g.bias2)))) {
+  // (3) 160 x 128 tiles, two workgroups per CU
+  if (tall_ok && dma_ok && c160 < c128 - 1e-9) {
     const int tm160 = cdiv(g.M, 160);
-    const double c128 = dma_ok ? rounds_cost((int64_t)tiles_m * tiles_n * Z, 1.0) : 1e30;
-    const double c160 = rounds_cost((int64_t)tm160 * tiles_n * Z, 1.25);
-    if (dma_ok && c160 < c128 - 1e-9) {
-      gemm_fn tf = pick_tall(g.transB);
-      static thread_local bool tall_set[2] = {false, false};
-      if (!tall_set[g.transB ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tf), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           TALL_SMEM);
-        if (e != hipSuccess) return vmr_fail(-5, "vmr_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        tall_set[g.transB ? 1 : 0] = true;
-      }
-      hipLaunchKernelGGL(tf, dim3((unsigned)(tm160 * tiles_n), 1, (unsigned)Z), dim3(256), TALL_SMEM, (hipStream_t)stream,
-                         g, tm160, tiles_n);
-      VMR_LAUNCH_CHECK();
-      return 0;
-    }
-  }
-  if (pk.smem > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into once per kernel
-    static thread_local const void* done[32];
-    static thread_local int ndone = 0;
-    bool seen = false;
-    for (int i = 0; i < ndone; ++i) seen = seen || done[i] == reinterpret_cast<const void*>(pk.fn);
-    if (!seen) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk.fn),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, pk.smem);
-      if (e != hipSuccess) return vmr_fail(-5, "vmr_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      if (ndone < 32) done[ndone++] = reinterpret_cast<const void*>(pk.fn);
-    }
-  }
-  dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)Z);
-  if (g.splitk > 1 && g.Z1 * g.Z2 == 1) grid = dim3((unsigned)(tiles_m * tiles_n * g.splitk), 1, 1);   // see tile_coord
-  // VMR_GEMM_W16=1 (experiment): the same 128 x 128 x 64 two-stage tile worked by EIGHT waves (4 x 2, wave tile
-  // 32 x 64, <= 128 VGPRs) so that two resident workgroups put 16 waves on the CU -- the operand fill follows the number of
-  // waves issuing loads.  x.W^T layout, register-direct epilogue only.
-  static int g_w16 = -1;
-  if (g_w16 < 0) {
-    const char* e = getenv("VMR_GEMM_W16");
-    g_w16 = e ? atoi(e) : 0;
-  }
-  if (g_w16 && dma_ok && g_gemm_dma == 2 && !g.transA && !g.transB && g.splitk <= 1 && !(g.flags & VMR_EPI_ACCUM)) {
-    hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false, 64, 2, 2, 4>), grid, dim3(512), 2 * (128 * 64 * 2 + 128 * 64 * 2),
-                       (hipStream_t)stream, g, tiles_m, tiles_n);
+    gemm_fn tf = pick_tall(g.dtype, g.transB);
+    if (int rc = set_smem_once(tf, TALL_SMEM)) return rc;
+    hipLaunchKernelGGL(tf, dim3((unsigned)(tm160 * tiles_n), 1, (unsigned)Z), dim3(256), TALL_SMEM, st, g, tm160, tiles_n);
     VMR_LAUNCH_CHECK();
     return 0;
   }
+  // (4) 128 x 128 tiles: LDS-DMA interior kernel, or the register-staged kernel for everything else (any shape /
+  // alignment / dtype)
+  Pick pk = dma_ok ? Pick{pick_dma(g.dtype, g.transA, g.transB), DMA_SMEM} : pick_reg(g.dtype, g.transA, g.transB, al);
+  if (int rc = set_smem_once(pk.fn, pk.smem)) return rc;
+  dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)Z);
+  if (g.splitk > 1 && g.Z1 * g.Z2 == 1) grid = dim3((unsigned)(tiles_m * tiles_n * g.splitk), 1, 1);   // see tile_coord
   float* colsum_fallback = nullptr;
   if (g.a_colsum && !dma_ok) {   // only the LDS-DMA kernel folds the column sums into the product
     colsum_fallback = g.a_colsum;
     g.a_colsum = nullptr;
   }
-  hipLaunchKernelGGL(pk.fn, grid, dim3(256), pk.smem, (hipStream_t)stream, g, tiles_m, tiles_n);
+  hipLaunchKernelGGL(pk.fn, grid, dim3(256), pk.smem, st, g, tiles_m, tiles_n);
   VMR_LAUNCH_CHECK();
   if (colsum_fallback)   // A is stored [K][M]: a plain column-sum pass (vmr_relu_bwd_bias mode 0 accumulates)
     return vmr_relu_bwd_bias(0, g.A, nullptr, nullptr, colsum_fallback, g.K, g.M, g.lda, 1.0f, g.dtype, 0.f, 0, nullptr, nullptr,
@@ -1591,19 +1419,14 @@ extern "C" int vmr_gemm(const vmr_gemm_t* gp, void* stream) {
   return 0;
 }
 
-// Two independent bf16 products in one launch where both take the single-round LDS-DMA tiles (see
-// gemm_bf16_dma2_kernel): g1 = an x.W^T-layout product without split-K (the input gradient on the K-major weight copy),
+// Two independent 16-bit products in one launch where both take the single-round LDS-DMA tiles (see
+// gemm_e16_dma2_kernel): g1 = an x.W^T-layout product without split-K (the input gradient on the K-major weight copy),
 // g2 = a transposed-operand split-K slab product (the weight gradient).  Anything else falls back to two vmr_gemm calls.
 extern "C" int vmr_gemm2_reduce(const vmr_gemm_t* p1, const vmr_gemm_t* p2, const float* slab, float* dst, int nsplit, int64_t n,
                                 int cols, int64_t ld_dst, void* stream) {
   VMR_CHECK(p1 && p2, "vmr_gemm2: null descriptor");
   VMR_CHECK(!slab || (dst && nsplit > 0 && n % 4 == 0 && (cols == 0 || (cols % 4 == 0 && ld_dst % 4 == 0 && ld_dst > 0 && n % cols == 0))),
             "vmr_gemm2_reduce: bad reduction job");
-  static int g_merge = -1;
-  if (g_merge < 0) {
-    const char* e = getenv("VMR_GEMM_MERGE");
-    g_merge = e ? atoi(e) : 1;
-  }
   vmr_gemm_t g1 = *p1, g2 = *p2;
   auto norm = [](vmr_gemm_t& g) {
     if (g.Z1 <= 0) g.Z1 = 1;
@@ -1615,13 +1438,13 @@ extern "C" int vmr_gemm2_reduce(const vmr_gemm_t* p1, const vmr_gemm_t* p2, cons
   };
   norm(g1); norm(g2);
   auto basic = [](const vmr_gemm_t& g) {
-    return g.dtype == VMR_BF16 && g.A && g.B && g.C && g.Z1 * g.Z2 == 1 && g.M > 0 && g.N % BN == 0 && g.K % 64 == 0 &&
-           !(g.flags & VMR_EPI_ACCUM) && gemm_aligned(g) && g.lda >= (g.transA ? g.M : g.K) && g.ldb >= (g.transB ? g.N : g.K) &&
-           g.ldc >= g.N && (!(g.flags & VMR_EPI_BIAS) || (g.bias && aligned16(g.bias) && aligned16(g.bias2))) &&
+    return vmr_dtype_16(g.dtype) && g.A && g.B && g.C && g.Z1 * g.Z2 == 1 && g.M > 0 && g.N % BN == 0 && g.K % 64 == 0 &&
+           !(g.flags & (VMR_EPI_ACCUM | VMR_EPI_AUX_BITS)) && gemm_aligned(g) && g.lda >= (g.transA ? g.M : g.K) &&
+           g.ldb >= (g.transB ? g.N : g.K) && g.ldc >= g.N && (!(g.flags & VMR_EPI_BIAS) || (g.bias && bias_ok(g))) &&
            (!(g.flags & VMR_EPI_RESIDUAL) || g.residual) && (!(g.flags & VMR_EPI_AUX) || g.aux) &&
            (!(g.flags & VMR_EPI_ROWSCALE) || g.rowscale);
   };
-  bool ok = g_merge && basic(g1) && basic(g2);
+  bool ok = cfg().dma && cfg().merge && basic(g1) && basic(g2) && g1.dtype == g2.dtype;
   // the ridden reduction moves float4s: a misaligned job takes the fallback, where vmr_splitk_reduce reports it
   ok = ok && (!slab || (aligned16(slab) && aligned16(dst)));
   // problem 1: row-major operands, no split; 128- or 160-row tiles exactly as vmr_gemm would pick, single round
@@ -1630,7 +1453,7 @@ extern "C" int vmr_gemm2_reduce(const vmr_gemm_t* p1, const vmr_gemm_t* p2, cons
   if (ok) {
     ok = !g1.transA && !g1.transB && g1.splitk == 1 && g1.K >= 128 && g1.M % 8 == 0 && !(g1.flags & VMR_EPI_SLAB);
     const double c128 = g1.M % BM == 0 ? rounds_cost((int64_t)(g1.M / BM) * tn1, 1.0) : 1e30;
-    const double c160 = rounds_cost((int64_t)cdiv(g1.M, 160) * tn1, 1.25);
+    const double c160 = cfg().tall ? rounds_cost((int64_t)cdiv(g1.M, 160) * tn1, 1.25) : 1e30;
     mt1 = c160 < c128 - 1e-9 ? 5 : 4;
     tm1 = mt1 == 5 ? cdiv(g1.M, 160) : g1.M / BM;
     ok = ok && (mt1 == 5 || g1.M % BM == 0) && (int64_t)tm1 * tn1 <= 512;
@@ -1638,7 +1461,7 @@ extern "C" int vmr_gemm2_reduce(const vmr_gemm_t* p1, const vmr_gemm_t* p2, cons
   // problem 2: both operands transposed, split-K slabs
   const int tm2 = g2.M / BM, tn2 = g2.N / BN;
   ok = ok && g2.transA && g2.transB && g2.splitk > 1 && (g2.flags & VMR_EPI_SLAB) && g2.M % BM == 0 &&
-       g2.K >= 128 * g2.splitk && (int64_t)tm2 * tn2 * g2.splitk <= 1024 && (!g2.a_colsum || true);
+       g2.K >= 128 * g2.splitk && (int64_t)tm2 * tn2 * g2.splitk <= 1024;
   if (!ok) {
     if (slab)
       if (int rc = vmr_splitk_reduce(slab, dst, nsplit, n, cols, ld_dst, stream)) return rc;
@@ -1655,35 +1478,33 @@ extern "C" int vmr_gemm2_reduce(const vmr_gemm_t* p1, const vmr_gemm_t* p2, cons
     rj.nblocks = (int)min((int64_t)384, (n / 4 + 255) / 256);
   }
   const int smem = TALL_SMEM;   // >= both variants' two-stage rings (direct epilogues: no staging tile)
-  if (mt1 == 5) {
-    if (int rc = set_smem_once((gemm_fn)(void*)gemm_bf16_dma2_kernel<5>, smem)) return rc;
-    hipLaunchKernelGGL(gemm_bf16_dma2_kernel<5>, dim3(nblk1 + nblk2 + rj.nblocks), dim3(256), smem, (hipStream_t)stream, g1, tm1,
-                       tn1, g2, tm2, tn2, nblk2, nblk1 + nblk2, rj);
-  } else {
-    if (int rc = set_smem_once((gemm_fn)(void*)gemm_bf16_dma2_kernel<4>, smem)) return rc;
-    hipLaunchKernelGGL(gemm_bf16_dma2_kernel<4>, dim3(nblk1 + nblk2 + rj.nblocks), dim3(256), smem, (hipStream_t)stream, g1, tm1,
-                       tn1, g2, tm2, tn2, nblk2, nblk1 + nblk2, rj);
-  }
+  typedef void (*gemm2_fn)(vmr_gemm_t, int, int, vmr_gemm_t, int, int, int, int, ReduceJob);
+  gemm2_fn fn;
+  if (g1.dtype == VMR_F16) fn = mt1 == 5 ? gemm_e16_dma2_kernel<f16_t, 5> : gemm_e16_dma2_kernel<f16_t, 4>;
+  else fn = mt1 == 5 ? gemm_e16_dma2_kernel<bf16_t, 5> : gemm_e16_dma2_kernel<bf16_t, 4>;
+  if (int rc = set_smem_once(reinterpret_cast<const void*>(fn), smem)) return rc;
+  hipLaunchKernelGGL(fn, dim3(nblk1 + nblk2 + rj.nblocks), dim3(256), smem, (hipStream_t)stream, g1, tm1, tn1, g2, tm2, tn2, nblk2,
+                     nblk1 + nblk2, rj);
   VMR_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vmr_gemm_aux_bits_supported(const vmr_gemm_t* gp) {
   if (!gp) return 0;
-  if (g_gemm_dma < 0) {
-    const char* e = getenv("VMR_GEMM_DMA");
-    g_gemm_dma = e ? atoi(e) : 2;
-  }
-  return gemm_perm_direct(*gp) ? 1 : 0;
+  vmr_gemm_t g = *gp;
+  if (g.splitk <= 0) g.splitk = 1;
+  return (vmr_dtype_16(g.dtype) && gemm_perm_direct(g)) ? 1 : 0;
 }
 
-extern "C" int vmr_debug_set_gemm_p8(int mode) {
-  g_p8 = mode;
+extern "C" int vmr_debug_set_gemm_p8(int mode) {   // -1: back to VMR_GEMM_P8 / the default
+  VMR_CHECK(mode >= -1 && mode <= 2, "vmr_debug_set_gemm_p8: mode %d (0 never, 1 by the rounds model, 2 wherever allowed)", mode);
+  cfg().p8 = mode < 0 ? env_int("VMR_GEMM_P8", 1) : mode;
   return 0;
 }
 
-extern "C" int vmr_debug_set_gemm_dma(int mode) {
-  g_gemm_dma = mode;      // -1: re-read VMR_GEMM_DMA at the next call
+extern "C" int vmr_debug_set_gemm_dma(int mode) {  // -1: back to VMR_GEMM_DMA / the default
+  VMR_CHECK(mode >= -1 && mode <= 1, "vmr_debug_set_gemm_dma: mode %d (0 register-staged kernels only, 1 LDS-DMA kernels)", mode);
+  cfg().dma = mode < 0 ? (env_int("VMR_GEMM_DMA", 1) != 0 ? 1 : 0) : mode;
   return 0;
 }
 

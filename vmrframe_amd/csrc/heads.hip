@@ -177,12 +177,8 @@ extern "C" int vmr_gumbel_softmax_fwd(const float* logits, const float* noise, f
   VMR_CHECK(C >= 1 && C <= HC_MAX && (!padded || ldo >= C), "vmr_gumbel_softmax_fwd: need 1 <= C <= %d and ldo >= C", HC_MAX);
   if (R == 0) return 0;
   const dim3 grid((unsigned)min((int64_t)2048, (R + 255) / 256));
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(gumbel_softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, logits, noise, 1.f / tau, seed,
-                       step, probs, (bf16_t*)padded, R, C, ldo);
-  else
-    hipLaunchKernelGGL(gumbel_softmax_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, logits, noise, 1.f / tau, seed,
-                       step, probs, (float*)padded, R, C, ldo);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(gumbel_softmax_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, logits, noise, 1.f / tau, seed,
+                       step, probs, (T*)padded, R, C, ldo));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -193,12 +189,8 @@ extern "C" int vmr_gumbel_softmax_bwd(const float* dprobs, const void* dpadded, 
   VMR_CHECK(C >= 1 && C <= HC_MAX, "vmr_gumbel_softmax_bwd: need 1 <= C <= %d", HC_MAX);
   if (R == 0) return 0;
   const dim3 grid((unsigned)min((int64_t)2048, (R + 255) / 256));
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(gumbel_softmax_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, dprobs, (const bf16_t*)dpadded,
-                       probs, 1.f / tau, dlogits, R, C, ldo);
-  else
-    hipLaunchKernelGGL(gumbel_softmax_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, dprobs, (const float*)dpadded,
-                       probs, 1.f / tau, dlogits, R, C, ldo);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(gumbel_softmax_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, dprobs, (const T*)dpadded,
+                       probs, 1.f / tau, dlogits, R, C, ldo));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -295,12 +287,8 @@ extern "C" int vmr_scale_shift_fwd(const void* x, const float* a, const float* b
   VMR_CHECK(x && a && b && y && D % 8 == 0, "vmr_scale_shift_fwd: bad arguments");
   if (rows == 0) return 0;
   const dim3 grid((unsigned)min((int64_t)4096, (rows * (D / 8) + 255) / 256));
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(scale_shift_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, a, b, (bf16_t*)y,
-                       rows, D);
-  else
-    hipLaunchKernelGGL(scale_shift_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, a, b, (float*)y,
-                       rows, D);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(scale_shift_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, a, b, (T*)y,
+                       rows, D));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -313,12 +301,8 @@ extern "C" int vmr_scale_shift_bwd(const void* dy, const void* x, const float* a
   int gy = (int)min((int64_t)(512 / gx > 0 ? 512 / gx : 1), (rows + 31) / 32);
   const int rpb = (int)((rows + gy - 1) / gy);
   gy = (int)((rows + rpb - 1) / rpb);
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(scale_shift_bwd_kernel<bf16_t>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                       (const bf16_t*)x, a, (bf16_t*)dx, da, db, rows, D, rpb);
-  else
-    hipLaunchKernelGGL(scale_shift_bwd_kernel<float>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
-                       (const float*)x, a, (float*)dx, da, db, rows, D, rpb);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(scale_shift_bwd_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
+                       (const T*)x, a, (T*)dx, da, db, rows, D, rpb));
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -109,18 +109,18 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const T* __restrict_
 //             dh tiles summed through 4 KiB of LDS; then one (batch row, unit) per thread.
 // h ping-pongs between two [2][B][H] buffers (a workgroup reads ALL of h_{s-1} while others write h_s).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KS>
-__device__ __forceinline__ void ld_frags(const bf16_t* __restrict__ p, bf16x8 (&f)[KS]) {   // KS k-steps of 32, lane offset applied
+template <int KS, typename E>
+__device__ __forceinline__ void ld_frags(const E* __restrict__ p, bf16x8 (&f)[KS]) {   // KS k-steps of 32, lane offset applied
 #pragma unroll
   for (int k = 0; k < KS; ++k) f[k] = *reinterpret_cast<const bf16x8*>(p + k * 32);
 }
 
-template <int HH>
-__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const bf16_t* __restrict__ gx, const bf16_t* __restrict__ hprev,
-                                                            const bf16_t* __restrict__ whh, const int* __restrict__ len,
-                                                            float* __restrict__ c, bf16_t* __restrict__ hnext,
-                                                            bf16_t* __restrict__ act, float* __restrict__ cs,
-                                                            bf16_t* __restrict__ hp, bf16_t* __restrict__ y, int B, int Tn, int s) {
+template <typename E, int HH>
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const E* __restrict__ gx, const E* __restrict__ hprev,
+                                                            const E* __restrict__ whh, const int* __restrict__ len,
+                                                            float* __restrict__ c, E* __restrict__ hnext,
+                                                            E* __restrict__ act, float* __restrict__ cs,
+                                                            E* __restrict__ hp, E* __restrict__ y, int B, int Tn, int s) {
   constexpr int H = HH, KS = HH / 32;
   __shared__ float tile[64][17];                     // [batch row of the workgroup][gate * 4 + unit]
   __shared__ bf16x8 wfrag[KS][64];                   // the tile's weight fragments, shared by the four waves (8-16 KiB)
@@ -139,19 +139,19 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const bf16_t* __rest
 #pragma unroll
   for (int g = 0; g < 4; ++g) gxv[g] = (float)gx[ga + g * H];
   const float cprev = c[zb * H + j];
-  const bf16_t hpv = hprev[zb * H + j];              // (both ping-pong buffers start zeroed: valid at s = 0 too)
+  const E hpv = hprev[zb * H + j];              // (both ping-pong buffers start zeroed: valid at s = 0 too)
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (s > 0) {                                       // (h_{-1} = 0: step 0 has no recurrent part; s is uniform: no divergent barrier)
     // the four waves multiply their own 16 batch rows by the SAME 16 weight rows: each wave fetches a quarter of the
     // weight fragments into LDS (KS/4 loads instead of KS: a wave's loads are what a step costs), all read all of them
     bf16x8 a[KS];
-    ld_frags<KS>(hprev + ((int64_t)z * B + min(b0 + w * 16 + r16, B - 1)) * H + kq * 8, a);
-    const bf16_t* wp = whh + ((int64_t)z * 4 * H + (r16 >> 2) * H + u0 + (r16 & 3)) * H + kq * 8;
+    ld_frags<KS, E>(hprev + ((int64_t)z * B + min(b0 + w * 16 + r16, B - 1)) * H + kq * 8, a);
+    const E* wp = whh + ((int64_t)z * 4 * H + (r16 >> 2) * H + u0 + (r16 & 3)) * H + kq * 8;
 #pragma unroll
     for (int k = 0; k < KS / 4; ++k) wfrag[w * (KS / 4) + k][lane] = *reinterpret_cast<const bf16x8*>(wp + (w * (KS / 4) + k) * 32);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], wfrag[k][lane], acc, 0, 0, 0);
+    for (int k = 0; k < KS; ++k) acc = mfma16<E>(a[k], wfrag[k][lane], acc);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[w * 16 + kq * 4 + r][r16] = acc[r];   // D[batch kq*4 + r][n = gate * 4 + unit]
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const bf16_t* __rest
   if (b >= B) return;
   hp[(zb * Tn + s) * H + j] = hpv;
   if (s >= L) {
-    act[ga] = (bf16_t)0.f; act[ga + H] = (bf16_t)0.f; act[ga + 2 * H] = (bf16_t)0.f; act[ga + 3 * H] = (bf16_t)0.f;
+    act[ga] = (E)0.f; act[ga + H] = (E)0.f; act[ga + 2 * H] = (E)0.f; act[ga + 3 * H] = (E)0.f;
     cs[(zb * Tn + s) * H + j] = cprev;
     hnext[zb * H + j] = hpv;
     return;
@@ -172,17 +172,17 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const bf16_t* __rest
   const float hn = og * tanh_f(cn);
   c[zb * H + j] = cn;
   cs[(zb * Tn + s) * H + j] = cn;
-  act[ga] = (bf16_t)ig; act[ga + H] = (bf16_t)fg; act[ga + 2 * H] = (bf16_t)gg; act[ga + 3 * H] = (bf16_t)og;
-  hnext[zb * H + j] = (bf16_t)hn;
+  act[ga] = (E)ig; act[ga + H] = (E)fg; act[ga + 2 * H] = (E)gg; act[ga + 3 * H] = (E)og;
+  hnext[zb * H + j] = (E)hn;
   const int t = (z & 1) == 0 ? s : L - 1 - s;
-  y[(((int64_t)(z >> 1) * B + b) * Tn + t) * 2 * H + (z & 1) * H + j] = (bf16_t)hn;
+  y[(((int64_t)(z >> 1) * B + b) * Tn + t) * 2 * H + (z & 1) * H + j] = (E)hn;
 }
 
-template <int HH>
-__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ act,
+template <typename E, int HH>
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const E* __restrict__ dy, const E* __restrict__ act,
                                                             const float* __restrict__ cs, const int* __restrict__ len,
-                                                            const bf16_t* __restrict__ whht, float* __restrict__ dc,
-                                                            bf16_t* __restrict__ dg, int B, int Tn, int s) {
+                                                            const E* __restrict__ whht, float* __restrict__ dc,
+                                                            E* __restrict__ dg, int B, int Tn, int s) {
   constexpr int H = HH, KS = HH / 32;
   __shared__ float part[4][16][17];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -205,18 +205,18 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const bf16_t* __rest
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (s + 1 < Tn) {                                  // dh = dg_{s+1} . W_hh (nothing flows into the last step); wave w: gate w's K range
     bf16x8 a[KS], bw[KS];
-    ld_frags<KS>(dg + (((int64_t)z * B + min(b0 + r16, B - 1)) * Tn + s + 1) * 4 * H + w * H + kq * 8, a);
-    ld_frags<KS>(whht + ((int64_t)z * H + j0 + r16) * 4 * H + w * H + kq * 8, bw);
+    ld_frags<KS, E>(dg + (((int64_t)z * B + min(b0 + r16, B - 1)) * Tn + s + 1) * 4 * H + w * H + kq * 8, a);
+    ld_frags<KS, E>(whht + ((int64_t)z * H + j0 + r16) * 4 * H + w * H + kq * 8, bw);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], bw[k], acc, 0, 0, 0);
+    for (int k = 0; k < KS; ++k) acc = mfma16<E>(a[k], bw[k], acc);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) part[w][kq * 4 + r][r16] = acc[r];      // D[batch kq*4 + r][unit r16]
   __syncthreads();
   if (b >= B) return;
   if (s >= L) {
-    dg[ga] = (bf16_t)0.f; dg[ga + H] = (bf16_t)0.f; dg[ga + 2 * H] = (bf16_t)0.f; dg[ga + 3 * H] = (bf16_t)0.f;
+    dg[ga] = (E)0.f; dg[ga + H] = (E)0.f; dg[ga + 2 * H] = (E)0.f; dg[ga + 3 * H] = (E)0.f;
     return;
   }
   const int n = threadIdx.x & 15;
@@ -226,10 +226,10 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const bf16_t* __rest
   const float th = tanh_f(cn);
   const float dct = dcv + dht * og * (1.f - th * th);
   dc[zb * H + j] = dct * fg;
-  dg[ga] = (bf16_t)(dct * gg * ig * (1.f - ig));
-  dg[ga + H] = (bf16_t)(dct * cp * fg * (1.f - fg));
-  dg[ga + 2 * H] = (bf16_t)(dct * ig * (1.f - gg * gg));
-  dg[ga + 3 * H] = (bf16_t)(dht * th * og * (1.f - og));
+  dg[ga] = (E)(dct * gg * ig * (1.f - ig));
+  dg[ga + H] = (E)(dct * cp * fg * (1.f - fg));
+  dg[ga + 2 * H] = (E)(dct * ig * (1.f - gg * gg));
+  dg[ga + 3 * H] = (E)(dht * th * og * (1.f - og));
 }
 
 // dst[b][s][:] = s < len_b ? src[b][len_b - 1 - s][:] : 0   (its own inverse on the valid part: also maps gradients back)
@@ -249,40 +249,34 @@ __global__ __launch_bounds__(256) void lstm_reverse_rows_kernel(const T* __restr
 }  // namespace
 
 extern "C" int vmr_lstm_cell_fwd(const void* gx, const void* gh, const int* len, void* c, void* hs, void* act, void* cs,
-                                 void* hp, void* y, int B, int T, int H, int s, int ndir, int dtype, void* stream) {
+                                 void* hp, void* y, int B, int T_, int H, int s, int ndir, int dtype, void* stream) {
   VMR_CHECK(ndir >= 2 && ndir % 2 == 0, "vmr_lstm: ndir must be 2 x the number of independent LSTMs");
   VMR_CHECK(gx && gh && len && c && hs && act && cs && hp && y, "vmr_lstm_cell_fwd: null pointer");
-  VMR_CHECK(B > 0 && T > 0 && H > 0 && s >= 0 && s < T, "vmr_lstm_cell_fwd: bad shape B=%d T=%d H=%d s=%d", B, T, H, s);
-  VMR_CHECK(dtype == VMR_BF16 || dtype == VMR_F32, "vmr_lstm_cell_fwd: bad dtype %d", dtype);
+  VMR_CHECK(B > 0 && T_ > 0 && H > 0 && s >= 0 && s < T_, "vmr_lstm_cell_fwd: bad shape B=%d T=%d H=%d s=%d", B, T_, H, s);
+  VMR_CHECK(vmr_dtype_ok(dtype), "vmr_lstm_cell_fwd: bad dtype %d", dtype);
   const int nblk = (int)(((int64_t)ndir * B * H + 255) / 256);
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gx,
-                       (const float*)gh, len, (float*)c, (bf16_t*)hs, (bf16_t*)act, (float*)cs, (bf16_t*)hp, (bf16_t*)y, B, T, H, s, ndir);
-  else
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)gx,
-                       (const float*)gh, len, (float*)c, (float*)hs, (float*)act, (float*)cs, (float*)hp, (float*)y, B, T, H, s, ndir);
+  VMR_DISPATCH(dtype, T,
+               hipLaunchKernelGGL(lstm_cell_fwd_kernel<T>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const T*)gx, (const float*)gh,
+                                  len, (float*)c, (T*)hs, (T*)act, (float*)cs, (T*)hp, (T*)y, B, T_, H, s, ndir));
   VMR_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vmr_lstm_cell_bwd(const void* dy, const void* act, const void* cs, const int* len, const void* dh,
-                                 void* dc, void* dg, int B, int T, int H, int s, int ndir, int dtype, void* stream) {
+                                 void* dc, void* dg, int B, int T_, int H, int s, int ndir, int dtype, void* stream) {
   VMR_CHECK(ndir >= 2 && ndir % 2 == 0, "vmr_lstm: ndir must be 2 x the number of independent LSTMs");
   VMR_CHECK(dy && act && cs && len && dh && dc && dg, "vmr_lstm_cell_bwd: null pointer");
-  VMR_CHECK(B > 0 && T > 0 && H > 0 && s >= 0 && s < T, "vmr_lstm_cell_bwd: bad shape B=%d T=%d H=%d s=%d", B, T, H, s);
-  VMR_CHECK(dtype == VMR_BF16 || dtype == VMR_F32, "vmr_lstm_cell_bwd: bad dtype %d", dtype);
+  VMR_CHECK(B > 0 && T_ > 0 && H > 0 && s >= 0 && s < T_, "vmr_lstm_cell_bwd: bad shape B=%d T=%d H=%d s=%d", B, T_, H, s);
+  VMR_CHECK(vmr_dtype_ok(dtype), "vmr_lstm_cell_bwd: bad dtype %d", dtype);
   const int nblk = (int)(((int64_t)ndir * B * H + 255) / 256);
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                       (const bf16_t*)act, (const float*)cs, len, (const float*)dh, (float*)dc, (bf16_t*)dg, B, T, H, s, ndir);
-  else
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
-                       (const float*)act, (const float*)cs, len, (const float*)dh, (float*)dc, (float*)dg, B, T, H, s, ndir);
+  VMR_DISPATCH(dtype, T,
+               hipLaunchKernelGGL(lstm_cell_bwd_kernel<T>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)act,
+                                  (const float*)cs, len, (const float*)dh, (float*)dc, (T*)dg, B, T_, H, s, ndir));
   VMR_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int vmr_lstm_step_supported(int H, int dtype) { return dtype == VMR_BF16 && (H == 256 || H == 512); }
+extern "C" int vmr_lstm_step_supported(int H, int dtype) { return vmr_dtype_16(dtype) && (H == 256 || H == 512); }
 
 extern "C" int vmr_lstm_step_fwd(const void* gx, const void* hprev, const void* whh, const int* len, void* c, void* hnext,
                                  void* act, void* cs, void* hp, void* y, int B, int T, int H, int s, int ndir, int dtype, void* stream) {
@@ -293,9 +287,11 @@ extern "C" int vmr_lstm_step_fwd(const void* gx, const void* hprev, const void* 
   VMR_CHECK(B > 0 && T > 0 && s >= 0 && s < T, "vmr_lstm_step_fwd: bad shape B=%d T=%d s=%d", B, T, s);
   VMR_CHECK((((uintptr_t)hprev | (uintptr_t)whh) & 15) == 0, "vmr_lstm_step_fwd: 16-byte alignment");
   const dim3 grid(H / 4, ndir, (B + 63) / 64);
-#define VMR_LSTM_FWD(HH)                                                                                                      \
-  hipLaunchKernelGGL(lstm_step_fwd_kernel<HH>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gx, (const bf16_t*)hprev, \
-                     (const bf16_t*)whh, len, (float*)c, (bf16_t*)hnext, (bf16_t*)act, (float*)cs, (bf16_t*)hp, (bf16_t*)y, B, T, s)
+#define VMR_LSTM_FWD(HH)                                                                                               \
+  VMR_DISPATCH16(dtype, E,                                                                                             \
+                 hipLaunchKernelGGL((lstm_step_fwd_kernel<E, HH>), grid, dim3(256), 0, (hipStream_t)stream, (const E*)gx, \
+                                    (const E*)hprev, (const E*)whh, len, (float*)c, (E*)hnext, (E*)act, (float*)cs, (E*)hp, \
+                                    (E*)y, B, T, s))
   if (H == 256) VMR_LSTM_FWD(256); else VMR_LSTM_FWD(512);
 #undef VMR_LSTM_FWD
   VMR_LAUNCH_CHECK();
@@ -310,20 +306,20 @@ extern "C" int vmr_lstm_step_bwd(const void* dy, const void* act, const void* cs
   VMR_CHECK(B > 0 && T > 0 && s >= 0 && s < T, "vmr_lstm_step_bwd: bad shape B=%d T=%d s=%d", B, T, s);
   VMR_CHECK((((uintptr_t)dg | (uintptr_t)whht) & 15) == 0, "vmr_lstm_step_bwd: 16-byte alignment");
   const dim3 grid(H / 16, ndir, (B + 15) / 16);
-  if (H == 256)
-    hipLaunchKernelGGL(lstm_step_bwd_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)act,
-                       (const float*)cs, len, (const bf16_t*)whht, (float*)dc, (bf16_t*)dg, B, T, s);
-  else
-    hipLaunchKernelGGL(lstm_step_bwd_kernel<512>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)act,
-                       (const float*)cs, len, (const bf16_t*)whht, (float*)dc, (bf16_t*)dg, B, T, s);
+#define VMR_LSTM_BWD(HH)                                                                                               \
+  VMR_DISPATCH16(dtype, E,                                                                                             \
+                 hipLaunchKernelGGL((lstm_step_bwd_kernel<E, HH>), grid, dim3(256), 0, (hipStream_t)stream, (const E*)dy, \
+                                    (const E*)act, (const float*)cs, len, (const E*)whht, (float*)dc, (E*)dg, B, T, s))
+  if (H == 256) VMR_LSTM_BWD(256); else VMR_LSTM_BWD(512);
+#undef VMR_LSTM_BWD
   VMR_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vmr_lstm_reverse_rows(const void* src, const int* len, void* dst, int B, int T, int D, int dtype, void* stream) {
   VMR_CHECK(src && len && dst, "vmr_lstm_reverse_rows: null pointer");
-  VMR_CHECK(dtype == VMR_BF16 || dtype == VMR_F32, "vmr_lstm_reverse_rows: bad dtype %d", dtype);
-  const int per16 = dtype == VMR_BF16 ? 8 : 4;
+  VMR_CHECK(vmr_dtype_ok(dtype), "vmr_lstm_reverse_rows: bad dtype %d", dtype);
+  const int per16 = 16 / vmr_dtype_size(dtype);
   VMR_CHECK(B > 0 && T > 0 && D > 0 && D % per16 == 0, "vmr_lstm_reverse_rows: D=%d must be a multiple of %d", D, per16);
   VMR_CHECK((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "vmr_lstm_reverse_rows: 16-byte alignment");
   const int D8 = D / per16;

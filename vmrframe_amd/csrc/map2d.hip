@@ -50,6 +50,13 @@ template <> struct Raw<bf16_t> {
   __device__ __forceinline__ float y() const { return __uint_as_float(v & 0xFFFF0000u); }
 };
 
+template <> struct Raw<f16_t> {
+  uint32_t v;
+  __device__ __forceinline__ void load(const f16_t* p) { v = *reinterpret_cast<const uint32_t*>(p); }
+  __device__ __forceinline__ float x() const { return e16_lo<f16_t>(v); }
+  __device__ __forceinline__ float y() const { return e16_hi<f16_t>(v); }
+};
+
 template <typename T, int RUN>
 __global__ __launch_bounds__(256) void map2d_pool_fwd_kernel(const T* __restrict__ x, const T* __restrict__ ps,
                                                              const T* __restrict__ pe, int64_t ldp,
@@ -349,14 +356,10 @@ extern "C" int vmr_map2d_pool_fwd(const void* x, const void* ps, const void* pe,
   if (B == 0) return 0;
   const int64_t C = count_cells(grow_host, ndiag, N);
   const dim3 grid(B * (F / MP_CH));
-  if (dtype == VMR_BF16)
-    MP_RUN_DISPATCH(N, hipLaunchKernelGGL((map2d_pool_fwd_kernel<bf16_t, RUN>), grid, dim3(256), 0, (hipStream_t)stream,
-                                          (const bf16_t*)x, (const bf16_t*)ps, (const bf16_t*)pe, ldp, grow, ndiag,
-                                          (bf16_t*)M, (bf16_t*)R, N, F, C));
-  else
-    MP_RUN_DISPATCH(N, hipLaunchKernelGGL((map2d_pool_fwd_kernel<float, RUN>), grid, dim3(256), 0, (hipStream_t)stream,
-                                          (const float*)x, (const float*)ps, (const float*)pe, ldp, grow, ndiag, (float*)M,
-                                          (float*)R, N, F, C));
+  VMR_CHECK(vmr_dtype_ok(dtype), "vmr_map2d_pool_fwd: bad dtype %d", dtype);
+  VMR_DISPATCH(dtype, T,
+               MP_RUN_DISPATCH(N, hipLaunchKernelGGL((map2d_pool_fwd_kernel<T, RUN>), grid, dim3(256), 0, (hipStream_t)stream,
+                                                     (const T*)x, (const T*)ps, (const T*)pe, ldp, grow, ndiag, (T*)M, (T*)R, N, F, C)));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -374,24 +377,16 @@ extern "C" int vmr_map2d_pool_bwd(const void* x, const void* dM, const void* dR,
   const int64_t C = count_cells(grow_host, ndiag, N);
   const size_t lds = (size_t)N * MP_CH * sizeof(float);      // the dx image (<= 40 KiB)
   const dim3 grid(B * (F / MP_CH));
-  if (dtype == VMR_BF16) {
-    MP_RUN_DISPATCH(N, hipLaunchKernelGGL((map2d_pool_bwd_kernel<bf16_t, RUN>), grid, dim3(256), lds, (hipStream_t)stream,
-                                          (const bf16_t*)x, (const bf16_t*)dM, grow, ndiag, (bf16_t*)dx, N, F, C));
+  VMR_CHECK(vmr_dtype_ok(dtype), "vmr_map2d_pool_bwd: bad dtype %d", dtype);
+  VMR_DISPATCH(dtype, T,
+               MP_RUN_DISPATCH(N, hipLaunchKernelGGL((map2d_pool_bwd_kernel<T, RUN>), grid, dim3(256), lds, (hipStream_t)stream,
+                                                     (const T*)x, (const T*)dM, grow, ndiag, (T*)dx, N, F, C)));
+  VMR_LAUNCH_CHECK();
+  if (dR) {
+    VMR_DISPATCH(dtype, T,
+                 hipLaunchKernelGGL(map2d_dp_kernel<T>, dim3(B * N), dim3(64), 0, (hipStream_t)stream, (const T*)dR, grow, ndiag,
+                                    (T*)dps, (T*)dpe, ldp, N, F, C));
     VMR_LAUNCH_CHECK();
-    if (dR) {
-      hipLaunchKernelGGL(map2d_dp_kernel<bf16_t>, dim3(B * N), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)dR, grow, ndiag,
-                         (bf16_t*)dps, (bf16_t*)dpe, ldp, N, F, C);
-      VMR_LAUNCH_CHECK();
-    }
-  } else {
-    MP_RUN_DISPATCH(N, hipLaunchKernelGGL((map2d_pool_bwd_kernel<float, RUN>), grid, dim3(256), lds, (hipStream_t)stream,
-                                          (const float*)x, (const float*)dM, grow, ndiag, (float*)dx, N, F, C));
-    VMR_LAUNCH_CHECK();
-    if (dR) {
-      hipLaunchKernelGGL(map2d_dp_kernel<float>, dim3(B * N), dim3(64), 0, (hipStream_t)stream, (const float*)dR, grow, ndiag,
-                         (float*)dps, (float*)dpe, ldp, N, F, C);
-      VMR_LAUNCH_CHECK();
-    }
   }
   return 0;
 }
@@ -406,17 +401,13 @@ extern "C" int vmr_map2d_scatter(const void* cells, const int32_t* cell_of, cons
   const int wv = v8 ? W / 8 : W;
   const int cpb = 256 / wv > 0 ? 256 / wv : 1;
   const int grid = (int)min((int64_t)65535, (total + cpb - 1) / cpb);
-  if (dtype == VMR_BF16) {
-    if (v8) hipLaunchKernelGGL((map2d_scatter_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)cells,
-                               cell_of, fill, (bf16_t*)out, N, W, C, total);
-    else hipLaunchKernelGGL((map2d_scatter_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)cells,
-                            cell_of, fill, (bf16_t*)out, N, W, C, total);
-  } else {
-    if (v8) hipLaunchKernelGGL((map2d_scatter_kernel<float, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)cells,
-                               cell_of, fill, (float*)out, N, W, C, total);
-    else hipLaunchKernelGGL((map2d_scatter_kernel<float, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)cells,
-                            cell_of, fill, (float*)out, N, W, C, total);
-  }
+  VMR_CHECK(vmr_dtype_ok(dtype), "vmr_map2d_scatter: bad dtype %d", dtype);
+  VMR_DISPATCH(dtype, T, {
+    if (v8) hipLaunchKernelGGL((map2d_scatter_kernel<T, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)cells, cell_of,
+                               fill, (T*)out, N, W, C, total);
+    else hipLaunchKernelGGL((map2d_scatter_kernel<T, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)cells, cell_of,
+                            fill, (T*)out, N, W, C, total);
+  });
   VMR_LAUNCH_CHECK();
   return 0;
 }

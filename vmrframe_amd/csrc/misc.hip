@@ -328,13 +328,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 
 // torch.optim.AdamW semantics (decoupled decay, bias correction, eps outside sqrt)
 // with clip_grad_norm_'s scale min(1, max_norm/(norm+1e-6)) folded into the read of g.
+// Loss scaling (16-bit activation gradients, VMR_F16): `scale` = device float[1] holding S; g and gnorm_sq were produced
+// from S * loss, so both are divided by S here; a non-finite norm (an inf / NaN anywhere in the gradients) SKIPS the
+// update -- p, m, v and the mirror stay as they are; loss_scale_update_kernel below then halves S and holds the step count.
+template <typename TM>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
-                                                    const uint8_t* __restrict__ decay, bf16_t* __restrict__ pb,
+                                                    const uint8_t* __restrict__ decay, TM* __restrict__ pb,
                                                     const float* __restrict__ gnorm_sq, float max_norm, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1,
                                                     float bc2, const int* __restrict__ step_dev,
-                                                    float warmup_steps, float total_steps, int64_t n) {
+                                                    float warmup_steps, float total_steps,
+                                                    const float* __restrict__ scale, int64_t n) {
   if (step_dev) {   // device-resident step: a captured hipGraph replays with the current lr / bias corrections
     const float s = (float)step_dev[0];
     const float t = s + 1.f;
@@ -344,10 +349,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       lr *= s < warmup_steps ? s / fmaxf(1.f, warmup_steps)
                              : fmaxf(0.f, total_steps - s) / fmaxf(1.f, total_steps - warmup_steps);
   }
-  float clip = 1.f;
-  if (gnorm_sq && max_norm > 0.f) {
-    const float nrm = sqrtf(gnorm_sq[0]);
-    clip = fminf(1.f, max_norm / (nrm + 1e-6f));
+  float clip = scale ? 1.f / scale[0] : 1.f;
+  if (gnorm_sq) {
+    const float nrm = sqrtf(gnorm_sq[0]) * clip;
+    if (scale && !(nrm <= 3.0e38f)) return;          // inf / NaN: skipped step (uniform over the grid)
+    if (max_norm > 0.f) clip *= fminf(1.f, max_norm / (nrm + 1e-6f));
   }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = g[i] * clip;
@@ -360,7 +366,30 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
     pi -= (lr / bc1) * (mi / denom);
     p[i] = pi;
-    if (pb) pb[i] = f2bf(pi);
+    if (pb) pb[i] = from_f<TM>(pi);
+  }
+}
+
+// The dynamic loss scaler's bookkeeping, on the device so a captured step replays it: a non-finite gradient norm halves
+// S and resets the streak (the optimizer step was skipped and the step counter holds); otherwise the step counter advances
+// and after `growth_interval` clean steps in a row S doubles (capped at 2^24).  state = {S, clean streak}.
+__global__ void loss_scale_update_kernel(float* __restrict__ state, const float* __restrict__ gnorm_sq, int* __restrict__ step_dev,
+                                         int growth_interval, float min_scale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float S = state[0];
+  const float nrm = sqrtf(gnorm_sq[0]) / S;
+  if (!(nrm <= 3.0e38f)) {
+    state[0] = fmaxf(S * 0.5f, min_scale);
+    state[1] = 0.f;
+  } else {
+    if (step_dev) step_dev[0] += 1;
+    const float streak = state[1] + 1.f;
+    if (growth_interval > 0 && streak >= (float)growth_interval) {
+      state[0] = fminf(S * 2.f, 16777216.f);
+      state[1] = 0.f;
+    } else {
+      state[1] = streak;
+    }
   }
 }
 
@@ -376,18 +405,13 @@ int launch_cast(const void* src, void* dst, int dst_dtype, int64_t rows, int col
 #define VMR_CAST8(TD, SV)                                                                                          \
   hipLaunchKernelGGL((cast8_kernel<TS, TD, SV>), dim3(g8), dim3(256), 0, st, (const TS*)src, (TD*)dst, rows, cols, \
                      ld_src, ld_dst, drop_p, seed, step)
-    if (dst_dtype == VMR_BF16) { if (src_vec) VMR_CAST8(bf16_t, true); else VMR_CAST8(bf16_t, false); }
-    else { if (src_vec) VMR_CAST8(float, true); else VMR_CAST8(float, false); }
+    VMR_DISPATCH(dst_dtype, T, { if (src_vec) VMR_CAST8(T, true); else VMR_CAST8(T, false); });
 #undef VMR_CAST8
     return 0;
   }
   const int grid = (int)min((int64_t)8192, (total + 255) / 256);
-  if (dst_dtype == VMR_BF16)
-    hipLaunchKernelGGL((cast_kernel<TS, bf16_t>), dim3(grid), dim3(256), 0, st, (const TS*)src, (bf16_t*)dst, rows, cols,
-                       ld_src, ld_dst, drop_p, seed, step);
-  else
-    hipLaunchKernelGGL((cast_kernel<TS, float>), dim3(grid), dim3(256), 0, st, (const TS*)src, (float*)dst, rows, cols,
-                       ld_src, ld_dst, drop_p, seed, step);
+  VMR_DISPATCH(dst_dtype, T, hipLaunchKernelGGL((cast_kernel<TS, T>), dim3(grid), dim3(256), 0, st, (const TS*)src, (T*)dst, rows, cols,
+                       ld_src, ld_dst, drop_p, seed, step));
   return 0;
 }
 
@@ -498,8 +522,7 @@ extern "C" int vmr_cast(const void* src, int src_dtype, void* dst, int dst_dtype
   VMR_CHECK(src && dst, "vmr_cast: null pointer");
   VMR_CHECK(ld_src >= cols && ld_dst >= cols, "vmr_cast: leading dim < cols");
   if (rows == 0 || ld_dst == 0) return 0;
-  if (src_dtype == VMR_BF16) launch_cast<bf16_t>(src, dst, dst_dtype, rows, cols, ld_src, ld_dst, drop_p, drop_seed, drop_step, (hipStream_t)stream);
-  else launch_cast<float>(src, dst, dst_dtype, rows, cols, ld_src, ld_dst, drop_p, drop_seed, drop_step, (hipStream_t)stream);
+  VMR_DISPATCH(src_dtype, T, launch_cast<T>(src, dst, dst_dtype, rows, cols, ld_src, ld_dst, drop_p, drop_seed, drop_step, (hipStream_t)stream));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -540,12 +563,8 @@ extern "C" int vmr_relu_bwd_bias(int mode, const void* dy, const void* h, void* 
   int gy = (int)min((int64_t)(1024 / gx > 0 ? 1024 / gx : 1), (rows + 63) / 64);
   const int rpb = (int)((rows + gy - 1) / gy);
   gy = (int)((rows + rpb - 1) / rpb);
-  if (dtype == VMR_BF16)
-    launch_rbb<bf16_t>(mode, dim3(gx, gy), (hipStream_t)stream, dy, h, dz, db, rows, D, ld, scale, rpb, drop_p,
-                       drop_seed, drop_step, db2, db_scale);
-  else
-    launch_rbb<float>(mode, dim3(gx, gy), (hipStream_t)stream, dy, h, dz, db, rows, D, ld, scale, rpb, drop_p,
-                      drop_seed, drop_step, db2, db_scale);
+  VMR_DISPATCH(dtype, T, launch_rbb<T>(mode, dim3(gx, gy), (hipStream_t)stream, dy, h, dz, db, rows, D, ld, scale, rpb, drop_p,
+                       drop_seed, drop_step, db2, db_scale));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -589,17 +608,29 @@ extern "C" int vmr_sumsq(const float* g, float* out, int64_t n, void* stream) {
   return 0;
 }
 
-extern "C" int vmr_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay, void* p_bf16,
+extern "C" int vmr_adamw(float* p, const float* g, float* m, float* v, const uint8_t* decay, void* p16, int p16_dtype,
                          const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
-                         float wd, int step, const int* step_dev, float warmup_steps, float total_steps, int64_t n,
-                         void* stream) {
+                         float wd, int step, const int* step_dev, float warmup_steps, float total_steps,
+                         const float* loss_scale, int64_t n, void* stream) {
   VMR_CHECK(p && g && m && v && decay, "vmr_adamw: null pointer");
   VMR_CHECK(step >= 1 || step_dev, "vmr_adamw: step starts at 1");
+  VMR_CHECK(!p16 || vmr_dtype_16(p16_dtype), "vmr_adamw: the compute-dtype mirror is bf16 or f16 (got %d)", p16_dtype);
+  VMR_CHECK(!loss_scale || gnorm_sq, "vmr_adamw: loss scaling needs the gradient norm (the overflow check)");
   if (n == 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3((int)min((int64_t)4096, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     p, g, m, v, decay, (bf16_t*)p_bf16, gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, step_dev,
-                     warmup_steps, total_steps, n);
+  const dim3 grid((int)min((int64_t)4096, (n + 255) / 256));
+  VMR_DISPATCH16(p16_dtype, TM,
+                 hipLaunchKernelGGL(adamw_kernel<TM>, grid, dim3(256), 0, (hipStream_t)stream, p, g, m, v, decay, (TM*)p16, gnorm_sq,
+                                    max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, step_dev, warmup_steps, total_steps, loss_scale, n));
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_loss_scale_update(float* state, const float* gnorm_sq, int* step_dev, int growth_interval, float min_scale,
+                                     void* stream) {
+  VMR_CHECK(state && gnorm_sq, "vmr_loss_scale_update: null pointer");
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, gnorm_sq, step_dev,
+                     growth_interval, min_scale > 0.f ? min_scale : 1.f);
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -608,7 +639,7 @@ extern "C" int vmr_word_embedding_fwd(const int64_t* ids, const float* pad_vec, 
                                       void* out, int64_t n, int wd, int64_t nglove, int64_t ldo, int zero_from, int zero_to,
                                       int dtype, float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream) {
   VMR_CHECK(ids && pad_vec && unk_vec && glove_vec && out, "vmr_word_embedding_fwd: null pointer");
-  VMR_CHECK(dtype == VMR_F32 || dtype == VMR_BF16, "vmr_word_embedding_fwd: bad dtype");
+  VMR_CHECK(vmr_dtype_ok(dtype), "vmr_word_embedding_fwd: bad dtype");
   VMR_CHECK(wd > 0 && wd % 4 == 0 && ldo % 4 == 0 && ldo >= wd && nglove >= 0, "vmr_word_embedding_fwd: wd / ldo must be multiples of 4");
   VMR_CHECK(zero_to >= zero_from && (zero_to - zero_from) % 4 == 0 && zero_from % 4 == 0 && zero_to <= ldo && (zero_to == zero_from || zero_from >= wd),
             "vmr_word_embedding_fwd: bad zero range");
@@ -616,12 +647,8 @@ extern "C" int vmr_word_embedding_fwd(const int64_t* ids, const float* pad_vec, 
   if (n == 0) return 0;
   const int64_t work = n * (wd / 4 + (zero_to - zero_from) / 4);
   const int grid = (int)min((int64_t)4096, (work + 255) / 256);
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(word_embed_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, pad_vec, unk_vec, glove_vec,
-                       (bf16_t*)out, n, wd, nglove, ldo, zero_from, zero_to, drop_p, drop_seed, drop_step);
-  else
-    hipLaunchKernelGGL(word_embed_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, pad_vec, unk_vec, glove_vec,
-                       (float*)out, n, wd, nglove, ldo, zero_from, zero_to, drop_p, drop_seed, drop_step);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(word_embed_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, pad_vec, unk_vec, glove_vec,
+                       (T*)out, n, wd, nglove, ldo, zero_from, zero_to, drop_p, drop_seed, drop_step));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -629,15 +656,11 @@ extern "C" int vmr_word_embedding_fwd(const int64_t* ids, const float* pad_vec, 
 extern "C" int vmr_word_embedding_bwd(const int64_t* ids, const void* dout, float* dunk, int64_t n, int wd, int64_t ldo, int dtype,
                                       float drop_p, uint32_t drop_seed, const uint32_t* drop_step, void* stream) {
   VMR_CHECK(ids && dout && dunk, "vmr_word_embedding_bwd: null pointer");
-  VMR_CHECK(dtype == VMR_F32 || dtype == VMR_BF16, "vmr_word_embedding_bwd: bad dtype");
+  VMR_CHECK(vmr_dtype_ok(dtype), "vmr_word_embedding_bwd: bad dtype");
   if (n == 0) return 0;
   const int grid = (int)min((int64_t)1024, (n + 3) / 4);
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(word_embed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, (const bf16_t*)dout, dunk, n,
-                       wd, ldo, drop_p, drop_seed, drop_step);
-  else
-    hipLaunchKernelGGL(word_embed_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, (const float*)dout, dunk, n,
-                       wd, ldo, drop_p, drop_seed, drop_step);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(word_embed_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, (const T*)dout, dunk, n,
+                       wd, ldo, drop_p, drop_seed, drop_step));
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -588,14 +588,9 @@ extern "C" int vmr_layernorm_fwd(const void* x, const float* gamma, const float*
   VMR_CHECK(!pos || S > 0, "vmr_layernorm_fwd: pos needs S > 0");
   if (rows == 0) return 0;
   const int grid = (int)min((int64_t)4096, (rows + 3) / 4);
-  if (dtype == VMR_BF16)
-    LN_DISPATCH(D, hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, MC>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                      (const bf16_t*)x, gamma, beta, eps, (const bf16_t*)pos, S, (bf16_t*)y, mean, rstd,
-                                      rows, D, drop_p, drop_seed, drop_step));
-  else
-    LN_DISPATCH(D, hipLaunchKernelGGL((ln_fwd_kernel<float, MC>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                      (const float*)x, gamma, beta, eps, (const float*)pos, S, (float*)y, mean, rstd,
-                                      rows, D, drop_p, drop_seed, drop_step));
+  VMR_DISPATCH(dtype, T, LN_DISPATCH(D, hipLaunchKernelGGL((ln_fwd_kernel<T, MC>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)x, gamma, beta, eps, (const T*)pos, S, (T*)y, mean, rstd,
+                                      rows, D, drop_p, drop_seed, drop_step)));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -622,25 +617,16 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* gamma, const 
   const int maxc = D <= 512 ? 1 : (D <= 1024 ? 2 : 4);
   const int slots = maxc * 8 * 64;
   const size_t lds = (size_t)4 * 2 * slots * sizeof(float);
-  if (dtype == VMR_BF16)
-    LN_DISPATCH(D, hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, MC>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
-                                      (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)dres,
-                                      (bf16_t*)dx, part, dpos, S, rows, D, drop_p, drop_seed, drop_step));
-  else
-    LN_DISPATCH(D, hipLaunchKernelGGL((ln_bwd_kernel<float, MC>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
-                                      (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres,
-                                      (float*)dx, part, dpos, S, rows, D, drop_p, drop_seed, drop_step));
+  VMR_DISPATCH(dtype, T, LN_DISPATCH(D, hipLaunchKernelGGL((ln_bwd_kernel<T, MC>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
+                                      (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)dres,
+                                      (T*)dx, part, dpos, S, rows, D, drop_p, drop_seed, drop_step)));
   VMR_LAUNCH_CHECK();
   if (dpos) {
     VMR_CHECK(S > 0 && D % 8 == 0, "vmr_layernorm_bwd: dpos needs S > 0");
     const int nsp = dpos_split(rows, S);
     const dim3 gp((unsigned)min((int64_t)4096, ((int64_t)S * (D / 8) * nsp + 255) / 256));
-    if (dtype == VMR_BF16)
-      hipLaunchKernelGGL(dpos_kernel<bf16_t>, gp, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dpos, rows, S, D, drop_p,
-                         drop_seed, drop_step, nsp);
-    else
-      hipLaunchKernelGGL(dpos_kernel<float>, gp, dim3(256), 0, (hipStream_t)stream, (const float*)dy, dpos, rows, S, D, drop_p,
-                         drop_seed, drop_step, nsp);
+    VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(dpos_kernel<T>, gp, dim3(256), 0, (hipStream_t)stream, (const T*)dy, dpos, rows, S, D, drop_p,
+                         drop_seed, drop_step, nsp));
     VMR_LAUNCH_CHECK();
   }
   if (part && !defer) {
@@ -693,7 +679,7 @@ extern "C" int vmr_ln_dwconv_fwd2(const void* x, const float* gamma, const float
   if (B1 == 0 || S1 == 0) { B1 = 0; S1 = S1 > 0 ? S1 : 1; }
   if (B2 == 0 || S2 == 0) { B2 = 0; S2 = S2 > 0 ? S2 : 1; }
   if (B1 + B2 == 0) return 0;
-  const size_t esz = dtype == VMR_BF16 ? 2 : 4;
+  const size_t esz = (size_t)vmr_dtype_size(dtype);
   int R1, tiles1, R2, tiles2;
   dwconv_tiling(S1, D, esz, R1, tiles1);
   dwconv_tiling(S2, D, esz, R2, tiles2);
@@ -709,22 +695,16 @@ extern "C" int vmr_ln_dwconv_fwd2(const void* x, const float* gamma, const float
     if ((size_t)pad * 1024 > lds) lds = (size_t)pad * 1024;
   }
   const void* fn = nullptr;
-  if (dtype == VMR_BF16) LN_DISPATCH(D, fn = (const void*)ln_dwconv_fwd_kernel<bf16_t, MC>);
-  else LN_DISPATCH(D, fn = (const void*)ln_dwconv_fwd_kernel<float, MC>);
+  VMR_DISPATCH(dtype, T, LN_DISPATCH(D, fn = (const void*)ln_dwconv_fwd_kernel<T, MC>));
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vmr_fail(-5, "vmr_ln_dwconv_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
   const int nb1 = B1 * tiles1, nb = nb1 + B2 * tiles2;
   const int64_t rows1 = (int64_t)B1 * S1;
-  if (dtype == VMR_BF16)
-    LN_DISPATCH(D, hipLaunchKernelGGL((ln_dwconv_fwd_kernel<bf16_t, MC>), dim3(nb), dim3(256), lds,
-                                      (hipStream_t)stream, (const bf16_t*)x, gamma, beta, eps, w, (bf16_t*)u, mean,
-                                      rstd, S1, D, R1, tiles1, nb1, S2, R2, tiles2, rows1));
-  else
-    LN_DISPATCH(D, hipLaunchKernelGGL((ln_dwconv_fwd_kernel<float, MC>), dim3(nb), dim3(256), lds,
-                                      (hipStream_t)stream, (const float*)x, gamma, beta, eps, w, (float*)u, mean, rstd,
-                                      S1, D, R1, tiles1, nb1, S2, R2, tiles2, rows1));
+  VMR_DISPATCH(dtype, T, LN_DISPATCH(D, hipLaunchKernelGGL((ln_dwconv_fwd_kernel<T, MC>), dim3(nb), dim3(256), lds,
+                                      (hipStream_t)stream, (const T*)x, gamma, beta, eps, w, (T*)u, mean,
+                                      rstd, S1, D, R1, tiles1, nb1, S2, R2, tiles2, rows1)));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -750,14 +730,9 @@ static int dwconv_bwd2_impl(const void* du, const void* x, const float* gamma, c
   const int nb1 = B1 * slices * bps1, nb = nb1 + B2 * slices * bps2;
   const int prow1 = B1 * bps1, prows = prow1 + B2 * bps2;
   const int64_t rows1 = (int64_t)B1 * S1;
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(dwconv_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)du, (const bf16_t*)x, gamma, beta, mean, rstd, w, (bf16_t*)dn, workspace, S1, D,
-                       slices, bps1, nb1, S2, bps2, rows1, prow1);
-  else
-    hipLaunchKernelGGL(dwconv_bwd_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)du, (const float*)x, gamma, beta, mean, rstd, w, (float*)dn, workspace, S1, D,
-                       slices, bps1, nb1, S2, bps2, rows1, prow1);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(dwconv_bwd_kernel<T>, dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)du, (const T*)x, gamma, beta, mean, rstd, w, (T*)dn, workspace, S1, D,
+                       slices, bps1, nb1, S2, bps2, rows1, prow1));
   VMR_LAUNCH_CHECK();
   if (nblocks) *nblocks = prows;
   if (defer) return 0;
@@ -841,10 +816,7 @@ extern "C" int vmr_add_pos_fwd(const void* x, const float* pos, void* y, int64_t
   VMR_CHECK(S > 0 && D % 8 == 0 && rows >= 0, "vmr_add_pos_fwd: need S > 0 and D %% 8 == 0");
   if (rows == 0) return 0;
   const unsigned grid = (unsigned)min((int64_t)4096, (rows * (D / 8) + 255) / 256);
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(add_pos_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, pos, (bf16_t*)y, rows, S, D);
-  else
-    hipLaunchKernelGGL(add_pos_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, pos, (float*)y, rows, S, D);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(add_pos_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, pos, (T*)y, rows, S, D));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -856,10 +828,7 @@ extern "C" int vmr_add_pos_bwd(const void* dy, float* dpos, int64_t rows, int S,
   if (rows == 0) return 0;
   const int nsp = dpos_split(rows, S);
   const dim3 gp((unsigned)min((int64_t)4096, ((int64_t)S * (D / 8) * nsp + 255) / 256));
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(dpos_kernel<bf16_t>, gp, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dpos, rows, S, D, 0.f, 0u, nullptr, nsp);
-  else
-    hipLaunchKernelGGL(dpos_kernel<float>, gp, dim3(256), 0, (hipStream_t)stream, (const float*)dy, dpos, rows, S, D, 0.f, 0u, nullptr, nsp);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(dpos_kernel<T>, gp, dim3(256), 0, (hipStream_t)stream, (const T*)dy, dpos, rows, S, D, 0.f, 0u, nullptr, nsp));
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -249,12 +249,8 @@ extern "C" int vmr_weighted_pool_fwd(const void* x, const float* w, const float*
   VMR_CHECK(x && w && mask && alpha && pooled, "vmr_weighted_pool_fwd: null pointer");
   VMR_CHECK(L >= 1 && L <= WP_MAX_L && D % 8 == 0, "vmr_weighted_pool_fwd: need 1 <= L <= %d and D %% 8 == 0", WP_MAX_L);
   if (B == 0) return 0;
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL((weighted_pool_fwd_kernel<bf16_t>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w,
-                       mask, alpha, (bf16_t*)pooled, L, D);
-  else
-    hipLaunchKernelGGL((weighted_pool_fwd_kernel<float>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)x, w,
-                       mask, alpha, (float*)pooled, L, D);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL((weighted_pool_fwd_kernel<T>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)x, w,
+                       mask, alpha, (T*)pooled, L, D));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -264,12 +260,8 @@ extern "C" int vmr_weighted_pool_bwd(const void* dpooled, const void* x, const f
   VMR_CHECK(dpooled && x && w && alpha && dx && dw, "vmr_weighted_pool_bwd: null pointer");
   VMR_CHECK(L >= 1 && L <= WP_MAX_L && D % 8 == 0, "vmr_weighted_pool_bwd: need 1 <= L <= %d and D %% 8 == 0", WP_MAX_L);
   if (B == 0) return 0;
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL((weighted_pool_bwd_kernel<bf16_t>), dim3(B), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)dpooled, (const bf16_t*)x, w, alpha, (bf16_t*)dx, dw, L, D);
-  else
-    hipLaunchKernelGGL((weighted_pool_bwd_kernel<float>), dim3(B), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)dpooled, (const float*)x, w, alpha, (float*)dx, dw, L, D);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL((weighted_pool_bwd_kernel<T>), dim3(B), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)dpooled, (const T*)x, w, alpha, (T*)dx, dw, L, D));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -546,12 +538,8 @@ extern "C" int vmr_label_fuse_fwd(const float* p, const float* E, const void* re
   if (M == 0) return 0;
   const dim3 grid((unsigned)min((int64_t)4096, (M * (K / 8) + 255) / 256));
   const size_t lds = (size_t)N * K * 4;
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL((label_fuse_fwd_kernel<bf16_t, 4>), grid, dim3(256), lds, (hipStream_t)stream, p, E, (const bf16_t*)res,
-                       rowscale, (bf16_t*)y, M, K);
-  else
-    hipLaunchKernelGGL((label_fuse_fwd_kernel<float, 4>), grid, dim3(256), lds, (hipStream_t)stream, p, E, (const float*)res,
-                       rowscale, (float*)y, M, K);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL((label_fuse_fwd_kernel<T, 4>), grid, dim3(256), lds, (hipStream_t)stream, p, E, (const T*)res,
+                       rowscale, (T*)y, M, K));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -566,17 +554,12 @@ extern "C" int vmr_label_fuse_bwd(const void* dy, const float* p, const float* E
   const size_t lds = (size_t)N * K * 4;
   const dim3 gw((unsigned)((M + NL_RPB - 1) / NL_RPB));
   const int groups = max(1, 256 / (K / 8));
-  if (dtype == VMR_BF16) {
-    hipLaunchKernelGGL((label_fuse_bwd_kernel<bf16_t, 4>), g1, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, E, rowscale,
-                       (bf16_t*)dres, dp, M, K, rpb);
-    hipLaunchKernelGGL((narrow_dw_kernel<bf16_t, 4>), gw, dim3(256), 0, (hipStream_t)stream, p, (const bf16_t*)dres, workspace, M, K,
+  VMR_DISPATCH(dtype, T, {
+    hipLaunchKernelGGL((label_fuse_bwd_kernel<T, 4>), g1, dim3(256), lds, (hipStream_t)stream, (const T*)dy, E, rowscale,
+                       (T*)dres, dp, M, K, rpb);
+    hipLaunchKernelGGL((narrow_dw_kernel<T, 4>), gw, dim3(256), 0, (hipStream_t)stream, p, (const T*)dres, workspace, M, K,
                        (int64_t)K, NL_RPB);
-  } else {
-    hipLaunchKernelGGL((label_fuse_bwd_kernel<float, 4>), g1, dim3(256), lds, (hipStream_t)stream, (const float*)dy, E, rowscale,
-                       (float*)dres, dp, M, K, rpb);
-    hipLaunchKernelGGL((narrow_dw_kernel<float, 4>), gw, dim3(256), 0, (hipStream_t)stream, p, (const float*)dres, workspace, M, K,
-                       (int64_t)K, NL_RPB);
-  }
+  });
   hipLaunchKernelGGL(narrow_reduce_t_kernel, dim3(cdiv(N * K, 256), cdiv((int)gw.x * groups, 16)), dim3(256), 0, (hipStream_t)stream,
                      workspace, dE, (int)gw.x * groups, N, K);
   VMR_LAUNCH_CHECK();
@@ -592,8 +575,7 @@ extern "C" int vmr_narrow_linear_fwd(const void* x, const float* W, const float*
   const int rpb = 32;
   dim3 grid((unsigned)((M + rpb - 1) / rpb));
   const size_t lds = (size_t)N * K * 4;
-  if (dtype == VMR_BF16) launch_narrow_fwd<bf16_t>(N, grid, lds, (hipStream_t)stream, x, W, bias, y, M, K, ldx, rpb);
-  else launch_narrow_fwd<float>(N, grid, lds, (hipStream_t)stream, x, W, bias, y, M, K, ldx, rpb);
+  VMR_DISPATCH(dtype, T, launch_narrow_fwd<T>(N, grid, lds, (hipStream_t)stream, x, W, bias, y, M, K, ldx, rpb));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -615,8 +597,7 @@ extern "C" int vmr_narrow_linear_bwd_add(const float* dy, const void* x, const f
   VMR_CHECK(N >= 1 && N <= NL_MAXN && K % 8 == 0 && K <= 2048 && ldx % 8 == 0 && ldx >= K && (size_t)N * K * 4 <= 64 * 1024,
             "vmr_narrow_linear_bwd: need 1 <= N <= 8, K %% 8 == 0, K <= 2048, N*K*4 <= 64 KiB (N=%d K=%d)", N, K);
   if (M == 0) return 0;
-  if (dtype == VMR_BF16) launch_narrow_bwd<bf16_t>(N, (hipStream_t)stream, dy, x, W, dx, dW, db, workspace, M, K, ldx, dx_add);
-  else launch_narrow_bwd<float>(N, (hipStream_t)stream, dy, x, W, dx, dW, db, workspace, M, K, ldx, dx_add);
+  VMR_DISPATCH(dtype, T, launch_narrow_bwd<T>(N, (hipStream_t)stream, dy, x, W, dx, dW, db, workspace, M, K, ldx, dx_add));
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -19,7 +19,10 @@ void sample_clip(const float* sc, const int32_t* cells, int C, float thresh, int
                  int64_t* out, int* n_written) {
   std::vector<int> order(C);
   std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sc[a] > sc[b]; });
+  // NaN scores (a diverged run, or uninitialised memory) sort FIRST, as torch.sort(descending=True) orders them: the
+  // key maps NaN to +inf so that the comparator stays a strict weak ordering (std::stable_sort on `a > b` with NaNs is UB)
+  auto key = [&](int i) { return sc[i] != sc[i] ? __builtin_huge_valf() : sc[i]; };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) > key(b); });
   std::vector<float> st(C), en(C);
   for (int r = 0; r < C; ++r) {
     st[r] = (float)cells[2 * order[r]];

@@ -135,14 +135,9 @@ extern "C" int vmr_softmax_fwd(const float* S, void* P, void* Pkeep, const float
   const int64_t nrows = (int64_t)Z * R;
   if (nrows == 0) return 0;
   const int grid = (int)min((int64_t)8192, (nrows + 3) / 4);
-  if (dtype == VMR_BF16)
-    SM_DISPATCH(ldP, hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t, MN>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                        S, (bf16_t*)P, (bf16_t*)Pkeep, rmask, cmask, mode, nrows, H, R, C, ldS, ldP,
-                                        cm_stride, scale, drop_p, drop_seed, drop_step));
-  else
-    SM_DISPATCH(ldP, hipLaunchKernelGGL((softmax_fwd_kernel<float, MN>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                        S, (float*)P, (float*)Pkeep, rmask, cmask, mode, nrows, H, R, C, ldS, ldP,
-                                        cm_stride, scale, drop_p, drop_seed, drop_step));
+  VMR_DISPATCH(dtype, T, SM_DISPATCH(ldP, hipLaunchKernelGGL((softmax_fwd_kernel<T, MN>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                        S, (T*)P, (T*)Pkeep, rmask, cmask, mode, nrows, H, R, C, ldS, ldP,
+                                        cm_stride, scale, drop_p, drop_seed, drop_step)));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -155,14 +150,9 @@ extern "C" int vmr_softmax_bwd(const float* dP, const void* P, void* dS, int Z, 
   const int64_t nrows = (int64_t)Z * R;
   if (nrows == 0) return 0;
   const int grid = (int)min((int64_t)8192, (nrows + 3) / 4);
-  if (dtype == VMR_BF16)
-    SM_DISPATCH(ldP, hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t, MN>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                        dP, (const bf16_t*)P, (bf16_t*)dS, nrows, C, ldS, ldP, scale, drop_p, drop_seed,
-                                        drop_step));
-  else
-    SM_DISPATCH(ldP, hipLaunchKernelGGL((softmax_bwd_kernel<float, MN>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                        dP, (const float*)P, (float*)dS, nrows, C, ldS, ldP, scale, drop_p, drop_seed,
-                                        drop_step));
+  VMR_DISPATCH(dtype, T, SM_DISPATCH(ldP, hipLaunchKernelGGL((softmax_bwd_kernel<T, MN>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                        dP, (const T*)P, (T*)dS, nrows, C, ldS, ldP, scale, drop_p, drop_seed,
+                                        drop_step)));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -377,17 +367,14 @@ extern "C" int vmr_cq_softmax_fwd(const float* S2, const float* rowterm, const f
             "vmr_cq_softmax_fwd: score tile %dx%d does not fit LDS", Lc, Lq);
   if (B == 0) return 0;
   const size_t lds = ((size_t)Lc * Lq + 256 + Lq) * 4;   // tile + column-stripe partials
-  const void* fn = dtype == VMR_BF16 ? (const void*)cq_softmax_fwd_kernel<bf16_t> : (const void*)cq_softmax_fwd_kernel<float>;
+  const void* fn = nullptr;
+  VMR_DISPATCH(dtype, T, fn = (const void*)cq_softmax_fwd_kernel<T>);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vmr_fail(-5, "vmr_cq_softmax_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(cq_softmax_fwd_kernel<bf16_t>, dim3(B, 2), dim3(256), lds, (hipStream_t)stream, S2, rowterm, colterm,
-                       cmask, qmask, (bf16_t*)Srow, (bf16_t*)Scol, Lc, Lq, ldS, ldP);
-  else
-    hipLaunchKernelGGL(cq_softmax_fwd_kernel<float>, dim3(B, 2), dim3(256), lds, (hipStream_t)stream, S2, rowterm, colterm,
-                       cmask, qmask, (float*)Srow, (float*)Scol, Lc, Lq, ldS, ldP);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(cq_softmax_fwd_kernel<T>, dim3(B, 2), dim3(256), lds, (hipStream_t)stream, S2, rowterm, colterm,
+                       cmask, qmask, (T*)Srow, (T*)Scol, Lc, Lq, ldS, ldP));
   VMR_LAUNCH_CHECK();
   return 0;
 }
@@ -400,17 +387,14 @@ extern "C" int vmr_cq_softmax_bwd(const void* dSrow, const void* dScol, const vo
             "vmr_cq_softmax_bwd: score tile %dx%d does not fit LDS", Lc, Lq);
   if (B == 0) return 0;
   const size_t lds = ((size_t)Lc * Lq + 2 * Lq + 256) * 4;   // dS tile + column dots + column-stripe partials
-  const void* fn = dtype == VMR_BF16 ? (const void*)cq_softmax_bwd_kernel<bf16_t> : (const void*)cq_softmax_bwd_kernel<float>;
+  const void* fn = nullptr;
+  VMR_DISPATCH(dtype, T, fn = (const void*)cq_softmax_bwd_kernel<T>);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vmr_fail(-5, "vmr_cq_softmax_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  if (dtype == VMR_BF16)
-    hipLaunchKernelGGL(cq_softmax_bwd_kernel<bf16_t>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dSrow,
-                       (const bf16_t*)dScol, (const bf16_t*)Srow, (const bf16_t*)Scol, dS2, drow, dcol, Lc, Lq, ldS, ldP);
-  else
-    hipLaunchKernelGGL(cq_softmax_bwd_kernel<float>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const float*)dSrow,
-                       (const float*)dScol, (const float*)Srow, (const float*)Scol, dS2, drow, dcol, Lc, Lq, ldS, ldP);
+  VMR_DISPATCH(dtype, T, hipLaunchKernelGGL(cq_softmax_bwd_kernel<T>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const T*)dSrow,
+                       (const T*)dScol, (const T*)Srow, (const T*)Scol, dS2, drow, dcol, Lc, Lq, ldS, ldP));
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -53,12 +53,10 @@ extern "C" int vmr_resample_pad(const float* arena, const int64_t* row_off, cons
   if (B == 0) return 0;
   const int64_t total = (int64_t)B * T * ((V + 3) / 4);
   const dim3 grid((unsigned)min((int64_t)8192, (total + 255) / 256));
-  if (out_dtype == VMR_BF16)
-    hipLaunchKernelGGL(resample_pad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, arena, row_off, seg, out_len,
-                       (bf16_t*)out, mask, B, T, V, ldo);
-  else
-    hipLaunchKernelGGL(resample_pad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, arena, row_off, seg, out_len,
-                       (float*)out, mask, B, T, V, ldo);
+  VMR_CHECK(vmr_dtype_ok(out_dtype), "vmr_resample_pad: bad dtype %d", out_dtype);
+  VMR_DISPATCH(out_dtype, TO,
+               hipLaunchKernelGGL(resample_pad_kernel<TO>, grid, dim3(256), 0, (hipStream_t)stream, arena, row_off, seg, out_len,
+                                  (TO*)out, mask, B, T, V, ldo));
   VMR_LAUNCH_CHECK();
   return 0;
 }

@@ -352,7 +352,7 @@ class WeightCache:
     def get_t(params: Sequence[torch.Tensor], dtype: torch.dtype) -> Optional[torch.Tensor]:
         """K-major copy [K, sum N] of the (grouped) weight, if the optimizer arena keeps one (optim.FlatArena:
         bf16, refreshed by one batched transpose per step); None otherwise."""
-        if dtype != torch.bfloat16 or not USE_WT:
+        if not L.is_16bit(dtype) or not USE_WT:
             return None
         return (getattr(params[0], "_vmr_wt_views", None) or {}).get(tuple(id(p) for p in params))
 
@@ -364,11 +364,11 @@ class WeightCache:
         hit = self.store.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
-        if dtype == torch.bfloat16:
-            # masters living in the flat arena have a bf16 mirror maintained by the AdamW kernel
+        if L.is_16bit(dtype):
+            # masters living in the flat arena have a 16-bit mirror (in the model's compute dtype) maintained by the AdamW kernel
             # (optim.FlatArena): a group laid out back to back is used in place, no cast launch
             mirrors = [getattr(p, "_vmr_w16", None) for p in params]
-            if all(m is not None for m in mirrors):
+            if all(m is not None and m.dtype == dtype for m in mirrors):
                 if any(p._version != getattr(p, "_vmr_synced_version", p._version) for p in params):
                     # a master was edited in place behind the optimizer's back (load_state_dict, p.copy_()): the
                     # mirror the AdamW kernel maintains -- and the K-major copies -- have not seen it yet

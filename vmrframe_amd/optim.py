@@ -35,7 +35,14 @@ class FlatArena:
     """Contiguous fp32 parameter / gradient arenas over the parameters that receive
     gradients (device-agnostic: pure tensor plumbing, also used by the gloo DP tests)."""
 
-    def __init__(self, model: torch.nn.Module, bf16_mirror: bool = False):
+    def __init__(self, model: torch.nn.Module, bf16_mirror: bool = False, mirror_dtype=None):
+        """mirror_dtype: torch.bfloat16 / torch.float16 = keep a 16-bit copy of every master (and the K-major weight
+        copies) in that dtype, rewritten by the AdamW kernel; None = fp32 only.  (bf16_mirror=True: the round-1 spelling
+        of mirror_dtype=torch.bfloat16.)"""
+        if mirror_dtype is None and bf16_mirror:
+            mirror_dtype = torch.bfloat16
+        assert mirror_dtype in (None, torch.bfloat16, torch.float16)
+        self.mirror_dtype = mirror_dtype
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None]
         assert named, "FlatArena needs one backward pass first (to learn which parameters get gradients)"
         # weights that feed ONE grouped GEMM (q|k|v, ...) are laid out back to back so their
@@ -84,9 +91,9 @@ class FlatArena:
         assert lo == total
         self.flat_w = None
         self._t_count = 0
-        if bf16_mirror:
-            # bf16 copy of every master weight, refreshed by the fused AdamW kernel itself
-            self.flat_w = self.flat_p.to(torch.bfloat16)
+        if mirror_dtype is not None:
+            # 16-bit copy of every master weight, refreshed by the fused AdamW kernel itself
+            self.flat_w = self.flat_p.to(mirror_dtype)
             for n, p in named:
                 o, k = offs[n], p.numel()
                 p._vmr_w16 = self.flat_w[o:o + k].view(p.shape)
@@ -137,7 +144,7 @@ class FlatArena:
         parameter broadcast, manual `p.data` edits)."""
         if self.flat_w is not None:
             n = self.flat_p.numel()
-            L.check(L.lib().vmr_cast(self.flat_p.data_ptr(), L.F32, self.flat_w.data_ptr(), L.BF16, n // 8, 8, 8, 8,
+            L.check(L.lib().vmr_cast(self.flat_p.data_ptr(), L.F32, self.flat_w.data_ptr(), L.dtype_code(self.flat_w), n // 8, 8, 8, 8,
                                      0.0, 0, None, L.stream_ptr()), "vmr_cast")
             self.refresh_transposed()
         self.mark_synced()
@@ -145,8 +152,23 @@ class FlatArena:
 
 class FlatAdamW:
     def __init__(self, model: torch.nn.Module, lr: float, weight_decay: float = 0.01, betas=(0.9, 0.999),
-                 eps: float = 1e-8, max_norm: float = 1.0, warmup_steps: float = 0.0, total_steps: int = 0):
+                 eps: float = 1e-8, max_norm: float = 1.0, warmup_steps: float = 0.0, total_steps: int = 0,
+                 loss_scale="auto", growth_interval: int = 200, decay_exempt=None):
+        """loss_scale: "auto" = a dynamic loss scale (initial 2^16) when the model computes in fp16, none otherwise; a
+        number = the initial scale S of a dynamic scaler; None / 0 = off.  With a scale, run the backward pass through
+        `opt.backward(loss)` (= (S * loss).backward(), S read on the device): the weight gradients come out scaled by
+        S, the AdamW kernel divides by S, and a step whose gradient norm is not finite is SKIPPED on the device (no
+        host sync) while vmr_loss_scale_update halves S; `growth_interval` clean steps in a row double it.
+        decay_exempt: name fragments of parameters without weight decay (default: the reference's bias / layer_norm
+        rule, utils/utils.py:89)."""
         self.model = model
+        cd = getattr(model, "compute_dtype", None)
+        if loss_scale == "auto":
+            loss_scale = 65536.0 if cd == torch.float16 else None
+        self.init_scale = float(loss_scale) if loss_scale else 0.0
+        self.growth_interval = int(growth_interval)
+        self.scale_state = None    # device float[2] = {S, clean-step streak}
+        self.decay_exempt = tuple(decay_exempt) if decay_exempt is not None else None
         self.base_lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
         self.sched = linear_warmup_lambda(warmup_steps, total_steps) if total_steps > 0 else (lambda s: 1.0)
         self.t = 0                 # optimizer steps taken (host mirror)
@@ -157,13 +179,22 @@ class FlatAdamW:
 
     # -- arena -----------------------------------------------------------------
     def _build(self):
-        self.arena = FlatArena(self.model, bf16_mirror=getattr(self.model, "compute_dtype", None) == torch.bfloat16)
+        cd = getattr(self.model, "compute_dtype", None)
+        self.arena = FlatArena(self.model, mirror_dtype=cd if L.is_16bit(cd) else None)
+        if self.decay_exempt is not None:
+            A = self.arena
+            A.decay.zero_()
+            for n, p in zip(A.names, A.params):
+                if not any(nd in n for nd in self.decay_exempt):
+                    A.decay[A.offsets[n]:A.offsets[n] + p.numel()] = 1
         L.require_gpu(self.arena.flat_p)
         self.m = torch.zeros_like(self.arena.flat_p)
         self.v = torch.zeros_like(self.arena.flat_p)
         dev = self.arena.flat_p.device
         self.gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.step_t = torch.full((1,), self.t, device=dev, dtype=torch.int32)
+        if self.init_scale > 0 and self.scale_state is None:
+            self.scale_state = torch.tensor([self.init_scale, 0.0], device=dev, dtype=torch.float32)
         self.arena.refresh_transposed()
         # a checkpoint loaded into the model from now on lands in the fp32 arena (in-place copies): bring the
         # compute-dtype copies along (reference main.py:26-28 / utils/utils.py:208-215 resume-and-eval flow)
@@ -210,16 +241,46 @@ class FlatAdamW:
         self.gnorm_sq.zero_()
         n = A.flat_p.numel()
         L.check(lib.vmr_sumsq(A.flat_g.data_ptr(), self.gnorm_sq.data_ptr(), n, st), "vmr_sumsq")
+        sc = self.scale_state
         L.check(lib.vmr_adamw(A.flat_p.data_ptr(), A.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                               A.decay.data_ptr(), None if A.flat_w is None else A.flat_w.data_ptr(),
+                              L.BF16 if A.flat_w is None else L.dtype_code(A.flat_w),
                               self.gnorm_sq.data_ptr(), self.max_norm, self.base_lr,
                               self.betas[0], self.betas[1], self.eps, self.wd, 0, self.step_t.data_ptr(),
-                              self.warmup_steps, float(self.total_steps), n, st), "vmr_adamw")
-        A.refresh_transposed()       # K-major weight copies follow the bf16 mirror the kernel just rewrote
-        self.step_t += 1             # scheduler.step() of the reference loop
+                              self.warmup_steps, float(self.total_steps), None if sc is None else sc.data_ptr(), n, st),
+                "vmr_adamw")
+        A.refresh_transposed()       # K-major weight copies follow the 16-bit mirror the kernel just rewrote
+        if sc is None:
+            self.step_t += 1         # scheduler.step() of the reference loop
+        else:                        # the same, unless the step overflowed (then S halves and the count holds)
+            L.check(lib.vmr_loss_scale_update(sc.data_ptr(), self.gnorm_sq.data_ptr(), self.step_t.data_ptr(),
+                                              self.growth_interval, 1.0, st), "vmr_loss_scale_update")
         self.t += 1
         if hasattr(self.model, "_cache"):   # the masters changed under the compute-dtype weight cache
             self.model._cache.clear()
 
     def grad_norm(self) -> float:
-        return float(self.gnorm_sq.sqrt().item())
+        """the (unscaled) global gradient norm of the last step; inf / nan if that step overflowed and was skipped"""
+        g = float(self.gnorm_sq.sqrt().item())
+        return g if self.scale_state is None else g / self._last_scale()
+
+    def _last_scale(self) -> float:
+        return float(self.scale_state[0].item())
+
+    def loss_scale(self) -> float:
+        """current loss scale S (1.0 when scaling is off); a device read"""
+        return 1.0 if self.scale_state is None else self._last_scale()
+
+    def scaled(self, loss: torch.Tensor) -> torch.Tensor:
+        """S * loss with S read on the device (graph-capturable); the loss itself when scaling is off"""
+        if self.init_scale <= 0:
+            return loss
+        if self.scale_state is None:        # first pass, before the arena exists
+            self.scale_state = torch.tensor([self.init_scale, 0.0], device=loss.device, dtype=torch.float32)
+        return loss * self.scale_state[0]
+
+    def backward(self, loss: torch.Tensor, run=None):
+        """loss.backward() with the loss scale applied.  `run`: a callable that runs the backward pass for the given
+        (scaled) loss -- e.g. model.segmented_backward -- default .backward()."""
+        loss = self.scaled(loss)
+        return loss.backward() if run is None else run(loss)

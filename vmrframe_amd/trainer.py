@@ -49,13 +49,29 @@ class GraphedTrainStep:
         self.opt.zero_grad()
         return self.engine(self.model, self.static_batch, self.cfg, "train")
 
+    def _backward(self, loss):
+        """The whole backward pass in one go.  With stage cuts armed (`model.backward_cuts`) a plain `loss.backward()`
+        would stop at the last stage's cut and leave every earlier stage without gradients: resume through the model's
+        own segmented pass.  The optimizer applies its loss scale (fp16 models) on the way in."""
+        m = self.model
+        run = m.segmented_backward if (getattr(m, "backward_cuts", False) and hasattr(m, "segmented_backward")) else None
+        if hasattr(self.opt, "backward"):
+            self.opt.backward(loss, run=run)
+        elif run is not None:
+            run(loss)
+        else:
+            loss.backward()
+
+    def _scaled(self, loss):
+        return self.opt.scaled(loss) if hasattr(self.opt, "scaled") else loss
+
     def _eager_step(self):
         loss, out = self._forward()
         if self.reducer is not None:
-            self.reducer.backward(loss)
+            self.reducer.backward(self._scaled(loss))
             self.reducer.finish()
         else:
-            loss.backward()
+            self._backward(loss)
         self.opt.step()
 
     def capture(self, batch: Dict[str, torch.Tensor]):
@@ -82,7 +98,7 @@ class GraphedTrainStep:
         if not self.split:
             with torch.cuda.graph(g0, stream=s):
                 self.loss, self.out = self._forward()
-                self.loss.backward()
+                self._backward(self.loss)
                 self.opt.step()
             self.pieces = [(g0, [])]
             return self
@@ -91,8 +107,9 @@ class GraphedTrainStep:
         mode = dict(capture_error_mode="thread_local")
         with torch.cuda.graph(g0, stream=s, **mode):
             self.loss, self.out = self._forward()
-            plan = self.model.backward_plan(self.loss) if hasattr(self.model, "backward_plan") else \
-                [(self.loss.backward, list(range(len(self.reducer.ranges()) - 1, -1, -1)))]
+            sl = self._scaled(self.loss)
+            plan = self.model.backward_plan(sl) if hasattr(self.model, "backward_plan") else \
+                [(sl.backward, list(range(len(self.reducer.ranges()) - 1, -1, -1)))]
             plan[0][0]()
         self.pieces = [(g0, plan[0][1])]
         for run, done in plan[1:]:                  # the tape of the earlier stages lives in g0's memory pool
