@@ -184,6 +184,26 @@ int vmr_dwconv_bwd2(const void* du, const void* x, const float* gamma, const flo
                     const float* mean, const float* rstd, const float* w, void* dn, float* dw,
                     float* workspace, int B1, int S1, int B2, int S2, int D, int dtype, void* stream);
 
+/* The row half of one conv-block layer's backward in ONE pass (csrc/convblock.hip; reference layers.py:126-148:
+ * x' = drop(relu(pw(dw7(LN(x))) + b)) + x).  Given du = the gradient of u = dw7(LN(x)) and dres = the gradient of the
+ * layer's output (= the residual branch's gradient) it produces what vmr_dwconv_bwd2 + vmr_layernorm_bwd + the LOWER
+ * layer's vmr_relu_bwd_bias(mode 3) produce in three launches, with the same arithmetic:
+ *   dx = LN-backward(conv^T(du)) + dres;   dz = dx * bit * bscale  (optional: `bits` = the lower layer's
+ *   VMR_EPI_AUX_BITS mask [rows, D/8], bscale = its 1/(1-p));
+ * and leaves ONE partial row per (persistent) workgroup for vmr_colreduce_batched: part_dw [nblocks, 7*D] (item
+ * {part_dw, dw, dw, nblocks, 7*D, 0, 0}) and part_gb [nblocks, 2*D] ({part_gb, dgamma, dbeta, nblocks, D, D, 0}); the
+ * lower layer's bias gradient is colsum(dz): give its weight-gradient product vmr_gemm_t.a_colsum.
+ * *nblocks = vmr_convblock_bwd_blocks(...) <= VMR_CONVBLOCK_BWD_MAX_BLOCKS (one workgroup per CU).  D in {512, 1024}
+ * (vmr_convblock_bwd_supported); other widths take the three separate kernels.  dz and bits are given together or
+ * not at all. */
+#define VMR_CONVBLOCK_BWD_MAX_BLOCKS 1024
+int vmr_convblock_bwd_supported(int D, int dtype);
+int vmr_convblock_bwd_blocks(int B1, int S1, int B2, int S2, int D);
+int vmr_convblock_bwd(const void* du, const void* x, const void* dres, const unsigned char* bits, float bscale,
+                      const float* gamma, const float* beta, const float* mean, const float* rstd,
+                      const float* w, void* dx, void* dz, float* part_dw, float* part_gb,
+                      int B1, int S1, int B2, int S2, int D, int dtype, int32_t* nblocks, void* stream);
+
 /* Batched bf16 transpose: dst[c*rows + r] = src[r*cols + c] for every item, one launch per 64 items (the list
  * travels as kernel arguments).  The optimizer keeps a K-major copy of every weight matrix this way, so the input-
  * gradient products dX = dY.W (backward of Conv1D, models/layers.py:15-26) run as row-major-weight products. */

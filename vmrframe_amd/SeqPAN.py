@@ -369,6 +369,14 @@ class SeqPAN(nn.Module):
         """DepthwiseSeparableConvBlock (reference layers.py:139-148): 4 x {LN -> dw conv k7 ->
         pw conv + bias -> ReLU -> dropout -> + residual}; LN+dw is one kernel, the rest is the
         GEMM epilogue."""
+        layers = [(self.P(f"{prefix}.layer_norms.{l}.weight"), self.P(f"{prefix}.layer_norms.{l}.bias"),
+                   self.P(f"{prefix}.depthwise_separable_conv.{l}.0.weight"),
+                   self.P(f"{prefix}.depthwise_separable_conv.{l}.1.weight"),
+                   self.P(f"{prefix}.depthwise_separable_conv.{l}.1.bias")) for l in range(nlayers)]
+        if len(segs) <= 2 and ops.conv_block_fusable(x, layers):
+            # one autograd node for the block: per layer the backward is one merged dX + dW launch and one row kernel
+            # (csrc/convblock.hip); the dropout sites are drawn in the same order as below
+            return ops.conv_block(x, self._cache, segs, 1e-6, [dc.next(f"{prefix}.{l}") for l in range(nlayers)], layers)
         for l in range(nlayers):
             u, x = ops.ln_dwconv(x, self.P(f"{prefix}.layer_norms.{l}.weight"),
                                  self.P(f"{prefix}.layer_norms.{l}.bias"),

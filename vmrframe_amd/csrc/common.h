@@ -279,6 +279,25 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// The same sum on the DPP path: four in-row steps (quad_perm x 2, row_half_mirror, row_mirror: every lane of a 16-lane
+// row then holds its row's sum) and the four rows met through SGPRs (v_readlane) -- about 10 short-latency VALU ops
+// instead of six dependent ds_bpermute round trips through the LDS crossbar (~100 cycles each; __shfl_xor compiles to
+// ds_bpermute_b32 for every distance).  ALL 64 lanes must be active.  The association differs from wave_sum's
+// butterfly, so the two are not bit-interchangeable: the LayerNorm family (norm.hip, convblock.hip) uses this one
+// throughout.  The result is wave-uniform (it lives in SGPRs).
+template <int CTRL> __device__ __forceinline__ float dpp_get(float v) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_get<0xB1>(v);    // quad_perm:[1,0,3,2]
+  v += dpp_get<0x4E>(v);    // quad_perm:[2,3,0,1]
+  v += dpp_get<0x141>(v);   // row_half_mirror
+  v += dpp_get<0x140>(v);   // row_mirror
+  const uint32_t u = __float_as_uint(v);
+  const float r0 = __uint_as_float(__builtin_amdgcn_readlane(u, 0)), r1 = __uint_as_float(__builtin_amdgcn_readlane(u, 16));
+  const float r2 = __uint_as_float(__builtin_amdgcn_readlane(u, 32)), r3 = __uint_as_float(__builtin_amdgcn_readlane(u, 48));
+  return (r0 + r1) + (r2 + r3);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

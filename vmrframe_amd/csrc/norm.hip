@@ -38,7 +38,7 @@ __device__ __forceinline__ void row_stats(const float (&v)[MAXC][8], int D, int 
   for (int c = 0; c < MAXC; ++c)
 #pragma unroll
     for (int e = 0; e < 8; ++e) s += v[c][e];
-  mean = wave_sum(s) / (float)D;
+  mean = wave_sum_dpp(s) / (float)D;
   float q = 0.f;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
@@ -48,7 +48,7 @@ __device__ __forceinline__ void row_stats(const float (&v)[MAXC][8], int D, int 
       for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
     }
   }
-  rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  rstd = rsqrtf(wave_sum_dpp(q) / (float)D + eps);
 }
 
 // ------------------------------------------------------------ LayerNorm fwd
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         s2 += dh * h;
       }
     }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
+    s1 = wave_sum_dpp(s1) / (float)D;
+    s2 = wave_sum_dpp(s2) / (float)D;
     float o[MAXC][8];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {

@@ -1342,6 +1342,137 @@ def ln_dwconv(x, gamma, beta, w, eps, segs, tee=False, cache=None):
 
 
 # ---------------------------------------------------------------------------
+# the whole DepthwiseSeparableConvBlock as ONE autograd node (fused row-kernel backward)
+# ---------------------------------------------------------------------------
+FUSED_CONV_BLOCK = os.environ.get("VMR_FUSED_CONVBLOCK", "1") != "0"
+
+
+def conv_block_fusable(x, layers) -> bool:
+    """True when `conv_block` can take the one-node path: 16-bit activations of a width the fused backward kernel is
+    built for, every parameter's gradient slot in the flat arena (so all parameter gradients accumulate in place and
+    their column reductions are deferred), and K-major weight copies for the dX products."""
+    if not (FUSED_CONV_BLOCK and DEFER_COLREDUCE and MERGE_DX_DW and USE_SLABS and AUX_BITS and DW_SIDE_STREAM is None):
+        return False
+    if not (x.is_cuda and x.dim() == 2 and L.is_16bit(x.dtype) and torch.is_grad_enabled()):
+        return False
+    D = x.shape[1]
+    if not L.lib().vmr_convblock_bwd_supported(D, L.dtype_code(x)):
+        return False
+    for (g, b, dw, pw, pb) in layers:
+        if any(main_grad(p) is None for p in (g, b, dw, pw, pb)):
+            return False
+        if tuple(pw.shape[:2]) != (D, D) or WeightCache.get_t([pw], x.dtype) is None:
+            return False
+    # the pointwise products must land on a kernel whose epilogue writes the ReLU / dropout mask as bits
+    probe = L.GemmDesc()
+    probe.lda = probe.ldb = probe.ldc = probe.ldr = D
+    probe.M, probe.N, probe.K, probe.transA, probe.transB = x.shape[0], D, D, 0, 0
+    probe.dtype, probe.Z1, probe.Z2, probe.splitk = L.dtype_code(x), 1, 1, 1
+    probe.flags = L.EPI_BIAS | L.EPI_RELU | L.EPI_RESIDUAL
+    p0 = layers[0]
+    probe.A = probe.C = probe.residual = x.data_ptr()
+    probe.B = p0[3].data_ptr()
+    probe.bias = p0[4].data_ptr()
+    return bool(L.lib().vmr_gemm_aux_bits_supported(C.byref(probe)))
+
+
+class _ConvBlock(torch.autograd.Function):
+    """n x { u = dw7(LN(x)); x <- drop(relu(u.W^T + b)) + x }  (reference DepthwiseSeparableConvBlock, layers.py:126-148)
+    as ONE autograd node.  Forward = the same two launches per layer as `ln_dwconv` + `linear` (LN + dw conv, then
+    the product with its bias / ReLU / dropout / residual / bit-mask epilogue).  Backward per layer: ONE merged
+    dX + dW launch (the bias gradient rides on the dW product, vmr_gemm_t.a_colsum) and ONE vmr_convblock_bwd launch
+    (conv backward + LayerNorm backward + residual gradient + the LOWER layer's ReLU / dropout mask) -- the dn, dy
+    round trips and the relu_bwd_bias launch of every layer but the top one are gone.  Needs `conv_block_fusable`."""
+
+    @staticmethod
+    def forward(ctx, x, cache, segs, eps, drops, *params):
+        L.require_gpu(x)
+        x = x.contiguous()
+        rows, D = x.shape
+        assert rows == sum(b * s for b, s in segs) and len(segs) <= 2 and len(params) % 5 == 0
+        nl = len(params) // 5
+        lib, st, dt = L.lib(), L.stream_ptr(), L.dtype_code(x)
+        (B1, S1), (B2, S2) = segs[0], (segs[1] if len(segs) > 1 else (0, 0))
+        saved, scales = [], []
+        for l in range(nl):
+            g, b, dw, pw, pb = params[5 * l:5 * l + 5]
+            drop = drops[l]
+            u = torch.empty_like(x)
+            mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            w2 = dw.detach().reshape(D, 7)
+            L.check(lib.vmr_ln_dwconv_fwd2(x.data_ptr(), g.data_ptr(), b.data_ptr(), eps, w2.data_ptr(), u.data_ptr(),
+                                           mean.data_ptr(), rstd.data_ptr(), B1, S1, B2, S2, D, dt, st), "vmr_ln_dwconv_fwd2")
+            W = cache.get([pw], x.dtype, D)
+            y = torch.empty_like(x)
+            bits = torch.empty(rows, D // 8, device=x.device, dtype=torch.uint8)
+            flags = L.EPI_BIAS | L.EPI_RELU | L.EPI_RESIDUAL | L.EPI_AUX | L.EPI_AUX_BITS | (L.EPI_DROPOUT if drop[0] > 0 else 0)
+            gemm(u, W, y, rows, D, D, 0, 0, D, W.stride(0), D, dtype=dt, flags=flags, bias=pb, residual=x, aux=bits, ldr=D,
+                 drop=drop)
+            saved += [x, u, mean, rstd, bits]
+            scales.append(1.0 / (1.0 - drop[0]) if drop[0] > 0 else 1.0)
+            x = y
+        ctx.save_for_backward(*saved)
+        ctx.params, ctx.meta, ctx.state = params, (segs, nl, scales), cache.state
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        segs, nl, scales = ctx.meta
+        saved, params, state = ctx.saved_tensors, ctx.params, ctx.state
+        lib, st = L.lib(), L.stream_ptr()
+        dy = dy.contiguous()
+        rows, D = dy.shape
+        dt = L.dtype_code(dy)
+        (B1, S1), (B2, S2) = segs[0], (segs[1] if len(segs) > 1 else (0, 0))
+        nbmax = lib.vmr_convblock_bwd_blocks(B1, S1, B2, S2, D)
+        # top layer: its mask is applied here (no fused kernel above it); the bias gradient rides on the dW product
+        dz = torch.empty_like(dy)
+        L.check(lib.vmr_relu_bwd_bias(3, dy.data_ptr(), saved[5 * (nl - 1) + 4].data_ptr(), dz.data_ptr(), None, rows, D, D,
+                                      scales[nl - 1], dt, 0.0, 0, None, None, 1.0, st), "vmr_relu_bwd_bias")
+        for l in range(nl - 1, -1, -1):
+            x, u, mean, rstd, _ = saved[5 * l:5 * l + 5]
+            g, b, dw, pw, pb = params[5 * l:5 * l + 5]
+            # dX = dz . Wt^T held back, launched with dW = dz^T . u (split-K slabs; + the previous layer's slab reduction)
+            Wt = WeightCache.get_t([pw], dz.dtype)
+            du, held = mm(dz, Wt, 0, 0, hold=True)
+            merged = _cdiv(rows, 160) * _cdiv(D, 128) <= 512
+            sk = splitk_for(D, D, rows, SPLITK_TARGET_MERGED if merged else 0)
+            wgrad = main_grad(pw).view(D, D)
+            if sk > 1:
+                ws = torch.empty(sk, D, D, device=dy.device, dtype=torch.float32)
+                gemm(dz, u, ws, D, D, rows, 1, 1, D, D, D, dtype=dt, flags=L.EPI_SLAB, splitk=sk, a_colsum=main_grad(pb),
+                     held=held, state=state)
+                state.reduce_later(ws, wgrad, sk, D * D, D, D)
+            else:
+                gemm(dz, u, wgrad, D, D, rows, 1, 1, D, D, D, dtype=dt, flags=L.EPI_ACCUM, splitk=1, a_colsum=main_grad(pb),
+                     held=held)
+            dx = torch.empty_like(dy)
+            dzn = torch.empty_like(dy) if l > 0 else None
+            part_dw = torch.empty(nbmax, 7 * D, device=dy.device, dtype=torch.float32)
+            part_gb = torch.empty(nbmax, 2 * D, device=dy.device, dtype=torch.float32)
+            nb = C.c_int32(0)
+            L.check(lib.vmr_convblock_bwd(du.data_ptr(), x.data_ptr(), dy.data_ptr(),
+                                          saved[5 * (l - 1) + 4].data_ptr() if l > 0 else None,
+                                          scales[l - 1] if l > 0 else 1.0, g.data_ptr(), b.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), dw.detach().reshape(D, 7).data_ptr(), dx.data_ptr(), _ptr(dzn),
+                                          part_dw.data_ptr(), part_gb.data_ptr(), B1, S1, B2, S2, D, dt, C.byref(nb), st),
+                    "vmr_convblock_bwd")
+            mdw = main_grad(dw).view(D * 7)
+            state.defer_colreduce(part_dw, mdw, mdw, nb.value, 7 * D, 0, 0)
+            state.defer_colreduce(part_gb, main_grad(g), main_grad(b), nb.value, D, D, 0)
+            dy, dz = dx, dzn
+        return (dy, None, None, None, None) + (None,) * len(params)
+
+
+def conv_block(x, cache, segs, eps, drops, layers):
+    """layers: per layer (LN gamma, LN beta, depthwise weight [D,1,7], pointwise weight [D,D,1], pointwise bias);
+    drops: per layer dropout triple (DropCtx.next).  Call only when conv_block_fusable(x, layers)."""
+    flat = [p for lay in layers for p in lay]
+    return _ConvBlock.apply(x, cache, tuple(segs), eps, tuple(drops), *flat)
+
+
+# ---------------------------------------------------------------------------
 # attention cores: batched MFMA GEMMs + the masked softmax kernel
 # ---------------------------------------------------------------------------
 def _softmax_fwd(S, R, Cc, ldP, rmask, cmask, mode, H, cm_stride, scale, dtype, drop):
