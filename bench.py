@@ -133,8 +133,17 @@ def synth(a, seed):
     return S.synth_batch(a["B"], a["T"], a["L"], a["V"], a["num_words"], a["num_chars"], C=a["C"], seed=seed)
 
 
+# A timed launch is issued REPS times back to back between ONE event pair: in the eager instrumented steps the GPU sits
+# idle before every launch and an event pair around a single 30-70 us kernel reads 8-15 us long (round 2: 78 us between
+# events against 63 us in the rocprofv3 trace of the replayed graph); back to back the launch gaps are those of the
+# graph replay.  The products are pure functions of their operands; the merged launches additionally ACCUMULATE (the
+# ridden slab reduction, the bias column sums), so the gradients of the two instrumented steps -- taken after the timed
+# region and after the reported loss -- are over-counted, which nothing reads.
+TIMER_REPS = 3
+
+
 class GemmTimer:
-    """HIP events around every launch of the dominant kernel (the NT bf16 MFMA GEMM) on the
+    """HIP events around every launch of the forward x.W^T kernel (the NT bf16 MFMA GEMM) on the
     stream it is launched on; achieved TFLOP/s = sum(flops) / sum(event time)."""
 
     def __init__(self):
@@ -147,14 +156,15 @@ class GemmTimer:
             return launch()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        launch()
+        for _ in range(TIMER_REPS):
+            launch()
         e.record()
         self.records.append((s, e, 2.0 * M * N * K * Z, 2.0 * (M * K + N * K + M * N)))
 
     def summary(self):
         if not self.records:
             return None
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records) / TIMER_REPS
         fl = sum(r[2] for r in self.records)
         return {"launches": len(self.records), "ms_total": ms, "tflops": fl / (ms * 1e-3) / 1e12,
                 "avg_us": ms * 1e3 / len(self.records), "flops_per_launch": fl / len(self.records),
@@ -171,14 +181,15 @@ class Gemm2Timer:
     def __call__(self, launch, flops, nbytes):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        launch()
+        for _ in range(TIMER_REPS):
+            launch()
         e.record()
         self.records.append((s, e, flops, nbytes))
 
     def summary(self):
         if not self.records:
             return None
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records) / TIMER_REPS
         fl = sum(r[2] for r in self.records)
         return {"launches": len(self.records), "ms_total": ms, "tflops": fl / (ms * 1e-3) / 1e12,
                 "avg_us": ms * 1e3 / len(self.records), "flops_per_launch": fl / len(self.records),
@@ -195,7 +206,7 @@ def cpu_model_name() -> str:
     return "unknown CPU"
 
 
-def cpu_baseline(a):
+def cpu_baseline(a, B=16, n=3):
     """The oracle (CPU fp32 restatement of the reference, kind 'port') timed on the host cores on a BOUNDED sample of
     the same workload: cfg2 shapes at B = 16 clips, one warm-up + three timed train steps (fwd + losses + bwd + clip +
     AdamW, dropout on).  B = 64 itself takes 44 s per step on 8 cores of the build container (1.44 clips/s; the
@@ -210,7 +221,7 @@ def cpu_baseline(a):
         cores = os.cpu_count() or 1
     cores = max(1, min(16, cores))
     torch.set_num_threads(cores)
-    b = dict(a); b["B"] = 16
+    b = dict(a); b["B"] = B
     cfg = make_cfg(b, "fp32")
     weights = R.make_weights(cfg, 5)
     P = R.to_params(weights, requires_grad=True)
@@ -231,13 +242,12 @@ def cpu_baseline(a):
     step()
     print("[bench] cpu_baseline warm-up done", file=sys.stderr, flush=True)
     t0 = time.time()
-    n = 3
     for _ in range(n):
         step()
     dt = (time.time() - t0) / n
     return {"value": b["B"] / dt, "unit": "clips/sec", "cores": cores, "kind": "port", "cpu": cpu_model_name(),
             "sample": f"oracle/seqpan_ref.py fp32 train step (fwd+losses+bwd+clip+AdamW, dropout on) at cfg2 "
-                      f"shapes with B=16 clips, mean of {n} steps after 1 warm-up ({dt:.2f} s/step) on {cores} threads of "
+                      f"shapes with B={B} clips, mean of {n} step(s) after 1 warm-up ({dt:.2f} s/step) on {cores} threads of "
                       f"{cpu_model_name()}"}
 
 
@@ -293,11 +303,19 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
                     help="compute dtype (fp32 masters either way); fp16 = BASELINE configs[4]'s dtype, wired for --workload ban / banmap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="also time the CPU oracle at the metric's own B = 64 (1 warm-up + 1 step: about a minute on 16 cores)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of whole-step hipGraph replay")
     ap.add_argument("--workload", default="seqpan", choices=["seqpan", "basefast", "banmap", "ban"],
                     help="seqpan = BASELINE configs[1] (headline); basefast = configs[3] (T=256); banmap = the BAN "
                          "proposal-map stage of configs[4]; ban = the whole BAN train step of configs[4] (eager)")
     ap.add_argument("--selftest-launcher", action="store_true", help="rendezvous + one gloo all-reduce per rank, no GPU")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="reduce-scatter + AdamW on the local 1/N slices + all-gather of the 16-bit mirrors (dp.ShardedReducer) "
+                         "instead of all-reduce + replicated AdamW")
+    ap.add_argument("--force-split", action="store_true",
+                    help="at --gpus 1: replay the multi-rank form of the step (one graph per backward stage + the optimizer "
+                         "graph(s), reducer hand-over points on the host in between) so its host-hop cost is measured")
     ap.add_argument("--reduce-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="wire dtype of the gradient all-reduce (N > 1); fp32 = exact sum")
     args = ap.parse_args()
@@ -353,7 +371,13 @@ def main():
     total_steps = args.steps + args.warmup
     opt = FlatAdamW(model, lr=1e-4, weight_decay=0.01, max_norm=1.0, warmup_steps=0.0 * total_steps,
                     total_steps=10 * total_steps)
-    reducer = dp.GradReducer(model, opt, reduce_dtype=torch.bfloat16 if args.reduce_dtype == "bf16" else torch.float32)
+    if args.shard_optimizer:
+        reducer = dp.ShardedReducer(model, opt)
+    else:
+        reducer = dp.GradReducer(model, opt, reduce_dtype=torch.bfloat16 if args.reduce_dtype == "bf16" else torch.float32)
+    split = world > 1 or args.force_split
+    if split and hasattr(model, "backward_plan"):
+        model.backward_cuts = True
     if args.workload == "banmap":
         gen = torch.Generator().manual_seed(1234 + rank)
         batch = {"hidden_b": torch.relu(torch.randn(a["B"], a["N"], a["F"], generator=gen)).to(dev),   # post-ReLU features
@@ -378,7 +402,8 @@ def main():
     else:
         # one captured HIP graph per step (vmrframe_amd/trainer.py): the eager loop is launch-bound
         from vmrframe_amd.trainer import GraphedTrainStep
-        gstep = GraphedTrainStep(model, opt, engine, cfg, reducer if world > 1 else None, warmup=3).capture(batch)
+        gstep = GraphedTrainStep(model, opt, engine, cfg, reducer if split else None, warmup=3,
+                                 force_split=args.force_split).capture(batch)
         step = gstep
         for _ in range(args.warmup):
             loss = step()
@@ -490,9 +515,14 @@ def main():
                           "global_batch": a["B"] * world, "parallelism": f"dp{world}"},
                "step_mfma_frac": round(value * TRAIN_GFLOP_PER_CLIP * 1e9 / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
                "final_loss": round(final_loss, 4), "hipgraph": not args.no_graph,
+               "step_form": ("sharded-optimizer " if args.shard_optimizer else "") +
+                            ("piecewise graphs (multi-rank form)" if split and not args.no_graph else "one graph"),
                "dist": None if world == 1 else {"backend": dist.get_backend(), "world_observed": dist.get_world_size(),
                                                 "reduce_dtype": args.reduce_dtype,
-                                                "overlap": "stage-cut backward, one all-reduce per stage range"},
+                                                "overlap": ("stage-cut backward; per stage: reduce-scatter of the matrix region + "
+                                                            "all-reduce of the fp32 region; AdamW on the local slices; all-gather "
+                                                            "of the 16-bit mirrors") if args.shard_optimizer else
+                                                           "stage-cut backward, one all-reduce per stage range"},
                "roofline": roofline, "roofline_second": roofline2}
         if cq_rec:
             # the CQAttention score kernel (north-star "attention score/softmax/context-gather"): algorithmic
@@ -518,7 +548,7 @@ def main():
             t_apply = sum(r[0].elapsed_time(r[1]) for r in fw) / len(fw) * 1e-3
             t_score = sum(r[0].elapsed_time(r[1]) / CQ_REPS for r in cq_rec if r[3] == Lc_) / max(1, sum(1 for r in cq_rec if r[3] == Lc_)) * 1e-3
             cqa = [r for r in timer.records if abs(r[2] - 2.0 * B_ * Lc_ * 4 * D_ * D_) < 1.0]        # [B*T, D, 4D] products
-            t_lin = sum(r[0].elapsed_time(r[1]) for r in cqa) / max(1, len(cqa)) * 1e-3 if cqa else float("nan")
+            t_lin = sum(r[0].elapsed_time(r[1]) / TIMER_REPS for r in cqa) / max(1, len(cqa)) * 1e-3 if cqa else float("nan")
             flops = B_ * (2.0 * Lc_ * 4 * D_ * D_ + 3 * 2.0 * Lc_ * Lq_ * D_ + 2.0 * Lc_ * Lq_ * D_)
             nbytes = B_ * ((Lc_ + Lq_) * D_ * 2 + Lc_ * D_ * 2)
             t_all = t_score + t_apply + t_lin
@@ -537,6 +567,8 @@ def main():
             out["step_mfma_frac"] = None     # the 58 GFLOP/clip figure is SeqPAN's
         if world == 1 and not args.no_cpu_baseline and args.workload == "seqpan":
             out["cpu_baseline"] = cpu_baseline(a)
+            if args.cpu_baseline_full:     # BASELINE.md's 1.42 clips/s (the reference itself, 8 Xeon cores) is THIS batch size
+                out["cpu_baseline_full"] = cpu_baseline(a, B=a["B"], n=1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

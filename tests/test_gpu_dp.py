@@ -199,3 +199,97 @@ def test_two_ranks_real_model_gradient_average(dev, tmp_path, graph):
     print(f"[2 ranks, graph={graph}] averaged arena vs mean of shard gradients: rel {r_:.3e}")
     assert r_ < 5e-2                                                    # bf16 forward noise; a missing average is 0.5-1
     assert torch.equal(got[0]["w"], m.P("dual_attention_block_1.dense_1.conv1d.weight").detach().cpu())
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# reduce-scatter + sharded FlatAdamW + all-gather of the mirrors (dp.ShardedReducer) against all-reduce + replicated AdamW
+# --------------------------------------------------------------------------------------------------------------------
+def _rank_sharded(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import vmrframe_amd as V
+    from vmrframe_amd import dp
+    from vmrframe_amd.optim import FlatAdamW
+    from vmrframe_amd.trainer import GraphedTrainStep
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dp.init_process_group_from_env("gloo")
+    m, cfg, batch, g, weights = _build("g_cfg1", "bf16", dev)      # D = 512: the projections are GEMM matrices (>= 64 wide)
+    dp.broadcast_parameters(m)
+    shard = {k: v.to(dev) for k, v in dp.shard_batch(batch, rank, world).items()}
+    m.gumbel_override = g[rank::world].to(dev)
+    m.backward_cuts = True
+    # max_norm far above the gradient norm: the clip factor is exactly 1 on both paths (the two paths add the squares in
+    # different orders, so an ACTIVE clip would differ in the last bit)
+    opt = FlatAdamW(m, lr=1e-3, weight_decay=0.01, max_norm=1e9)
+    ar = dp.GradReducer(m, opt)
+    loss, _ = V.train_engine_SeqPAN(m, shard, cfg, "train")
+    opt.zero_grad(); ar.backward(loss); ar.finish(); opt.step()            # builds the arenas
+    A = opt.arena
+    sh = dp.ShardedReducer(m, opt)
+    opt.shard = None
+    nst = len(A.segment_split)
+    assert all(lo % 64 == 0 and mid % 64 == 0 and hi % 64 == 0 for lo, mid, hi in A.segment_split)
+    mat = sum(mid - lo for lo, mid, _ in A.segment_split)
+    assert mat > 0.9 * A.flat_p.numel()                                    # the GEMM weights are the arena
+    for n in m.fp32_consumed():
+        st = m.param_segment(n)
+        assert A.segment_split[st][1] <= A.offsets[n] < A.segment_split[st][2], n
+    res = {}
+    for it in range(2):
+        loss, _ = V.train_engine_SeqPAN(m, shard, cfg, "train")
+        opt.zero_grad()
+        m.segmented_backward(loss)
+        m._cache.state.flush_reduce(); m._cache.state.flush_colreduce()
+        torch.cuda.synchronize()
+        snap = [t.clone() for t in (A.flat_g, A.flat_p, A.flat_w, A.flat_wt, opt.m, opt.v, opt.step_t)]
+        host_t = opt.t
+        # path A
+        opt.shard = None
+        for i in range(nst - 1, -1, -1):
+            ar.stage_done(i)
+        ar.finish(); opt.step()
+        torch.cuda.synchronize()
+        wA, wtA, pA, mA, vA = A.flat_w.clone(), A.flat_wt.clone(), A.flat_p.clone(), opt.m.clone(), opt.v.clone()
+        # path B from the same state and the same local gradients
+        for dst, src in zip((A.flat_g, A.flat_p, A.flat_w, A.flat_wt, opt.m, opt.v, opt.step_t), snap):
+            dst.copy_(src)
+        opt.t = host_t
+        opt.shard = sh
+        for i in range(nst - 1, -1, -1):
+            sh.stage_done(i)
+        sh.finish(); opt.step()
+        torch.cuda.synchronize()
+        assert torch.equal(A.flat_w, wA) and torch.equal(A.flat_wt, wtA), it      # what every rank computes with
+        for lo, hi in sh.my_slices() + sh.fp32_regions():
+            assert torch.equal(A.flat_p[lo:hi], pA[lo:hi]), (it, lo, hi)
+        for lo, hi in sh.my_slices() + sh.fp32_regions():          # Adam moments: kept for the own slices only
+            assert torch.equal(opt.m[lo:hi], mA[lo:hi]) and torch.equal(opt.v[lo:hi], vA[lo:hi]), (it, lo, hi)
+        sh.gather_masters()
+        assert torch.equal(A.flat_p, pA), it
+        opt.m.copy_(mA); opt.v.copy_(vA)     # (the next round's path A needs the moments of every slice)
+        res[it] = A.flat_w.cpu()
+    # the captured multi-rank step with the sharded optimizer: three optimizer graphs around two exchanges
+    step = GraphedTrainStep(m, opt, V.train_engine_SeqPAN, cfg, sh, warmup=2).capture(shard)
+    assert step.sharded and len(step.g_parts) == 3 and step.g_opt is None
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    torch.save({"w": res, "wg": A.flat_w.cpu(), "logits": step.out["slogits"].float().cpu()}, os.path.join(outdir, f"sh{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_sharded_optimizer_equals_all_reduce(dev, tmp_path):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_sharded, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(500)
+        assert p.exitcode == 0
+    got = [torch.load(os.path.join(tmp_path, f"sh{r}.pt")) for r in range(2)]
+    for it in (0, 1):
+        assert torch.equal(got[0]["w"][it], got[1]["w"][it])           # the same mirrors on both ranks
+    assert torch.equal(got[0]["wg"], got[1]["wg"])                     # ... also after the captured steps (lock-step)
+    assert torch.isfinite(got[0]["logits"]).all()

@@ -291,6 +291,12 @@ class SeqPAN(nn.Module):
             out.append([f"{m}.bilinear_{b}.bias_value" for b in (1, 2)])
         return out
 
+    def fp32_consumed(self):
+        """Weight matrices some kernel reads from the fp32 MASTER rather than through the 16-bit mirror: the predictor's
+        positional table (ops.add_pos adds the fp32 rows).  optim.FlatArena keeps them in the all-reduced fp32 region
+        of their stage, so a sharded optimizer (dp.ShardedReducer) leaves a current copy on every rank."""
+        return ["predictor.feature_encoder.pos_embedding.position_embeddings.weight"]
+
     # -- backward segments (data-parallel overlap) ---------------------------------
     SEGMENT_PREFIXES = (("text_encoder.", "video_affine.", "vfeat_encoder."), ("dual_attention_block_1.",),
                         ("dual_attention_block_2.",), ("q2v_attn.", "v2q_attn.", "cq_cat.", "match_conv1d.", "label_embs"),

@@ -160,3 +160,124 @@ class GradReducer:
                 view.div_(self.world)
         self.handles.clear()
         self.reduced.clear()
+
+
+class ShardedReducer(GradReducer):
+    """Reduce-scatter + sharded AdamW + all-gather instead of all-reduce + replicated AdamW.
+
+    optim.FlatArena lays every stage out as [matrix region | fp32 region].  Per finished stage of the backward pass:
+      * the matrix region's gradients (the GEMM weights: 99 % of the arena) are REDUCE-SCATTERED -- rank r ends up with the
+        average of its 1/N slice only, (N-1)/N x bytes on the wire instead of all-reduce's 2(N-1)/N;
+      * the small fp32 region (biases, LayerNorm / depthwise parameters, tables read in fp32) is all-reduced: every rank
+        updates it, so the fp32 masters the kernels read stay current everywhere.
+    FlatAdamW then updates only this rank's slices (1/N of the optimizer's HBM traffic: `opt.step()` runs in three
+    parts with two host hops -- the clip norm needs one scalar all-reduce over the ranks' partial sums of squares) and the
+    16-bit mirrors of the matrix regions are ALL-GATHERED (half the bytes of the gradients) before the K-major copies are
+    refreshed.  fp32 masters of foreign slices go stale by design: `gather_masters()` before a checkpoint.
+
+    Results: the mirrors every rank computes with, and the owner's masters, are bit-identical to the all-reduce path
+    whenever the backend's reduce-scatter and all-reduce add in the same order (always at world size 2).
+    World sizes must divide 64 / 8 (2, 4, 8): the regions are padded to 64 elements."""
+
+    def __init__(self, model, optimizer, reduce_dtype: torch.dtype = torch.float32):
+        super().__init__(model, optimizer, reduce_dtype)
+        assert reduce_dtype == torch.float32, "the sharded path reduces in fp32 (the gather already moves 16-bit mirrors)"
+        assert self.world in (1, 2, 4, 8), "ShardedReducer: world size must be 1, 2, 4 or 8"
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self._native = None         # does the backend take reduce_scatter_tensor / all_gather_into_tensor on this device?
+        optimizer.shard = self
+
+    # -- layout -------------------------------------------------------------------
+    def split(self):
+        arena = getattr(self.opt, "arena", None)
+        return None if arena is None else arena.segment_split
+
+    def my_slices(self):
+        """[(lo, hi)] of this rank's slice of every stage's matrix region."""
+        out = []
+        for lo, mid, _ in self.split():
+            sz = (mid - lo) // self.world
+            out.append((lo + self.rank * sz, lo + (self.rank + 1) * sz))
+        return out
+
+    def fp32_regions(self):
+        return [(mid, hi) for _, mid, hi in self.split()]
+
+    # -- collectives ----------------------------------------------------------------
+    def _probe(self, like: torch.Tensor):
+        if self._native is None:
+            try:        # (gloo moves CPU tensors through these; with CUDA tensors it may not)
+                a = torch.zeros(8 * self.world, device=like.device)
+                b = torch.zeros(8, device=like.device)
+                dist.reduce_scatter_tensor(b, a, op=dist.ReduceOp.SUM)
+                dist.all_gather_into_tensor(a, b)
+                self._native = True
+            except Exception:
+                self._native = False
+        return self._native
+
+    def stage_done(self, i: int):
+        sp = self.split()
+        if self.world == 1 or sp is None or i >= len(sp) or i in self.reduced:
+            return
+        self.reduced.add(i)
+        lo, mid, hi = sp[i]
+        g = self.opt.grad_arena
+        if mid > lo:
+            sz = (mid - lo) // self.world
+            mine = g[lo + self.rank * sz: lo + (self.rank + 1) * sz]
+            if self._probe(g):
+                if self.avg:        # RCCL: in place (the output is the rank's own slice of the input), averaged by the collective
+                    self.handles.append((dist.reduce_scatter_tensor(mine, g[lo:mid], op=self.op, async_op=True), mine, None))
+                else:
+                    out = torch.empty_like(mine)
+                    self.handles.append((dist.reduce_scatter_tensor(out, g[lo:mid], op=self.op, async_op=True), mine, out))
+            else:                   # no reduce-scatter for this device in the backend: the same sums through all-reduce
+                self.handles.append((dist.all_reduce(g[lo:mid], op=self.op, async_op=True), g[lo:mid], None))
+        if hi > mid:
+            self.handles.append((dist.all_reduce(g[mid:hi], op=self.op, async_op=True), g[mid:hi], None))
+        self.launch_log.append(i)
+
+    def finish(self):
+        if self.world == 1:
+            return
+        if self.split() is None:
+            return super().finish()         # first step, no arena yet: one coalesced all-reduce
+        for i in range(len(self.split()) - 1, -1, -1):
+            self.stage_done(i)
+        for h, view, st in self.handles:
+            h.wait()
+            if st is not None:
+                view.copy_(st)
+            if not self.avg:
+                view.div_(self.world)
+        self.handles.clear()
+        self.reduced.clear()
+
+    def sum_scalar(self, t: torch.Tensor):
+        """partial sums of squares -> their sum over the ranks (the clip norm of the averaged gradient)"""
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def gather(self, flat: torch.Tensor):
+        """All-gather every stage's matrix region of `flat` (the 16-bit mirror arena, or the fp32 masters): each rank
+        contributes its own slice."""
+        if self.world == 1:
+            return
+        hs = []
+        for (lo, mid, _), (a, b) in zip(self.split(), self.my_slices()):
+            if mid == lo:
+                continue
+            if self._probe(flat):
+                src = flat[a:b] if self.avg else flat[a:b].clone()    # (RCCL gathers in place)
+                hs.append(dist.all_gather_into_tensor(flat[lo:mid], src, async_op=True))
+            else:
+                sz = b - a
+                for r in range(self.world):
+                    hs.append(dist.broadcast(flat[lo + r * sz: lo + (r + 1) * sz], r, async_op=True))
+        for h in hs:
+            h.wait()
+
+    def gather_masters(self):
+        """Bring the fp32 masters of the foreign slices up to date (before state_dict() / a checkpoint)."""
+        self.gather(self.opt.arena.flat_p)

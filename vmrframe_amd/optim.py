@@ -53,18 +53,51 @@ class FlatArena:
         # the backward pass is ONE contiguous range that data-parallel ranks can all-reduce while earlier stages run
         seg_of = (lambda n: model.param_segment(n)) if hasattr(model, "param_segment") else (lambda n: 0)
         nseg = 1 + max(seg_of(n) for n, _ in named)
-        order = []
+        # Within a stage: first the weight MATRICES that are consumed only through their 16-bit mirror / K-major copy (the
+        # GEMM operands: the members of the transposed set below), then everything the kernels read in fp32 (biases,
+        # LayerNorm and depthwise-conv parameters, small tables, model.fp32_consumed()).  A sharded optimizer
+        # (dp.ShardedReducer) reduce-scatters the first region and all-gathers its mirror; the second, small region is
+        # all-reduced and updated by every rank.  Region ends are padded to 64 elements, so a region splits evenly
+        # (into 16-byte aligned shards) over 2, 4 or 8 ranks.  Without a mirror every parameter is fp32-consumed.
+        fp32_names = set(model.fp32_consumed()) if hasattr(model, "fp32_consumed") else set()
+
+        def gemm_matrix(q):
+            return q.dim() >= 2 and min(q.shape[0], q.numel() // q.shape[0]) >= 64 and q.numel() % 8 == 0
+
+        def is_mat(names):
+            if mirror_dtype is None or any(n in fp32_names for n in names):
+                return False
+            ps = [have[n] for n in names]
+            if len(ps) > 1:      # a grouped projection: one [sum N, K] matrix
+                K = ps[0].numel() // ps[0].shape[0]
+                return all(q.dim() >= 2 and q.numel() // q.shape[0] == K and q.numel() % 8 == 0 for q in ps) and \
+                    min(sum(q.shape[0] for q in ps), K) >= 64
+            return gemm_matrix(ps[0])
+
+        plan = []      # (stage, [units of the matrix region], [units of the fp32 region]); unit = list of names kept adjacent
         for sg in range(nseg):
-            first = [n for grp in groups if all(g in have for g in grp) and seg_of(grp[0]) == sg for n in grp]
-            assert all(seg_of(n) == sg for n in first), "a weight group straddles two stages"
-            seen = set(first)
-            order += first + [n for n, _ in named if seg_of(n) == sg and n not in seen]
-        named = [(n, have[n]) for n in order]
+            units = [list(grp) for grp in groups if all(g in have for g in grp) and seg_of(grp[0]) == sg]
+            assert all(seg_of(n) == sg for u in units for n in u), "a weight group straddles two stages"
+            seen = {n for u in units for n in u}
+            units += [[n] for n, _ in named if seg_of(n) == sg and n not in seen]
+            plan.append((sg, [u for u in units if is_mat(u)], [u for u in units if not is_mat(u)]))
         dev = named[0][1].device
         total, offs = 0, {}
-        for n, p in named:
-            offs[n] = total
-            total += (p.numel() + 7) // 8 * 8            # 16-byte aligned slots in the fp32 AND the bf16 arena
+        self.segment_split = []        # per stage: (lo, mid, hi) = matrix region [lo, mid), fp32 region [mid, hi)
+        order = []
+        for sg, mats, vecs in plan:
+            lo = total
+            for region in (mats, vecs):
+                for u in region:
+                    for n in u:
+                        offs[n] = total
+                        total += (have[n].numel() + 7) // 8 * 8        # 16-byte aligned slots in the fp32 AND the bf16 arena
+                        order.append(n)
+                total = (total + 63) // 64 * 64
+                if region is mats:
+                    mid = total
+            self.segment_split.append((lo, mid, total))
+        named = [(n, have[n]) for n in order]
         self.flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros_like(self.flat_p)
         self.decay = torch.zeros(total, device=dev, dtype=torch.uint8)
@@ -81,14 +114,8 @@ class FlatArena:
         self.params = [p for _, p in named]
         self.offsets = offs
         # [lo, hi) of every stage inside the arenas (empty stages: lo == hi)
-        self.segment_ranges = []
-        lo = 0
-        for sg in range(nseg):
-            mine = [n for n in self.names if seg_of(n) == sg]
-            hi = (offs[mine[-1]] + (have[mine[-1]].numel() + 7) // 8 * 8) if mine else lo
-            self.segment_ranges.append((lo, hi))
-            lo = hi
-        assert lo == total
+        self.segment_ranges = [(lo, hi) for lo, _, hi in self.segment_split]
+        assert self.segment_ranges[-1][1] == total and all(a[1] == b[0] for a, b in zip(self.segment_ranges[:-1], self.segment_ranges[1:]))
         self.flat_w = None
         self._t_count = 0
         if mirror_dtype is not None:
@@ -102,17 +129,15 @@ class FlatArena:
             # batched transpose launch (refresh_transposed): the dX products then read weights k-contiguously
             self.flat_wt = torch.zeros_like(self.flat_w)
             items = []
-            grouped = set()
-            for grp in groups:
-                if all(g in have for g in grp) and len(grp) > 1:
-                    ps = [have[g] for g in grp]
-                    K = ps[0].numel() // ps[0].shape[0]
-                    if all(q.dim() >= 2 and q.numel() // q.shape[0] == K and q.numel() % 8 == 0 for q in ps):
-                        items.append((grp[0], ps, sum(q.shape[0] for q in ps), K))
-                        grouped.update(grp)
-            for n, p in named:
-                if n not in grouped and p.dim() >= 2 and min(p.shape[0], p.numel() // p.shape[0]) >= 64:
-                    items.append((n, [p], p.shape[0], p.numel() // p.shape[0]))
+            for sg, mats, vecs in plan:
+                for u in mats + vecs:
+                    ps = [have[n] for n in u]
+                    if len(ps) > 1:
+                        K = ps[0].numel() // ps[0].shape[0]
+                        if all(q.dim() >= 2 and q.numel() // q.shape[0] == K and q.numel() % 8 == 0 for q in ps):
+                            items.append((u[0], ps, sum(q.shape[0] for q in ps), K))
+                    elif ps[0].dim() >= 2 and min(ps[0].shape[0], ps[0].numel() // ps[0].shape[0]) >= 64:
+                        items.append((u[0], ps, ps[0].shape[0], ps[0].numel() // ps[0].shape[0]))
             self._t_items = (L.TransposeItem * len(items))()
             for it, (n0, ps, rows, cols) in zip(self._t_items, items):
                 o = offs[n0]
@@ -176,6 +201,7 @@ class FlatAdamW:
         self.m = self.v = self.gnorm_sq = None
         self.warmup_steps, self.total_steps = float(warmup_steps), int(total_steps)
         self.step_t = None   # device-resident step count: the kernel evaluates the lr schedule from it
+        self.shard = None    # a dp.ShardedReducer registers itself here: step() then updates this rank's slices only
 
     # -- arena -----------------------------------------------------------------
     def _build(self):
@@ -236,28 +262,77 @@ class FlatAdamW:
     def step(self):
         if self.arena is None:
             self._build()
+        sh = self.shard
+        if sh is not None and (sh.world > 1 or getattr(sh, "force", False)):
+            # sharded optimizer (dp.ShardedReducer): three device parts around two exchanges
+            self.step_norm()
+            sh.sum_scalar(self.gnorm_sq)
+            self.step_update()
+            sh.gather(self.arena.flat_w if self.arena.flat_w is not None else self.arena.flat_p)
+            self.step_finish()
+            return
         A = self.arena
         lib, st = L.lib(), L.stream_ptr()
         self.gnorm_sq.zero_()
         n = A.flat_p.numel()
         L.check(lib.vmr_sumsq(A.flat_g.data_ptr(), self.gnorm_sq.data_ptr(), n, st), "vmr_sumsq")
-        sc = self.scale_state
-        L.check(lib.vmr_adamw(A.flat_p.data_ptr(), A.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                              A.decay.data_ptr(), None if A.flat_w is None else A.flat_w.data_ptr(),
-                              L.BF16 if A.flat_w is None else L.dtype_code(A.flat_w),
-                              self.gnorm_sq.data_ptr(), self.max_norm, self.base_lr,
-                              self.betas[0], self.betas[1], self.eps, self.wd, 0, self.step_t.data_ptr(),
-                              self.warmup_steps, float(self.total_steps), None if sc is None else sc.data_ptr(), n, st),
-                "vmr_adamw")
+        self._adamw(0, n)
         A.refresh_transposed()       # K-major weight copies follow the 16-bit mirror the kernel just rewrote
+        self._advance()
+
+    def _adamw(self, lo: int, hi: int):
+        """vmr_adamw over [lo, hi) of the arenas (16-byte aligned bounds)."""
+        if hi <= lo:
+            return
+        A, sc = self.arena, self.scale_state
+        assert lo % 8 == 0
+        L.check(L.lib().vmr_adamw(A.flat_p[lo:].data_ptr(), A.flat_g[lo:].data_ptr(), self.m[lo:].data_ptr(), self.v[lo:].data_ptr(),
+                                  A.decay[lo:].data_ptr(), None if A.flat_w is None else A.flat_w[lo:].data_ptr(),
+                                  L.BF16 if A.flat_w is None else L.dtype_code(A.flat_w),
+                                  self.gnorm_sq.data_ptr(), self.max_norm, self.base_lr,
+                                  self.betas[0], self.betas[1], self.eps, self.wd, 0, self.step_t.data_ptr(),
+                                  self.warmup_steps, float(self.total_steps), None if sc is None else sc.data_ptr(), hi - lo,
+                                  L.stream_ptr()), "vmr_adamw")
+
+    def _advance(self):
+        sc = self.scale_state
         if sc is None:
             self.step_t += 1         # scheduler.step() of the reference loop
         else:                        # the same, unless the step overflowed (then S halves and the count holds)
-            L.check(lib.vmr_loss_scale_update(sc.data_ptr(), self.gnorm_sq.data_ptr(), self.step_t.data_ptr(),
-                                              self.growth_interval, 1.0, st), "vmr_loss_scale_update")
+            L.check(L.lib().vmr_loss_scale_update(sc.data_ptr(), self.gnorm_sq.data_ptr(), self.step_t.data_ptr(),
+                                                  self.growth_interval, 1.0, L.stream_ptr()), "vmr_loss_scale_update")
         self.t += 1
         if hasattr(self.model, "_cache"):   # the masters changed under the compute-dtype weight cache
             self.model._cache.clear()
+
+    # -- the three device parts of a SHARDED step (dp.ShardedReducer; each is capturable on its own) ----------------
+    def step_norm(self):
+        """Part 1: the sum of squares of THIS rank's slices of the averaged gradient (the matrix regions are reduce-
+        scattered: nobody holds them whole); the ranks' partial sums are added by one scalar all-reduce."""
+        if self.arena is None:
+            self._build()
+        lib, st = L.lib(), L.stream_ptr()
+        self.gnorm_sq.zero_()
+        g = self.arena.flat_g
+        for lo, hi in self.shard.my_slices():
+            if hi > lo:
+                L.check(lib.vmr_sumsq(g[lo:].data_ptr(), self.gnorm_sq.data_ptr(), hi - lo, st), "vmr_sumsq")
+
+    def step_update(self):
+        """Part 2 (gnorm_sq now holds the matrix regions' total): add the all-reduced fp32 regions' squares -- every rank
+        holds those whole -- then AdamW on this rank's slices and on the fp32 regions."""
+        lib, st = L.lib(), L.stream_ptr()
+        g = self.arena.flat_g
+        for lo, hi in self.shard.fp32_regions():
+            if hi > lo:
+                L.check(lib.vmr_sumsq(g[lo:].data_ptr(), self.gnorm_sq.data_ptr(), hi - lo, st), "vmr_sumsq")
+        for lo, hi in self.shard.my_slices() + self.shard.fp32_regions():
+            self._adamw(lo, hi)
+        self._advance()
+
+    def step_finish(self):
+        """Part 3 (the mirrors of the foreign slices have been gathered): the K-major weight copies."""
+        self.arena.refresh_transposed()
 
     def grad_norm(self) -> float:
         """the (unscaled) global gradient norm of the last step; inf / nan if that step overflowed and was skipped"""

@@ -21,8 +21,9 @@ With N > 1 ranks the backward pass is cut at the model's stage boundaries
 (SeqPAN.backward_plan) and every piece becomes its own graph: between two replays
 the host hands the finished stage's arena range to RCCL (dp.GradReducer.stage_done),
 so the all-reduce of stage k runs on RCCL's stream under the backward of stage k-1.
-The optimizer is a last graph behind GradReducer.finish().  Collectives are never
-captured.
+The optimizer is a last graph behind GradReducer.finish() -- three graphs around
+two exchanges with dp.ShardedReducer (reduce-scatter + sharded AdamW + all-gather of
+the 16-bit mirrors).  Collectives are never captured.
 """
 from __future__ import annotations
 
@@ -32,7 +33,10 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, engine, configs, reducer=None, warmup: int = 3):
+    def __init__(self, model, optimizer, engine, configs, reducer=None, warmup: int = 3, force_split: bool = False):
+        """force_split: capture the multi-rank form (one graph per backward piece + the optimizer graph(s), with the
+        reducer's hand-over points between the replays) even at world size 1, so that the host hops of the data-
+        parallel path can be timed on one GPU (bench.py --force-split)."""
         self.model, self.opt, self.engine, self.cfg, self.reducer = model, optimizer, engine, configs, reducer
         self.warmup = max(2, warmup)        # >= 2: the flat arena exists only after the first optimizer step
         self.pieces: List[Tuple[torch.cuda.CUDAGraph, List[int]]] = []
@@ -40,7 +44,11 @@ class GraphedTrainStep:
         self.static_batch: Dict[str, torch.Tensor] = {}
         self.loss = None
         self.out = None
-        self.split = reducer is not None and getattr(reducer, "world", 1) > 1
+        self.split = reducer is not None and (getattr(reducer, "world", 1) > 1 or force_split)
+        self.sharded = self.split and hasattr(reducer, "my_slices")     # dp.ShardedReducer: the optimizer in three parts
+        if self.sharded and force_split:
+            reducer.force = True
+        self.g_parts: List[torch.cuda.CUDAGraph] = []
         self.stream: Optional[torch.cuda.Stream] = None
 
     def _forward(self):
@@ -117,6 +125,15 @@ class GraphedTrainStep:
             with torch.cuda.graph(g, stream=s, pool=g0.pool(), **mode):
                 run()
             self.pieces.append((g, done))
+        if self.sharded:
+            # reduce-scatter path: sum of squares of the local slices | scalar all-reduce | AdamW on the local slices and
+            # the fp32 regions | all-gather of the mirrors | K-major copies -- the exchanges stay outside the graphs
+            for part in (self.opt.step_norm, self.opt.step_update, self.opt.step_finish):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s, pool=g0.pool(), **mode):
+                    part()
+                self.g_parts.append(g)
+            return self
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, stream=s, pool=g0.pool(), **mode):
             self.opt.step()
@@ -136,5 +153,13 @@ class GraphedTrainStep:
                     self.reducer.stage_done(i)
         if self.split:
             self.reducer.finish()
-            self.g_opt.replay()
+            if self.sharded:
+                A = self.opt.arena
+                self.g_parts[0].replay()
+                self.reducer.sum_scalar(self.opt.gnorm_sq)
+                self.g_parts[1].replay()
+                self.reducer.gather(A.flat_w if A.flat_w is not None else A.flat_p)
+                self.g_parts[2].replay()
+            else:
+                self.g_opt.replay()
         return self.loss
