@@ -28,6 +28,7 @@ namespace {
 constexpr int DS = 128;          // channels per workgroup
 constexpr int IMG_LD = DS + 8;   // bf16 LDS image row: 272 B (16 rows hit 16 different 16-byte bank groups)
 constexpr int NB = 8;            // long-stream rows requested back to back before any is consumed
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 struct ApplyArgs {
   const bf16_t* C; const bf16_t* Q;      // ctx [B,Lc,D], qry [B,Lq,D]
@@ -52,14 +53,16 @@ __device__ __forceinline__ void ld_rows(const bf16_t* base, int64_t ld, int r0, 
 #pragma unroll
   for (int j = 0; j < NB; ++j) v[j] = ldw(base + (int64_t)min(r0 + j, rlast) * ld);
 }
-// the short stream's rows of this thread's channel pair -> registers (rows past `n`: zero)
+// the short stream's rows of this thread's channel pair -> registers.  Rows past `n` hold the clamped last row, NOT zero:
+// every use multiplies them by a probability column >= n, which cqscore.hip writes as exactly 0 (a `s < n ? x : 0` select
+// per row cost an SGPR pair each -- 48-96 wave-uniform masks that the kernels spilled to VGPR lanes and re-read per use)
 template <typename E, int SP>
-__device__ __forceinline__ void ld_short(const bf16_t* base, int64_t ld, int n, float (&r)[SP][2]) {
+__device__ __forceinline__ void ld_short(const bf16_t* base, int64_t ld, int n, f32x2 (&r)[SP]) {
   uint32_t w[SP];
 #pragma unroll
   for (int s = 0; s < SP; ++s) w[s] = ldw(base + (int64_t)min(s, n - 1) * ld);
 #pragma unroll
-  for (int s = 0; s < SP; ++s) { r[s][0] = s < n ? lo16<E>(w[s]) : 0.f; r[s][1] = s < n ? hi16<E>(w[s]) : 0.f; }
+  for (int s = 0; s < SP; ++s) { r[s][0] = lo16<E>(w[s]); r[s][1] = hi16<E>(w[s]); }
 }
 
 // A row of SP probabilities is loaded ONCE per wave as one coalesced vector load -- lane s holds p[s] -- in the same
@@ -74,44 +77,54 @@ __device__ __forceinline__ void ld_probs(const float* __restrict__ A, int r0, in
   for (int j = 0; j < NB; ++j) pv[j] = A[(int64_t)min(r0 + j, rlast) * SP + col];
 }
 __device__ __forceinline__ float bcast(float v, int s) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), s)); }
+// (the channel pair of a thread is ONE float2: p * r[s] is a v_pk_fma_f32 with the wave-uniform probability splat from an
+//  SGPR -- half the VALU instructions of the two scalar FMAs these kernels, which are instruction-bound, used to issue)
 template <int SP>
-__device__ __forceinline__ void dot_rows(float pv, const float (&r)[SP][2], float& o0, float& o1) {
-  float a0 = 0.f, a1 = 0.f;
+__device__ __forceinline__ void dot_rows(float pv, const f32x2 (&r)[SP], float& o0, float& o1) {
+  f32x2 a = {0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < SP; ++s) { const float p = bcast(pv, s); a0 += p * r[s][0]; a1 += p * r[s][1]; }
-  o0 = a0; o1 = a1;
+  for (int s = 0; s < SP; ++s) a += bcast(pv, s) * r[s];
+  o0 = a[0]; o1 = a[1];
 }
 template <int SP>
-__device__ __forceinline__ void axpy_rows(float pv, float x0, float x1, float (&acc)[SP][2]) {
+__device__ __forceinline__ void axpy_rows(float pv, float x0, float x1, f32x2 (&acc)[SP]) {
+  const f32x2 x = {x0, x1};
 #pragma unroll
-  for (int s = 0; s < SP; ++s) { const float p = bcast(pv, s); acc[s][0] += p * x0; acc[s][1] += p * x1; }
+  for (int s = 0; s < SP; ++s) acc[s] += bcast(pv, s) * x;
 }
 // Cross-wave sum of per-thread accumulators acc[SP][2]: every wave parks its partial in its own slot of
 // red[4][SP][DS] (plain 8-byte stores), a barrier, then whoever needs a row adds the four slots.  (LDS float atomics
 // into one shared [SP][DS] tile were the first version: ds_add_f32 runs at ~120 cycles per wave-instruction and the
 // 48-144 of them per wave were 2/3 of these kernels' time.)
 template <int SP>
-__device__ __forceinline__ void red_put(float* __restrict__ red, int w, const float (&acc)[SP][2], int lane) {
+__device__ __forceinline__ void red_put(float* __restrict__ red, int w, const f32x2 (&acc)[SP], int lane) {
 #pragma unroll
-  for (int s = 0; s < SP; ++s) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-    *reinterpret_cast<f32x2*>(red + ((w * SP + s) * DS + 2 * lane)) = (f32x2){acc[s][0], acc[s][1]};
-  }
+  for (int s = 0; s < SP; ++s) *reinterpret_cast<f32x2*>(red + ((w * SP + s) * DS + 2 * lane)) = acc[s];
 }
 template <int SP>
 __device__ __forceinline__ void red_row(const float* __restrict__ red, int s, int lane, float& o0, float& o1) {
-  typedef __attribute__((ext_vector_type(2))) float f32x2;
   f32x2 t = *reinterpret_cast<const f32x2*>(red + (s * DS + 2 * lane));
 #pragma unroll
   for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x2*>(red + ((w * SP + s) * DS + 2 * lane));
   o0 = t[0]; o1 = t[1];
 }
 template <int SP>
-__device__ __forceinline__ void red_get(const float* __restrict__ red, float (&r)[SP][2], int lane) {
+__device__ __forceinline__ f32x2 red_row2(const float* __restrict__ red, int s, int lane) {
+  f32x2 t = *reinterpret_cast<const f32x2*>(red + (s * DS + 2 * lane));
 #pragma unroll
-  for (int s = 0; s < SP; ++s) red_row<SP>(red, s, lane, r[s][0], r[s][1]);
+  for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x2*>(red + ((w * SP + s) * DS + 2 * lane));
+  return t;
+}
+template <int SP>
+__device__ __forceinline__ void red_get(const float* __restrict__ red, f32x2 (&r)[SP], int lane) {
+#pragma unroll
+  for (int s = 0; s < SP; ++s) r[s] = red_row2<SP>(red, s, lane);
 }
 #define WAVE_ID() __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))
+// One long-stream row at a time: a row's 24-48 broadcast probabilities live in SGPRs (v_readlane), and left alone the
+// scheduler interleaves the eight rows of a batch -- 200-400 SGPRs wanted, 100 there: the kernels were spilling SGPRs
+// to VGPR lanes (cq_apply_bwd_cshort: 693 v_writelane + 844 s_nop against 1194 FMAs)
+#define ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // =====================================================================================================================
 // forward, context = LONG stream (query short): A1[c][q] = S_, A2[c][q] = S_t
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_clong(ApplyArgs a) {
   const bf16_t* Cb = a.C + (int64_t)b * a.Lc * D + d0;
   const float* A1 = a.A1 + (int64_t)b * a.Lc * SP;
   const float* A2 = a.A2 + (int64_t)b * a.Lc * SP;
-  float Qr[SP][2], mid[SP][2];
+  f32x2 Qr[SP], mid[SP];
   ld_short<E, SP>(a.Q + (int64_t)b * a.Lq * D + d0, D, a.Lq, Qr);
 #pragma unroll
   for (int q = 0; q < SP; ++q) mid[q][0] = mid[q][1] = 0.f;
@@ -136,6 +149,7 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_clong(ApplyArgs a) {
     ld_probs<SP>(A2, c0, a.Lc - 1, lane, p2);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+      ROW_FENCE();
       const float ok = c0 + j < a.Lc ? 1.f : 0.f;
       axpy_rows<SP>(p2[j], ok * lo16<E>(cr[j]), ok * hi16<E>(cr[j]), mid);
     }
@@ -151,6 +165,7 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_clong(ApplyArgs a) {
     ld_probs<SP>(A1, c0, a.Lc - 1, lane, p1);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+      ROW_FENCE();
       const int c = c0 + j;
       float x0, x1, y0, y1;
       const float c0f = lo16<E>(cr[j]), c1f = hi16<E>(cr[j]);
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_cshort(ApplyArgs a) {
   const bf16_t* Qb = a.Q + (int64_t)b * a.Lq * D + d0;
   const float* A1 = a.A1 + (int64_t)b * a.Lq * SP;
   const float* A2 = a.A2 + (int64_t)b * a.Lq * SP;
-  float Cr[SP][2], a1[SP][2], a2[SP][2];
+  f32x2 Cr[SP], a1[SP], a2[SP];
   ld_short<E, SP>(Cb, D, a.Lc, Cr);
 #pragma unroll
   for (int c = 0; c < SP; ++c) a1[c][0] = a1[c][1] = a2[c][0] = a2[c][1] = 0.f;
@@ -192,6 +207,7 @@ __global__ __launch_bounds__(256) void cq_apply_fwd_cshort(ApplyArgs a) {
     ld_probs<SP>(A2, q0, a.Lq - 1, lane, p2);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+      ROW_FENCE();
       const float ok = q0 + j < a.Lq ? 1.f : 0.f;
       float m0, m1;
       dot_rows<SP>(p2[j], Cr, m0, m1);                                  // mid[q] = sum_c S_t[c,q] C[c]
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
   const bf16_t* gb = a.g + (int64_t)b * a.Lc * 4 * D + d0;
   const float* A1 = a.A1 + (int64_t)b * a.Lc * SP;
   const float* A2 = a.A2 + (int64_t)b * a.Lc * SP;
-  float Qr[SP][2], mid[SP][2];
+  f32x2 Qr[SP], mid[SP];
   ld_short<E, SP>(a.Q + (int64_t)b * a.Lq * D + d0, D, a.Lq, Qr);
   for (int i = threadIdx.x; i < 2 * a.LqP * IMG_LD; i += 256) midI[i] = (bf16_t)0.f;
 #pragma unroll
@@ -293,6 +309,7 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
     ld_probs<SP>(A2, c0, a.Lc - 1, lane, p2);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+      ROW_FENCE();
       const float ok = c0 + j < a.Lc ? 1.f : 0.f;
       axpy_rows<SP>(p2[j], ok * lo16<E>(cr[j]), ok * hi16<E>(cr[j]), mid);
     }
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
   }
   __syncthreads();                                      // everyone has read the mid partials: the slots are re-used below
   // ---- dQ = S_^T . dc2q, dmid = S_^T . dq2c over this wave's rows
-  float dQa[SP][2], dMa[SP][2];
+  f32x2 dQa[SP], dMa[SP];
 #pragma unroll
   for (int q = 0; q < SP; ++q) dQa[q][0] = dQa[q][1] = dMa[q][0] = dMa[q][1] = 0.f;
   for (int c0 = w * NB; c0 < a.Lc; c0 += 4 * NB) {
@@ -320,6 +337,7 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
     ld_probs<SP>(A1, c0, a.Lc - 1, lane, p1);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+      ROW_FENCE();
       const float ok = c0 + j < a.Lc ? 1.f : 0.f;
       axpy_rows<SP>(p1[j], ok * (lo16<E>(r2[j]) + lo16<E>(r3[j]) * lo16<E>(cr[j])), ok * (hi16<E>(r2[j]) + hi16<E>(r3[j]) * hi16<E>(cr[j])), dQa);
       axpy_rows<SP>(p1[j], ok * lo16<E>(r4[j]) * lo16<E>(cr[j]), ok * hi16<E>(r4[j]) * hi16<E>(cr[j]), dMa);
@@ -352,6 +370,7 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong(ApplyArgs a) {
     ld_probs<SP>(A2, c0, a.Lc - 1, lane, p2);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+      ROW_FENCE();
       const int c = c0 + j;
       float x0, x1, y0, y1, z0, z1;
       dot_rows<SP>(p1[j], Qr, x0, x1);
@@ -389,9 +408,9 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
   __syncthreads();
   bf16_t* dQb = a.dQ + (int64_t)b * a.Lq * D + d0;
   constexpr int RW = SP / 4;                            // context rows c = w, w + 4, ... of this wave (<= SP / 4)
-  float xr[RW][2], yr[RW][2], zr[RW][2];
+  f32x2 xr[RW], yr[RW], zr[RW];
   {   // pass A: forward quantities (c2q, q2c accumulators; the mid image)
-    float Cr[SP][2], a1[SP][2], a2[SP][2];
+    f32x2 Cr[SP], a1[SP], a2[SP];
     ld_short<E, SP>(Cb, D, a.Lc, Cr);
 #pragma unroll
     for (int c = 0; c < SP; ++c) a1[c][0] = a1[c][1] = a2[c][0] = a2[c][1] = 0.f;
@@ -403,6 +422,7 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
       ld_probs<SP>(A2, q0, a.Lq - 1, lane, p2);
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
+        ROW_FENCE();
         const float ok = q0 + j < a.Lq ? 1.f : 0.f;
         float m0, m1;
         dot_rows<SP>(p2[j], Cr, m0, m1);
@@ -414,24 +434,24 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
     red_put<SP>(red, w, a1, lane);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < RW; ++k) red_row<SP>(red, min(w + 4 * k, SP - 1), lane, xr[k][0], xr[k][1]);
+    for (int k = 0; k < RW; ++k) xr[k] = red_row2<SP>(red, min(w + 4 * k, SP - 1), lane);
     __syncthreads();
     red_put<SP>(red, w, a2, lane);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < RW; ++k) red_row<SP>(red, min(w + 4 * k, SP - 1), lane, yr[k][0], yr[k][1]);
+    for (int k = 0; k < RW; ++k) yr[k] = red_row2<SP>(red, min(w + 4 * k, SP - 1), lane);
     __syncthreads();
   }
   {   // pass B: dQ rows, the dmid image, dC_mid accumulators
-    float X1[SP][2], X2[SP][2], a3[SP][2];               // dc2q, dq2c rows of this channel pair
+    f32x2 X1[SP], X2[SP], a3[SP];               // dc2q, dq2c rows of this channel pair
 #pragma unroll
     for (int c = 0; c < SP; ++c) {
       const int cc = min(c, a.Lc - 1);
       const bf16_t* gr = gb + (int64_t)cc * 4 * D;
       const uint32_t cv = ldw(Cb + (int64_t)cc * D), g2 = ldw(gr + D), g3 = ldw(gr + 2 * D), g4 = ldw(gr + 3 * D);
-      const float ok = c < a.Lc ? 1.f : 0.f;
-      X1[c][0] = ok * (lo16<E>(g2) + lo16<E>(g3) * lo16<E>(cv)); X1[c][1] = ok * (hi16<E>(g2) + hi16<E>(g3) * hi16<E>(cv));
-      X2[c][0] = ok * (lo16<E>(g4) * lo16<E>(cv)); X2[c][1] = ok * (hi16<E>(g4) * hi16<E>(cv));
+      // (rows c >= Lc repeat the last row: their probability columns are exactly 0, see ld_short)
+      X1[c][0] = lo16<E>(g2) + lo16<E>(g3) * lo16<E>(cv); X1[c][1] = hi16<E>(g2) + hi16<E>(g3) * hi16<E>(cv);
+      X2[c][0] = lo16<E>(g4) * lo16<E>(cv); X2[c][1] = hi16<E>(g4) * hi16<E>(cv);
       a3[c][0] = a3[c][1] = 0.f;
     }
     for (int q0 = w * NB; q0 < a.Lq; q0 += 4 * NB) {
@@ -440,6 +460,7 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
       ld_probs<SP>(A2, q0, a.Lq - 1, lane, p2);
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
+        ROW_FENCE();
         const int q = q0 + j;
         const float ok = q < a.Lq ? 1.f : 0.f;
         float x0, x1, m0, m1;
@@ -456,7 +477,7 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < RW; ++k) red_row<SP>(red, min(w + 4 * k, SP - 1), lane, zr[k][0], zr[k][1]);
+  for (int k = 0; k < RW; ++k) zr[k] = red_row2<SP>(red, min(w + 4 * k, SP - 1), lane);
   bf16_t* dCb = a.dC + (int64_t)b * a.Lc * D + d0;
 #pragma unroll
   for (int k = 0; k < RW; ++k) {
@@ -594,7 +615,7 @@ __global__ __launch_bounds__(256) void cq_score_bwd_kernel(ScoreBwdArgs a) {
   const float* dSb = a.dS + (int64_t)b * a.Ll * SP;
   const bf16_t* Lb = a.lng + (int64_t)b * a.Ll * D + d0;
   bf16_t* dLb = a.dlng + (int64_t)b * a.Ll * D + d0;
-  float Sreg[SP][2], acc[SP][2];
+  f32x2 Sreg[SP], acc[SP];
   ld_short<E, SP>(a.sht + (int64_t)b * a.Ls * D + d0, D, a.Ls, Sreg);
 #pragma unroll
   for (int s = 0; s < SP; ++s) acc[s][0] = acc[s][1] = 0.f;
@@ -605,6 +626,7 @@ __global__ __launch_bounds__(256) void cq_score_bwd_kernel(ScoreBwdArgs a) {
     ld_probs<SP>(dSb, r0, a.Ll - 1, lane, pd);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+      ROW_FENCE();
       const int r = r0 + j;
       const float ok = r < a.Ll ? 1.f : 0.f;
       float x0, x1;
