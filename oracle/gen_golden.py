@@ -287,6 +287,44 @@ def staging_case():
     print("g_staging: ok", len(out), "arrays")
 
 
+def collate_case():
+    """Next row N3, text / label side: the reference's own BaseCollate (utils/BaseDataset.py:182-236, with pad_seq /
+    pad_char_seq of utils/data_utils.py:42-67) and its label producers (get_dist_idx, get_NER_label) on ragged random
+    samples -> tests/golden/g_collate.npz: the ragged inputs as flat arrays + offsets, and the collated batch."""
+    bd = importlib.import_module("utils.BaseDataset")
+    rng = np.random.default_rng(4242)
+    T, V = 24, 8
+    out = {"T": T, "V": V}
+    for case, (B, Lmax, Cmax) in enumerate([(7, 9, 6), (5, 20, 11), (3, 1, 1)]):
+        datas, wflat, woff, cflat, coff, ses, vlens = [], [], [0], [], [0], [], []
+        ds = bd.BaseDataset.__new__(bd.BaseDataset)      # the label producers only read max_vlen
+        ds.max_vlen = T
+        for b in range(B):
+            nw = int(rng.integers(1, Lmax + 1))
+            wids = rng.integers(1, 50, size=nw).tolist()
+            cids = [rng.integers(1, 30, size=int(rng.integers(1, Cmax + 1))).tolist() for _ in range(nw)]
+            vlen = int(rng.integers(2, T + 1))
+            s = int(rng.integers(0, vlen)); e = int(rng.integers(s, vlen))
+            vfeat = torch.from_numpy(rng.standard_normal((vlen, V)).astype(np.float32))
+            datas.append({"record": {"i": b}, "max_vlen": T, "vfeat": vfeat, "words_id": wids, "chars_id": cids,
+                          "label1d": ds.get_dist_idx(s, e), "NER_label": ds.get_NER_label(s, e, vfeat),
+                          "se_time": [float(s), float(e)], "se_frac": [s / vlen, e / vlen]})
+            wflat += wids; woff.append(len(wflat))
+            for c in cids:
+                cflat += c; coff.append(len(cflat))
+            ses.append((s, e)); vlens.append(vlen)
+            out[f"c{case}.vfeat{b}"] = vfeat.numpy()
+        res, _ = bd.BaseCollate()(datas)
+        out[f"c{case}.B"] = B
+        out[f"c{case}.wflat"] = np.asarray(wflat, np.int64); out[f"c{case}.woff"] = np.asarray(woff, np.int64)
+        out[f"c{case}.cflat"] = np.asarray(cflat, np.int64); out[f"c{case}.coff"] = np.asarray(coff, np.int64)
+        out[f"c{case}.ses"] = np.asarray(ses, np.int64); out[f"c{case}.vlens"] = np.asarray(vlens, np.int64)
+        for k, v in res.items():
+            out[f"c{case}.out.{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(GOLD, "g_collate.npz"), **out)
+    print("g_collate: ok", len(out), "arrays")
+
+
 def ban_map_case():
     """The BAN proposal-map stage built from the REAL reference classes (models/BANlib/model.py SparseMaxPool,
     SparseBoundaryCat, DenseMaxPool, NaivePredictor; wiring of models/BAN.py:38-65,87-99) in eval mode, with
@@ -396,8 +434,13 @@ def main():
     ap.add_argument("--only-ban", action="store_true")
     ap.add_argument("--only-labels", action="store_true")
     ap.add_argument("--only-cfg4", action="store_true")
+    ap.add_argument("--only-collate", action="store_true")
     args = ap.parse_args()
     torch.manual_seed(0)
+    if args.only_collate:
+        import_reference()
+        collate_case()
+        return
     if args.only_ban:
         ban_map_case()
         return
@@ -412,6 +455,7 @@ def main():
     labels_case()
     metrics_case(mods)
     staging_case()
+    collate_case()
     ban_map_case()
     if args.only_metrics:
         return
