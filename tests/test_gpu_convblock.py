@@ -246,3 +246,38 @@ def test_conv_block_matches_torch_reference(dev):
         mg = ops.main_grad(p)
         assert mg is not None
         assert rel(mg.view_as(gr), gr) < 6e-2, n
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2), (torch.float16, 3e-3)])
+@pytest.mark.parametrize("D,segs", [(512, [(3, 16), (3, 6)]), (1024, [(2, 128), (2, 20)]), (512, [(1, 1), (2, 3)]), (1024, [(2, 70)]),
+                                    (1024, [(5, 37), (4, 9)])])
+def test_ln_dwconv_forward_persistent_kernel_matches_torch(dev, dt, tol, D, segs):
+    """vmr_ln_dwconv_fwd2 at D = 512 / 1024 runs convblock.hip's persistent forward kernel (norm.hip's two-phase tile
+    kernel keeps the other widths, tests/test_gpu_a_ops.py): u, mean, rstd against PyTorch, ragged sequence groups."""
+    from vmrframe_amd import _lib as L
+    lib = L.lib()
+    torch.manual_seed(2)
+    rows = sum(b * s for b, s in segs)
+    x = (torch.randn(rows, D, device=dev) * 1.5 + 0.3).to(dt)
+    gamma = 1 + 0.1 * torch.randn(D, device=dev)
+    beta = 0.1 * torch.randn(D, device=dev)
+    w = torch.randn(D, 7, device=dev) / math.sqrt(7)
+    u = torch.full_like(x, float("nan"))
+    mean = torch.full((rows,), float("nan"), device=dev)
+    rstd = torch.full((rows,), float("nan"), device=dev)
+    (B1, S1), (B2, S2) = segs[0], (segs[1] if len(segs) > 1 else (0, 0))
+    L.check(lib.vmr_ln_dwconv_fwd2(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-6, w.data_ptr(), u.data_ptr(), mean.data_ptr(),
+                                   rstd.data_ptr(), B1, S1, B2, S2, D, L.dtype_code(x), L.stream_ptr()), "vmr_ln_dwconv_fwd2")
+    torch.cuda.synchronize()
+    xf = x.float()
+    assert torch.allclose(mean, xf.mean(1), atol=1e-5, rtol=1e-5)
+    assert torch.allclose(rstd, torch.rsqrt(xf.var(1, unbiased=False) + 1e-6), atol=1e-5, rtol=1e-4)
+    outs, r = [], 0
+    for (B, S) in segs:
+        n = torch.nn.functional.layer_norm(xf[r:r + B * S].view(B, S, D), (D,), gamma, beta, 1e-6)
+        n = n.to(dt).float()                                   # the kernel stages LN(x) in the storage type
+        c = torch.nn.functional.conv1d(n.transpose(1, 2), w.view(D, 1, 7), padding=3, groups=D).transpose(1, 2)
+        outs.append(c.reshape(B * S, D)); r += B * S
+    ref = torch.cat(outs, 0)
+    assert torch.isfinite(u.float()).all()
+    assert rel(u.float(), ref) < tol

@@ -237,6 +237,141 @@ __global__ __launch_bounds__(NT, 2) void convblock_bwd_kernel(CBArgs a) {
   *reinterpret_cast<f32x2*>(pgb + D + c0) = ab1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: u = dw7(LN(x)) with the same persistent skeleton (replaces ln_dwconv_fwd_kernel of norm.hip for D = 512 / 1024:
+// that kernel's workgroups normalised 16 rows to produce 10 -- a 60 % halo -- and ran load / normalise / barrier /
+// convolve / store in lock-step; here a workgroup keeps gamma, beta and its channels' taps in registers over all its
+// chunks, the NEXT chunk's rows are requested before the current one is convolved, and two LDS tiles alternate so a
+// chunk costs one barrier).  Chunk = 8 output frames; its 14 input frames (3-frame halo each side) are normalised by
+// one wave per row (ln_fwd_kernel's lane mapping and two-pass statistics) into an LDS tile in the storage type -- what
+// the two-phase kernel staged too -- and the convolution runs thread = 2 channels over a sliding window read from it.
+// ---------------------------------------------------------------------------------------------------------------------
+struct CFArgs {
+  const void* x;
+  const float *gamma, *beta, *w;
+  float eps;
+  void* u;
+  float *mean, *rstd;
+  int S1, cps1, nc1, S2, cps2, nchunks;
+  int64_t rows1;
+};
+
+template <typename T, int NT>
+__global__ __launch_bounds__(NT, 2) void convblock_fwd_kernel(CFArgs a) {
+  constexpr int CPT = 2, D = NT * CPT, MAXC = D / 512, R = CB_R, NR = R + 6, NW = NT / 64, RPW = (NR + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* tiles = reinterpret_cast<T*>(smem);   // [2][NR][D]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const T* x = reinterpret_cast<const T*>(a.x);
+  T* u = reinterpret_cast<T*>(a.u);
+  const int c0 = tid * CPT;
+  typedef __attribute__((ext_vector_type(CPT))) T TVC;
+  typedef __attribute__((ext_vector_type(8))) T TV8;
+  auto locate = [&](int ci, int& S, int64_t& rb, int& r0) {
+    int cps = a.cps1;
+    int64_t base = 0;
+    S = a.S1;
+    if (ci >= a.nc1) { ci -= a.nc1; S = a.S2; cps = a.cps2; base = a.rows1; }
+    const int b = ci / cps;
+    r0 = (ci - b * cps) * R;
+    rb = base + (int64_t)b * S;
+  };
+  // this wave's rows of a chunk (tile rows wid, wid + NW, ...: frames r0 - 3 + row), clamped, in the storage type
+  TV8 px[RPW][MAXC];
+  auto request = [&](int ci) {
+    int S, r0; int64_t rb;
+    locate(min(ci, a.nchunks - 1), S, rb, r0);
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+      const int s = min(max(r0 - 3 + wid + NW * q, 0), S - 1);
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) px[q][c] = *reinterpret_cast<const TV8*>(x + (rb + s) * D + (c * 64 + lane) * 8);
+    }
+  };
+  request(blockIdx.x);
+  float gam[MAXC][8], bet[MAXC][8];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    Vec8<float>::load(a.gamma + (c * 64 + lane) * 8, gam[c]);
+    Vec8<float>::load(a.beta + (c * 64 + lane) * 8, bet[c]);
+  }
+  f32x2 wk[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { wk[k][0] = a.w[c0 * 7 + k]; wk[k][1] = a.w[(c0 + 1) * 7 + k]; }
+  int buf = 0;
+  for (int ci = blockIdx.x; ci < a.nchunks; ci += gridDim.x, buf ^= 1) {
+    int S, r0; int64_t rb;
+    locate(ci, S, rb, r0);
+    const int nrows = min(R, S - r0);
+    T* tile = tiles + buf * NR * D;
+    // ---- phase A: LayerNorm of the chunk's 14 input frames, one wave per frame
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+      const int r = wid + NW * q;        // tile row
+      if (r < NR) {                      // wave-uniform
+        const int s = r0 - 3 + r;
+        float v[MAXC][8];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[c][e] = to_f<T>(px[q][c][e]);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sum += v[c][e];
+        const float mean = wave_sum_dpp(sum) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+        const float rstd = rsqrtf(wave_sum_dpp(sq) / (float)D + a.eps);
+        const bool inside = s >= 0 && s < S;                 // outside the sequence: the conv's zero padding
+        if (lane == 0 && inside && r >= 3 && r < 3 + nrows) {
+          a.mean[rb + s] = mean;
+          a.rstd[rb + s] = rstd;
+        }
+        const float msk = inside ? 1.f : 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = ((v[c][e] - mean) * rstd * gam[c][e] + bet[c][e]) * msk;
+          Vec8<T>::store(tile + r * D + (c * 64 + lane) * 8, o);
+        }
+      }
+    }
+    request(ci + gridDim.x);             // the next chunk's rows fly under the convolution below
+    __syncthreads();
+    // ---- phase B: depthwise conv (k = 7), this thread's 2 channels, sliding window over the tile
+    f32x2 win[7];
+    auto tl = [&](int r) -> f32x2 {
+      const TVC t = *reinterpret_cast<const TVC*>(tile + r * D + c0);
+      f32x2 o; o[0] = to_f<T>(t[0]); o[1] = to_f<T>(t[1]); return o;
+    };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) win[k + 1] = tl(k);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) win[k] = win[k + 1];
+      win[6] = tl(j + 6);
+      f32x2 acc = wk[0] * win[0];        // u[s] = sum_k w[k] * n[s + k - 3]
+#pragma unroll
+      for (int k = 1; k < 7; ++k) acc += wk[k] * win[k];
+      if (j < nrows) {
+        TVC o;
+        o[0] = from_f<T>(acc[0]); o[1] = from_f<T>(acc[1]);
+        *reinterpret_cast<TVC*>(u + (rb + r0 + j) * D + c0) = o;
+      }
+    }
+    // (no second barrier: the next chunk's phase A writes the OTHER tile; the one after that comes behind the next
+    //  chunk's barrier, which every wave reaches only after finishing this convolution)
+  }
+}
+
 // persistent grid: one 512-thread (two 256-thread) workgroup(s) per CU, never more than there are chunks
 int cb_grid(int nchunks, int D) {
   static int ncu = 0;
@@ -258,6 +393,42 @@ int cb_grid(int nchunks, int D) {
 extern "C" int vmr_convblock_bwd_blocks(int B1, int S1, int B2, int S2, int D) {
   const int nchunks = (B1 > 0 && S1 > 0 ? B1 * cdiv(S1, CB_R) : 0) + (B2 > 0 && S2 > 0 ? B2 * cdiv(S2, CB_R) : 0);
   return cb_grid(nchunks, D);
+}
+
+// called by vmr_ln_dwconv_fwd2 (norm.hip) for the widths this file is built for; -1 = not taken
+int convblock_fwd_launch(const void* x, const float* gamma, const float* beta, float eps, const float* w, void* u, float* mean,
+                         float* rstd, int B1, int S1, int B2, int S2, int D, int dtype, void* stream) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("VMR_CONVBLOCK_FWD");     // A/B switch: 0 = the two-phase tile kernel of norm.hip
+    on = e && atoi(e) == 0 ? 0 : 1;
+  }
+  if (!on || !(D == 512 || D == 1024) || !vmr_dtype_ok(dtype)) return -1;
+  CFArgs a;
+  a.x = x; a.gamma = gamma; a.beta = beta; a.w = w; a.eps = eps; a.u = u; a.mean = mean; a.rstd = rstd;
+  a.S1 = S1; a.S2 = S2;
+  a.cps1 = cdiv(S1, CB_R); a.cps2 = cdiv(S2, CB_R);
+  a.nc1 = B1 * a.cps1;
+  a.nchunks = a.nc1 + B2 * a.cps2;
+  a.rows1 = (int64_t)B1 * S1;
+  if (a.nchunks == 0) return 0;
+  const int nb = cb_grid(a.nchunks, D);
+  const size_t lds = (size_t)2 * (CB_R + 6) * D * vmr_dtype_size(dtype);
+  hipStream_t st = (hipStream_t)stream;
+#define CF_LAUNCH(T, NT)                                                                                            \
+  do {                                                                                                              \
+    const void* fn = (const void*)convblock_fwd_kernel<T, NT>;                                                      \
+    if (lds > 64 * 1024) {                                                                                          \
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+      if (e != hipSuccess) return vmr_fail(-5, "vmr_ln_dwconv_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
+    }                                                                                                               \
+    hipLaunchKernelGGL((convblock_fwd_kernel<T, NT>), dim3(nb), dim3(NT), lds, st, a);                              \
+  } while (0)
+  if (D == 512) VMR_DISPATCH(dtype, T, CF_LAUNCH(T, 256));
+  else VMR_DISPATCH(dtype, T, CF_LAUNCH(T, 512));
+#undef CF_LAUNCH
+  VMR_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int vmr_convblock_bwd_supported(int D, int dtype) {

@@ -670,6 +670,10 @@ static void dwconv_tiling(int S, int D, size_t esz, int& R, int& tiles) {
   R = cdiv(S, tiles);  // balance the tiles
 }
 
+// convblock.hip: the persistent form for D = 512 / 1024 (-1: not taken)
+int convblock_fwd_launch(const void* x, const float* gamma, const float* beta, float eps, const float* w, void* u, float* mean,
+                         float* rstd, int B1, int S1, int B2, int S2, int D, int dtype, void* stream);
+
 extern "C" int vmr_ln_dwconv_fwd2(const void* x, const float* gamma, const float* beta, float eps, const float* w,
                                   void* u, float* mean, float* rstd, int B1, int S1, int B2, int S2, int D,
                                   int dtype, void* stream) {
@@ -679,6 +683,7 @@ extern "C" int vmr_ln_dwconv_fwd2(const void* x, const float* gamma, const float
   if (B1 == 0 || S1 == 0) { B1 = 0; S1 = S1 > 0 ? S1 : 1; }
   if (B2 == 0 || S2 == 0) { B2 = 0; S2 = S2 > 0 ? S2 : 1; }
   if (B1 + B2 == 0) return 0;
+  if (const int rc = convblock_fwd_launch(x, gamma, beta, eps, w, u, mean, rstd, B1, S1, B2, S2, D, dtype, stream); rc != -1) return rc;
   const size_t esz = (size_t)vmr_dtype_size(dtype);
   int R1, tiles1, R2, tiles2;
   dwconv_tiling(S1, D, esz, R1, tiles1);
