@@ -610,6 +610,22 @@ int vmr_lstm_step_fwd(const void* gx, const void* hprev, const void* whh, const 
                       void* cs, void* hp, void* y, int B, int T, int H, int s, int ndir, int dtype, void* stream);
 int vmr_lstm_step_bwd(const void* dy, const void* act, const void* cs, const int32_t* len, const void* whht, void* dc, void* dg,
                       int B, int T, int H, int s, int ndir, int dtype, void* stream);
+/* The whole recurrence of a bi-LSTM layer in ONE launch (bf16 / fp16, H = 256 or 512, B <= 64, ndir <= 8): persistent
+ * workgroups (direction z = blockIdx % 8, 16 hidden units each) advance all T steps with one counter barrier per step
+ * instead of one kernel per step; results are those of T calls of vmr_lstm_step_fwd / _bwd (same layouts, same MFMA
+ * products; the gate math may contract into different FMAs: agreement to an ulp of the storage type).
+ * hist: caller-owned scratch of *bytes from vmr_lstm_seq_hist_bytes(T, H, ndir, &bytes) (the h exchange: every step writes fresh
+ * addresses); sync: int32[16] device words the caller ZEROES before each call ([0..7] arrival counters, [8] is raised
+ * if a workgroup gave up waiting -- bounded polls: a lost workgroup cannot hang the GPU; the results are then invalid).
+ * The exchange protocol is placement-independent (write-through stores, agent-scope counter, L1-bypassing loads); the
+ * GPU must otherwise be idle enough for all 8 * H / 16 workgroups to be resident at once.  whht (backward) = W_hh
+ * transposed, [ndir][H][4H]. */
+int vmr_lstm_seq_supported(int B, int H, int ndir, int dtype);
+int vmr_lstm_seq_hist_bytes(int T, int H, int ndir, int64_t* bytes);
+int vmr_lstm_seq_fwd(const void* gx, const void* whh, const int* len, void* act, void* cs, void* hp, void* y, void* hist,
+                     int* sync, int B, int T, int H, int ndir, int dtype, void* stream);
+int vmr_lstm_seq_bwd(const void* dy, const void* act, const void* cs, const int* len, const void* whht, void* dg,
+                     int* sync, int B, int T, int H, int ndir, int dtype, void* stream);
 /* dst[b][s][:] = s < len[b] ? src[b][len[b]-1-s][:] : 0 for [B][T][D] rows (its own inverse on the valid part).  D a
  * multiple of 16 bytes, 16-byte aligned pointers. */
 int vmr_lstm_reverse_rows(const void* src, const int32_t* len, void* dst, int B, int T, int D, int dtype, void* stream);

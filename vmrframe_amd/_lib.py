@@ -80,6 +80,10 @@ SIGNATURES = {
     "vmr_transpose_batched": [_P, _I, _P],
     "vmr_ln_dwconv_fwd2": [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_dwconv_bwd2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vmr_lstm_seq_supported": [_I, _I, _I, _I],
+    "vmr_lstm_seq_hist_bytes": [_I, _I, _I, _P],
+    "vmr_lstm_seq_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vmr_lstm_seq_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vmr_convblock_bwd_supported": [_I, _I],
     "vmr_convblock_bwd_blocks": [_I, _I, _I, _I, _I],
     "vmr_convblock_bwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],

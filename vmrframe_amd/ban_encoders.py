@@ -24,6 +24,7 @@ ban_sampler.py, ban_head.py, assembled in ban.py.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 
 import torch
@@ -42,6 +43,20 @@ def _reverse_rows(x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
     L.check(L.lib().vmr_lstm_reverse_rows(x.data_ptr(), lens.data_ptr(), out.data_ptr(), B, T, D, L.dtype_code(x),
                                           L.stream_ptr()), "vmr_lstm_reverse_rows")
     return out
+
+
+SEQ_KERNEL = os.environ.get("VMR_LSTM_SEQ", "1") != "0"     # one persistent launch per layer and pass (csrc/lstm.hip)
+_SYNC_LOG = []       # the sync words of the most recent sequence launches (tests read word 8: a workgroup gave up waiting)
+
+
+def _note_sync(sync):
+    _SYNC_LOG.append(sync)
+    del _SYNC_LOG[:-64]
+
+
+def seq_kernel_gave_up() -> bool:
+    """True if any of the recent one-launch recurrences raised its error word (a device read: tests / debugging only)."""
+    return any(int(t[8].item()) != 0 for t in _SYNC_LOG)
 
 
 class _BiLSTM(torch.autograd.Function):
@@ -71,7 +86,17 @@ class _BiLSTM(torch.autograd.Function):
         hp = torch.empty(Z, B, T, H, device=dev, dtype=dt)
         y = torch.zeros(K, B, T, 2 * H, device=dev, dtype=dt)
         ctx.fused = bool(FUSED_STEP and lib.vmr_lstm_step_supported(H, dc))
-        if ctx.fused:            # product + gates + state in one launch per step; h ping-pongs between two buffers
+        ctx.seq = bool(ctx.fused and SEQ_KERNEL and lib.vmr_lstm_seq_supported(B, H, Z, dc))
+        if ctx.seq:              # the whole recurrence in ONE launch: persistent workgroups, a counter barrier per step
+            nbytes = C.c_int64(0)
+            L.check(lib.vmr_lstm_seq_hist_bytes(T, H, Z, C.byref(nbytes)), "vmr_lstm_seq_hist_bytes")
+            hist = torch.empty(nbytes.value, device=dev, dtype=torch.uint8)
+            sync = torch.zeros(16, device=dev, dtype=torch.int32)
+            L.check(lib.vmr_lstm_seq_fwd(gx.data_ptr(), w_hh.data_ptr(), lens.data_ptr(), act.data_ptr(), cs.data_ptr(),
+                                         hp.data_ptr(), y.data_ptr(), hist.data_ptr(), sync.data_ptr(), B, T, H, Z, dc,
+                                         L.stream_ptr()), "vmr_lstm_seq_fwd")
+            _note_sync(sync)
+        elif ctx.fused:          # product + gates + state in one launch per step; h ping-pongs between two buffers
             hb = torch.zeros(2, Z, B, H, device=dev, dtype=dt)
             for s in range(T):
                 L.check(lib.vmr_lstm_step_fwd(gx.data_ptr(), hb[s & 1].data_ptr(), w_hh.data_ptr(), lens.data_ptr(),
@@ -103,7 +128,13 @@ class _BiLSTM(torch.autograd.Function):
         dy = dy.contiguous()
         dg = torch.empty(Z, B, T, 4 * H, device=dev, dtype=dt)
         dcell = torch.zeros(Z, B, H, device=dev)
-        if ctx.fused:
+        if ctx.seq:
+            whht = w_hh.transpose(1, 2).contiguous()                      # [Z, H, 4H]: the K-contiguous operand of dg . W_hh
+            sync = torch.zeros(16, device=dev, dtype=torch.int32)
+            L.check(lib.vmr_lstm_seq_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), whht.data_ptr(),
+                                         dg.data_ptr(), sync.data_ptr(), B, T, H, Z, dc, L.stream_ptr()), "vmr_lstm_seq_bwd")
+            _note_sync(sync)
+        elif ctx.fused:
             whht = w_hh.transpose(1, 2).contiguous()                      # [Z, H, 4H]: the K-contiguous operand of dg . W_hh
             for s in range(T - 1, -1, -1):
                 L.check(lib.vmr_lstm_step_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), whht.data_ptr(),

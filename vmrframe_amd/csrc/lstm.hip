@@ -232,6 +232,281 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const E* __restrict_
   dg[ga + 3 * H] = (E)(dht * th * og * (1.f - og));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole recurrence of a layer in ONE launch (bf16 / fp16, H = 256 or 512, B <= 64): persistent workgroups, one
+// counter barrier per step instead of one kernel boundary per step.  A graph-captured step kernel costs its 5-9 us PLUS
+// a ~1.4 us dependent-kernel boundary, 2 x 128 of them per layer; a step here is: poll the direction's arrival counter,
+// fetch h_{s-1} (32-64 KB, L2 / fabric), 32-64 MFMAs per wave against weights that never leave LDS, the gate math in
+// registers, publish this workgroup's 2 KB of h_s, arrive.
+//
+//   workgroup = (direction z, 16 hidden units x all 4 gates x up to 64 batch rows); its 64 rows of W_hh (32-64 KB) are
+//               loaded into LDS ONCE; the cell state c and this workgroup's slice of h stay in REGISTERS over all steps;
+//   exchange  = a history buffer hist[z][s] of h AFTER step s, slice-major ([H/16][64][16], so a workgroup publishes one
+//               contiguous 2 KB block and an MFMA A-fragment of any batch row is one aligned 16-byte load).  Every step
+//               writes FRESH addresses.  The protocol is placement-independent (MI355X_MICROARCH "Workgroup dispatch"):
+//               payload by write-through `sc1` stores, every storing wave's s_waitcnt vmcnt(0), the workgroup barrier,
+//               ONE agent-scope relaxed atomic add on the direction's counter; readers poll that counter with agent-
+//               scope (`sc1`) loads + s_sleep and fetch the payload with `sc1` loads (L1-bypassing).  No fence, no
+//               __threadfence (an L2 write-back / invalidate per step costs more than the step).
+//   placement = none assumed; a direction's workgroups are dealt over its share of the eight XCD groups (blockIdx % 8);
+//   liveness  = all 8 x H/16 <= 256 workgroups are resident at once on an otherwise idle GPU (one per CU); every poll
+//               is bounded: after ~0.25 s a workgroup raises sync[8] and stops waiting (the host checks the flag).
+// Same arithmetic as lstm_step_fwd_kernel / lstm_step_bwd_kernel (same MFMA products in the same k order; the gate math
+// may contract into different FMAs: results agree to an ulp of the storage type).
+// ---------------------------------------------------------------------------------------------------------------------
+struct SeqArgs {
+  const void *gx, *whh;
+  const int* len;
+  void* act; float* cs; void *hp, *y;      // forward outputs (see the layouts at the top)
+  const void *dy; float* dcs_unused; void* dg;   // backward
+  void* hist;                               // [Z][T][H/16][64][16] (fwd: h after step s; bwd: unused)
+  int* sync;                                // [0..7] arrival counters per direction, [8] error flag; zeroed by the caller
+  int B, T, ndir, xpd;
+};
+
+__device__ __forceinline__ bf16x8 ld16_sc1(const void* p) {
+  bf16x8 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void st8_sc1(void* p, u32x2 v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// wave-uniform wait of thread 0 for `*ctr >= target`; bounded (a lost workgroup must not hang the GPU)
+__device__ __forceinline__ void seq_wait(int* ctr, int target, int* err, int* dead) {
+  if (threadIdx.x == 0 && !*dead) {
+    int it = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++it > (1 << 18)) { *dead = 1; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void seq_arrive(int* ctr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's payload stores have been written through
+  __syncthreads();                                      // ... and every other wave's of the workgroup
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename E, int HH>
+__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
+  constexpr int H = HH, KS = HH / 32, WPX = HH / 16, LDW = HH + 8, LDT = 68;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  E* wS = reinterpret_cast<E*>(smem);                          // [64][LDW]: rows g * 16 + n = gate g of unit u0 + n
+  float* tile = reinterpret_cast<float*>(wS + 64 * LDW);       // [64][LDT]: pre-activations, [batch row][g * 16 + n]
+  __shared__ int dead;
+  // affinity (speed only): blocks with equal blockIdx % 8 share an XCD; direction z takes `xpd` of the 8 groups
+  const int grp = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int z = grp % a.ndir, slot = grp / a.ndir + a.xpd * kk;
+  if (grp / a.ndir >= a.xpd || slot >= WPX) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+  const int B = a.B, Tn = a.T, u0 = slot * 16;
+  const E* gx = reinterpret_cast<const E*>(a.gx);
+  const E* whh = reinterpret_cast<const E*>(a.whh);
+  E* act = reinterpret_cast<E*>(a.act);
+  E* hp = reinterpret_cast<E*>(a.hp);
+  E* y = reinterpret_cast<E*>(a.y);
+  E* hz = reinterpret_cast<E*>(a.hist) + (int64_t)z * Tn * (H * 64);
+  for (int i = tid; i < 64 * (H / 8); i += 256) {
+    const int row = i / (H / 8), ch = i - row * (H / 8);
+    *reinterpret_cast<bf16x8*>(wS + row * LDW + ch * 8) =
+        *reinterpret_cast<const bf16x8*>(whh + ((int64_t)z * 4 * H + (row >> 4) * H + u0 + (row & 15)) * H + ch * 8);
+  }
+  if (tid == 0) dead = 0;
+  __syncthreads();
+  // this thread's cells: batch row m, units j0 .. j0 + 3 (all four gates); rows past B repeat row B - 1 (never stored,
+  // except into the history, whose rows other workgroups read as MFMA operand rows: they must be finite)
+  const int m = tid >> 2, q = tid & 3, j0 = u0 + 4 * q;
+  const bool real = m < B;
+  const int bc = min(m, B - 1);
+  const int64_t zb = (int64_t)z * B + bc;
+  const int L = a.len[bc];
+  typedef __attribute__((ext_vector_type(4))) E E4;
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  E4 hprev = {(E)0.f, (E)0.f, (E)0.f, (E)0.f};
+  E4 gxv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) gxv[g] = *reinterpret_cast<const E4*>(gx + (zb * Tn + 0) * 4 * H + g * H + j0);
+  for (int s = 0; s < Tn; ++s) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {          // (h_{-1} = 0: step 0 has no recurrent part; s is uniform)
+      seq_wait(a.sync + z, s * WPX, a.sync + 8, &dead);
+      const E* hsrc = hz + (int64_t)(s - 1) * (H * 64);
+      bf16x8 af[KS];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        const int kk = k * 32 + kq * 8;
+        af[k] = ld16_sc1(hsrc + ((kk >> 4) * 64 + w * 16 + r16) * 16 + (kk & 15));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(af[k]));
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+          acc[g] = mfma16<E>(af[k], *reinterpret_cast<const bf16x8*>(wS + (g * 16 + r16) * LDW + k * 32 + kq * 8), acc[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[(w * 16 + kq * 4 + r) * LDT + g * 16 + r16] = acc[g][r];   // D[batch][gate g, unit r16]
+    __syncthreads();
+    f32x4 pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = *reinterpret_cast<const f32x4*>(tile + m * LDT + g * 16 + 4 * q);
+    const int64_t ga = (zb * Tn + s) * 4 * H + j0;
+    const int64_t ca = (zb * Tn + s) * H + j0;
+    E4 av[4], hn;
+    f32x4 cn4;
+    if (s >= L) {          // past this sample's length: state frozen, nothing emitted, zero gate record
+#pragma unroll
+      for (int g = 0; g < 4; ++g) av[g] = (E4){(E)0.f, (E)0.f, (E)0.f, (E)0.f};
+      hn = hprev;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cn4[e] = c[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ig = sigm((float)gxv[0][e] + pre[0][e]);
+        const float fg = sigm((float)gxv[1][e] + pre[1][e]);
+        const float gg = tanh_f((float)gxv[2][e] + pre[2][e]);
+        const float og = sigm((float)gxv[3][e] + pre[3][e]);
+        const float cn = fg * c[e] + ig * gg;
+        c[e] = cn; cn4[e] = cn;
+        hn[e] = (E)(og * tanh_f(cn));
+        av[0][e] = (E)ig; av[1][e] = (E)fg; av[2][e] = (E)gg; av[3][e] = (E)og;
+      }
+    }
+    if (real) {
+      *reinterpret_cast<E4*>(hp + ca) = hprev;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<E4*>(act + ga + g * H) = av[g];
+      *reinterpret_cast<f32x4*>(a.cs + ca) = cn4;
+      if (s < L) {
+        const int t = (z & 1) == 0 ? s : L - 1 - s;
+        *reinterpret_cast<E4*>(y + (((int64_t)(z >> 1) * B + m) * Tn + t) * 2 * H + (z & 1) * H + j0) = hn;
+      }
+    }
+    hprev = hn;
+    st8_sc1(hz + (int64_t)s * (H * 64) + (slot * 64 + m) * 16 + 4 * q, __builtin_bit_cast(u32x2, hn));
+    if (s + 1 < Tn) {
+      seq_arrive(a.sync + z);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gxv[g] = *reinterpret_cast<const E4*>(gx + (zb * Tn + s + 1) * 4 * H + g * H + j0);
+    }
+  }
+}
+
+// Backward of the whole recurrence in one launch.  Step s needs dh = dg_{s+1} . W_hh with K = 4H: EVERY workgroup's gate
+// gradients of step s + 1 -- the gate-gradient tensor dg [Z][B][T][4H] is itself the exchange buffer (each (b, s) row is
+// written once, with write-through stores, and read as MFMA operand rows).  What a step costs is that read: a workgroup
+// needs the full 4H-wide rows of its batch rows.  First form: (16 units x 64 batch rows) per workgroup = 128-256 KB per
+// workgroup and step through a handful of CUs -- 5.5 / 12 us per step at H = 256 / 512, slower than the per-step
+// launches.  Now workgroup = (direction z, 16 units, 16 batch rows): 32-64 KB per step, four times the workgroups (all
+// 256 CUs at H = 512), spread over the XCDs (the protocol does not care where they run).  512 threads: wave w takes the
+// k-steps w, w + 8, ... of K = 4H (4-8 sixteen-byte operand loads per lane), the eight partial 16 x 16 tiles are summed
+// through LDS; threads 0..63 then own (batch row, 4 units) cells; dc stays in registers over all steps.
+template <typename E, int HH>
+__global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(SeqArgs a) {
+  constexpr int H = HH, KT = 4 * HH / 32, KW = KT / 8, WPX = (HH / 16) * 4, LDW = 4 * HH + 8, LDP = 17;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  E* wT = reinterpret_cast<E*>(smem);                          // [16][LDW]: row n = W_hh^T row of unit u0 + n (K = 4H)
+  float* part = reinterpret_cast<float*>(wT + 16 * LDW);       // [8 waves][16][LDP]
+  __shared__ int dead;
+  // affinity (speed only): blocks with equal blockIdx % 8 share an XCD; direction z takes `xpd` of the 8 groups
+  const int grp = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int z = grp % a.ndir, role = grp / a.ndir + a.xpd * kk;
+  if (grp / a.ndir >= a.xpd || role >= WPX) return;
+  const int slot = role >> 2, bq = role & 3;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+  const int B = a.B, Tn = a.T, u0 = slot * 16, b0 = bq * 16;
+  const E* whht = reinterpret_cast<const E*>(a.whh);           // [Z][H][4H]
+  const E* act = reinterpret_cast<const E*>(a.act);
+  const E* dy = reinterpret_cast<const E*>(a.dy);
+  E* dg = reinterpret_cast<E*>(a.dg);
+  for (int i = tid; i < 16 * (4 * H / 8); i += 512) {
+    const int row = i / (4 * H / 8), ch = i - row * (4 * H / 8);
+    *reinterpret_cast<bf16x8*>(wT + row * LDW + ch * 8) =
+        *reinterpret_cast<const bf16x8*>(whht + ((int64_t)z * H + u0 + row) * 4 * H + ch * 8);
+  }
+  if (tid == 0) dead = 0;
+  __syncthreads();
+  const bool cell = tid < 64;
+  const int m = (tid & 63) >> 2, q = tid & 3, j0 = u0 + 4 * q;      // cell: batch row b0 + m, units j0 .. j0 + 3
+  const bool real = cell && b0 + m < B;
+  const int bc = min(b0 + m, B - 1);
+  const int64_t zb = (int64_t)z * B + bc;
+  const int L = a.len[bc];
+  const int arow = min(b0 + r16, B - 1);                       // this lane's MFMA operand row (batch)
+  typedef __attribute__((ext_vector_type(4))) E E4;
+  float dcv[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = Tn - 1; s >= 0; --s) {
+    // this step's pointwise operands first (independent of the recurrence: they fly under the wait)
+    const int64_t ga = (zb * Tn + s) * 4 * H + j0;
+    const int64_t ca = (zb * Tn + s) * H + j0;
+    E4 av[4], dyv;
+    f32x4 cn4, cp4;
+    if (cell) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) av[g] = *reinterpret_cast<const E4*>(act + ga + g * H);
+      cn4 = *reinterpret_cast<const f32x4*>(a.cs + ca);
+      cp4 = *reinterpret_cast<const f32x4*>(a.cs + (zb * Tn + max(s - 1, 0)) * H + j0);
+      const int t = min(max((z & 1) == 0 ? s : L - 1 - s, 0), Tn - 1);
+      dyv = *reinterpret_cast<const E4*>(dy + (((int64_t)(z >> 1) * B + bc) * Tn + t) * 2 * H + (z & 1) * H + j0);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (s + 1 < Tn) {        // dh = dg_{s+1} . W_hh (nothing flows into the last step)
+      seq_wait(a.sync + z, (Tn - 1 - s) * WPX, a.sync + 8, &dead);
+      const E* src = dg + (((int64_t)z * B + arow) * Tn + s + 1) * 4 * H + kq * 8;
+      bf16x8 af[KW];
+#pragma unroll
+      for (int k = 0; k < KW; ++k) af[k] = ld16_sc1(src + (w + 8 * k) * 32);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < KW; ++k) asm volatile("" : "+v"(af[k]));
+      const E* wr = wT + r16 * LDW + kq * 8;
+#pragma unroll
+      for (int k = 0; k < KW; ++k) acc = mfma16<E>(af[k], *reinterpret_cast<const bf16x8*>(wr + (w + 8 * k) * 32), acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[(w * 16 + kq * 4 + r) * LDP + r16] = acc[r];      // D[batch kq*4 + r][unit r16]
+    __syncthreads();
+    if (cell) {
+      E4 dgv[4];
+      if (s >= L) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dgv[g] = (E4){(E)0.f, (E)0.f, (E)0.f, (E)0.f};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = 4 * q + e;
+          float dht = (float)dyv[e];
+#pragma unroll
+          for (int ww = 0; ww < 8; ++ww) dht += part[(ww * 16 + m) * LDP + n];
+          const float ig = (float)av[0][e], fg = (float)av[1][e], gg = (float)av[2][e], og = (float)av[3][e];
+          const float cp = s > 0 ? cp4[e] : 0.f;
+          const float th = tanh_f(cn4[e]);
+          const float dct = dcv[e] + dht * og * (1.f - th * th);
+          dcv[e] = dct * fg;
+          dgv[0][e] = (E)(dct * gg * ig * (1.f - ig));
+          dgv[1][e] = (E)(dct * cp * fg * (1.f - fg));
+          dgv[2][e] = (E)(dct * ig * (1.f - gg * gg));
+          dgv[3][e] = (E)(dht * th * og * (1.f - og));
+        }
+      }
+      if (real) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st8_sc1(dg + ga + g * H, __builtin_bit_cast(u32x2, dgv[g]));
+      }
+    }
+    if (s > 0) seq_arrive(a.sync + z);     // (also the barrier that frees `part` for the next step)
+  }
+}
+
 // dst[b][s][:] = s < len_b ? src[b][len_b - 1 - s][:] : 0   (its own inverse on the valid part: also maps gradients back)
 template <typename T>
 __global__ __launch_bounds__(256) void lstm_reverse_rows_kernel(const T* __restrict__ src, const int* __restrict__ len,
@@ -312,6 +587,91 @@ extern "C" int vmr_lstm_step_bwd(const void* dy, const void* act, const void* cs
                                     (const E*)act, (const float*)cs, len, (const E*)whht, (float*)dc, (E*)dg, B, T, s))
   if (H == 256) VMR_LSTM_BWD(256); else VMR_LSTM_BWD(512);
 #undef VMR_LSTM_BWD
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_lstm_seq_supported(int B, int H, int ndir, int dtype) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("VMR_LSTM_SEQ");     // A/B switch: 0 = one launch per step
+    on = e && atoi(e) == 0 ? 0 : 1;
+  }
+  // (every workgroup of a launch must be resident at once: forward 8 * H/16, backward ndir * H/16 * 4 of them, one per CU)
+  return on && vmr_dtype_16(dtype) && (H == 256 || H == 512) && B >= 1 && B <= 64 && ndir >= 2 && ndir <= 8 && ndir % 2 == 0 &&
+         ndir * (H / 16) * 4 <= 256;
+}
+
+extern "C" int vmr_lstm_seq_hist_bytes(int T, int H, int ndir, int64_t* bytes) {
+  VMR_CHECK(bytes && T > 0 && H > 0 && ndir > 0, "vmr_lstm_seq_hist_bytes: bad argument");
+  *bytes = (int64_t)ndir * T * H * 64 * 2;
+  return 0;
+}
+
+extern "C" int vmr_lstm_seq_fwd(const void* gx, const void* whh, const int* len, void* act, void* cs, void* hp, void* y, void* hist,
+                                int* sync, int B, int T, int H, int ndir, int dtype, void* stream) {
+  VMR_CHECK(vmr_lstm_seq_supported(B, H, ndir, dtype), "vmr_lstm_seq_fwd: unsupported B=%d H=%d ndir=%d dtype=%d", B, H, ndir, dtype);
+  VMR_CHECK(gx && whh && len && act && cs && hp && y && hist && sync, "vmr_lstm_seq_fwd: null pointer");
+  VMR_CHECK(T > 0, "vmr_lstm_seq_fwd: T = %d", T);
+  VMR_CHECK((((uintptr_t)gx | (uintptr_t)whh | (uintptr_t)act | (uintptr_t)cs | (uintptr_t)hp | (uintptr_t)y | (uintptr_t)hist) & 15) == 0,
+            "vmr_lstm_seq_fwd: 16-byte alignment");
+  SeqArgs a;
+  memset(&a, 0, sizeof(a));
+  a.gx = gx; a.whh = whh; a.len = len; a.act = act; a.cs = (float*)cs; a.hp = hp; a.y = y; a.hist = hist; a.sync = sync;
+  a.B = B; a.T = T; a.ndir = ndir;
+  const size_t lds = (size_t)64 * (H + 8) * 2 + (size_t)64 * 68 * 4;
+  // a direction's H/16 workgroups share ONE XCD group here (measured at H = 256: 340 us per layer against 388 spread
+  // over four; the backward, with four times the workgroups and payload, is the other way round: 652 against 415)
+  static int xpd_env = -1;
+  if (xpd_env < 0) { const char* e = getenv("VMR_LSTM_SEQ_XPD_FWD"); xpd_env = e ? atoi(e) : 0; }
+  a.xpd = xpd_env > 0 ? xpd_env : 1;
+  if (a.xpd * ndir > 8) a.xpd = 8 / ndir;
+  const dim3 grid(8 * ((H / 16 + a.xpd - 1) / a.xpd));
+#define VMR_LSTM_SEQ_FWD(HH)                                                                                           \
+  VMR_DISPATCH16(dtype, E, do {                                                                                        \
+    const void* fn = (const void*)lstm_seq_fwd_kernel<E, HH>;                                                          \
+    if (lds > 64 * 1024) {                                                                                             \
+      hipError_t e_ = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+      if (e_ != hipSuccess) return vmr_fail(-5, "vmr_lstm_seq_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e_));   \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((lstm_seq_fwd_kernel<E, HH>), grid, dim3(256), lds, (hipStream_t)stream, a);                    \
+  } while (0))
+  if (H == 256) VMR_LSTM_SEQ_FWD(256); else VMR_LSTM_SEQ_FWD(512);
+#undef VMR_LSTM_SEQ_FWD
+  VMR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vmr_lstm_seq_bwd(const void* dy, const void* act, const void* cs, const int* len, const void* whht, void* dg, int* sync,
+                                int B, int T, int H, int ndir, int dtype, void* stream) {
+  VMR_CHECK(vmr_lstm_seq_supported(B, H, ndir, dtype), "vmr_lstm_seq_bwd: unsupported B=%d H=%d ndir=%d dtype=%d", B, H, ndir, dtype);
+  VMR_CHECK(dy && act && cs && len && whht && dg && sync, "vmr_lstm_seq_bwd: null pointer");
+  VMR_CHECK(T > 0, "vmr_lstm_seq_bwd: T = %d", T);
+  VMR_CHECK((((uintptr_t)dy | (uintptr_t)act | (uintptr_t)cs | (uintptr_t)whht | (uintptr_t)dg) & 15) == 0, "vmr_lstm_seq_bwd: 16-byte alignment");
+  SeqArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dy = dy; a.act = const_cast<void*>(act); a.cs = (float*)const_cast<void*>(cs); a.len = len; a.whh = whht; a.dg = dg; a.sync = sync;
+  a.B = B; a.T = T; a.ndir = ndir;
+  const size_t lds = (size_t)16 * (4 * H + 8) * 2 + (size_t)8 * 16 * 17 * 4;
+  // roles per direction = (16-unit slice, 16-row batch quarter); a direction's workgroups are spread over its share of
+  // the eight XCD groups
+  const int roles = (H / 16) * 4;
+  static int xpd_env = -1;
+  if (xpd_env < 0) { const char* e = getenv("VMR_LSTM_SEQ_XPD"); xpd_env = e ? atoi(e) : 0; }
+  a.xpd = xpd_env > 0 ? xpd_env : 8 / ndir;      // (measured at H = 256: all 64 workgroups on one XCD 652 us per layer, spread over four 415)
+  if (a.xpd * ndir > 8) a.xpd = 8 / ndir;
+  const dim3 grid(8 * ((roles + a.xpd - 1) / a.xpd));
+#define VMR_LSTM_SEQ_BWD(HH)                                                                                           \
+  VMR_DISPATCH16(dtype, E, do {                                                                                        \
+    const void* fn = (const void*)lstm_seq_bwd_kernel<E, HH>;                                                          \
+    if (lds > 64 * 1024) {                                                                                             \
+      hipError_t e_ = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+      if (e_ != hipSuccess) return vmr_fail(-5, "vmr_lstm_seq_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e_));   \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((lstm_seq_bwd_kernel<E, HH>), grid, dim3(512), lds, (hipStream_t)stream, a);                    \
+  } while (0))
+  if (H == 256) VMR_LSTM_SEQ_BWD(256); else VMR_LSTM_SEQ_BWD(512);
+#undef VMR_LSTM_SEQ_BWD
   VMR_LAUNCH_CHECK();
   return 0;
 }
