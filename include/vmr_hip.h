@@ -639,6 +639,13 @@ int vmr_lstm_reverse_rows(const void* src, const int32_t* len, void* dst, int B,
  * Equal scores keep cell order.  Fails (-22) when a clip yields a count != n_out. */
 int vmr_ban_sample_host(const float* scores, const int32_t* cells, int B, int C, float thresh, int topk, int neighbor,
                         int negative, int n_out, int64_t* out);
+/* The same sampling ON THE DEVICE (csrc/sampler.hip), one workgroup per clip: bitonic sort of the scores in LDS, the greedy
+ * pick-and-suppress with block-wide min / prefix sums, the output assembly.  Same order, tie rule (equal scores keep cell
+ * order, NaN first) and float arithmetic as vmr_ban_sample_host; lets the BAN train step be ONE captured graph (no
+ * device-to-host hop between the map stage and the proposal head).  scores, cells, out as above but DEVICE pointers;
+ * status: device int32 [B] = proposals produced per clip (== n_out when the reference's view would succeed).  C <= 8192. */
+int vmr_ban_sample(const float* scores, const int32_t* cells, int B, int C, float thresh, int topk, int neighbor,
+                   int negative, int n_out, int64_t* out, int32_t* status, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,7 @@ per-sample masked-select loop).  The one host round trip per step is the sampler
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -60,6 +61,7 @@ class BAN(nn.Module):
         super().__init__()
         m = cfg.model
         self.vlen, self.topk, self.neighbor, self.negative, self.prop_num = m.vlen, m.topk, m.neighbor, m.negative, m.prop_num
+        self.device_sampler = os.environ.get("VMR_BAN_DEVICE_SAMPLER", "1") != "0"     # csrc/sampler.hip instead of the host routine
         vocab_size = pre_train_emb.shape[0]
         droprate = float(getattr(m, "droprate", 0.1))
         trunk = BANTrunk(vocab_size, m.vdim, m.dim, m.lstm_layer, m.query_embed_dim, m.fuse_dim, m.vlen, pre_train_emb,
@@ -111,6 +113,29 @@ class BAN(nn.Module):
                                negative=self.negative, n_out=self.prop_num)       # vmr_ban_sample_host (C++, host threads)
         return torch.from_numpy(pse)
 
+    def sample_device(self, tmap_cells):
+        """The same sampling without leaving the device (csrc/sampler.hip, one workgroup per clip): sigmoid + reorder to the
+        reference's mask.nonzero() cell order, vmr_ban_sample.  Returns DEVICE int64 [B, prop_num, 2]; `self.sample_status`
+        (device int32 [B]) holds the proposals produced per clip (== prop_num unless the reference's view would fail).
+        Capturable: no host round trip, so the whole train step can be one hipGraph."""
+        from . import _lib as L
+        lay, N = self._pmap.layout, self.vlen
+        dev = tmap_cells.device
+        cache = getattr(self, "_sampler_tabs", None)
+        if cache is None or cache[0].device != dev:
+            rm = np.argsort(lay.ii.astype(np.int64) * N + lay.jj, kind="stable")
+            cells = np.stack([lay.ii[rm], lay.jj[rm]], axis=1).astype(np.int32)
+            cache = self._sampler_tabs = (torch.from_numpy(rm).to(dev), torch.from_numpy(np.ascontiguousarray(cells)).to(dev))
+        rm_d, cells_d = cache
+        score = torch.sigmoid(tmap_cells.detach().float())[:, rm_d].contiguous()
+        B, C = score.shape
+        pse = torch.empty(B, self.prop_num, 2, device=dev, dtype=torch.int64)
+        self.sample_status = torch.empty(B, device=dev, dtype=torch.int32)
+        L.check(L.lib().vmr_ban_sample(score.data_ptr(), cells_d.data_ptr(), B, C, float(self.sampler_thresh), int(self.topk),
+                                       int(self.neighbor), int(self.negative), int(self.prop_num), pse.data_ptr(),
+                                       self.sample_status.data_ptr(), L.stream_ptr()), "vmr_ban_sample")
+        return pse
+
     def forward_head(self, o, r, pred_s_e, offset_gt, video_seq_len):
         """gathers at the sampled cells, prop_pe -> prop_interact -> predictor2 / predictor_offset, contrast_encoder_t
         (BAN.py:98,107-118); pred_s_e: DEVICE int64 [B, prop_num, 2]"""
@@ -135,7 +160,8 @@ class BAN(nn.Module):
             torch.cuda.synchronize()
         start = time.time()
         o, r = self.forward_map(data_visual, data_text, video_seq_len, text_seq_len)
-        pred_s_e = self.sample(r["tmap_cells"]).to(data_visual.device)
+        pred_s_e = self.sample_device(r["tmap_cells"]) if self.device_sampler else \
+            self.sample(r["tmap_cells"]).to(data_visual.device)
         out = self.forward_head(o, r, pred_s_e, offset_gt, video_seq_len)
         if sync:
             torch.cuda.synchronize()

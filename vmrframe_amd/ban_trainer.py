@@ -1,9 +1,13 @@
-"""A BAN training step as TWO hipGraphs around the proposal sampler's host round trip.
+"""A BAN training step as ONE hipGraph (the proposal sampler runs on the device, csrc/sampler.hip), or -- with the host
+sampler (`model.device_sampler = False`) -- as TWO graphs around its host round trip:
 
     graph A   zero_grad, forward_map (encoders ... 2-D map, predictor)
     host      sigmoid(tmap) at the kept cells -> vmr_ban_sample_host -> [B, prop_num, 2] copied into a static device buffer
     graph B   forward_head, the five losses, the WHOLE backward (it walks the autograd graph built while A was captured: the
               two graphs share one memory pool, so A's saved tensors stay valid), the optimizer
+
+One graph: graph A's launches, vmr_ban_sample into the same static buffer, graph B's launches -- no device-to-host copy,
+no host threads, no idle GPU in the middle of the step.
 
 The eager step issues ~2500 launches of 5-80 us from Python (14 us of host time each): 34.5 ms with 25 ms of kernel time
 (profiles/r02_ban_summary.md).  Dropout stays a fresh draw per replay: the slices' DropCtx seeds are mixed with a device
@@ -56,6 +60,9 @@ class GraphedBANStep:
     def _host(self):
         self.pse.copy_(self.model.sample(self.r["tmap_cells"]), non_blocking=False)
 
+    def _device_sample(self):
+        self.pse.copy_(self.model.sample_device(self.r["tmap_cells"]))
+
     def capture(self, data):
         m = self.model
         dev = next(m.parameters()).device
@@ -66,14 +73,24 @@ class GraphedBANStep:
         for h in (m._trunk, m._pmap, m._head):
             h.drop_step = self.step_t
         self.pse = torch.zeros(self.data["vfeats"].shape[0], m.prop_num, 2, device=dev, dtype=torch.int64)
+        self.one_graph = bool(getattr(m, "device_sampler", False))
         s = self.stream = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(self.warmup):
-                self._part_a(); self._host(); self._part_b()
+                self._part_a()
+                self._device_sample() if self.one_graph else self._host()
+                self._part_b()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         m._cache.clear()                            # every weight cast must be recorded in the graphs
+        if self.one_graph:
+            self.gA = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.gA, stream=s):
+                self._part_a()
+                self._device_sample()
+                self._part_b()
+            return self
         self.gA, self.gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gA, stream=s):
             self._part_a()
@@ -92,6 +109,7 @@ class GraphedBANStep:
                                      f"capture() again)")
                 self.data[k].copy_(v, non_blocking=True)
         self.gA.replay()
-        self._host()
-        self.gB.replay()
+        if not self.one_graph:
+            self._host()
+            self.gB.replay()
         return self.loss
