@@ -271,10 +271,45 @@ def _rank_sharded(rank, world, port, outdir):
     # the captured multi-rank step with the sharded optimizer: three optimizer graphs around two exchanges
     step = GraphedTrainStep(m, opt, V.train_engine_SeqPAN, cfg, sh, warmup=2).capture(shard)
     assert step.sharded and len(step.g_parts) == 3 and step.g_opt is None
+    # a full, rank-independent snapshot of the optimizer state (foreign slices of the masters and of the Adam moments are
+    # stale by design: gather them)
+    sh.gather_masters(); sh.gather(opt.m); sh.gather(opt.v)
+    torch.cuda.synchronize()
+    w_start = A.flat_w.clone()
+    p_full, m_start, v_start, t_start = A.flat_p.clone(), opt.m.clone(), opt.v.clone(), opt.step_t.clone()
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    torch.save({"w": res, "wg": A.flat_w.cpu(), "logits": step.out["slogits"].float().cpu()}, os.path.join(outdir, f"sh{rank}.pt"))
+    w_sharded = A.flat_w.clone()
+    # the same two steps on the all-reduce path from the same state (a second model: the first one's graphs are captured):
+    # a kernel that read a STALE fp32 master on the rank that does not own it (e.g. a weight cast from the master instead of
+    # taken from the mirror) would show up here as a different forward pass
+    m2, _, _, _, _ = _build("g_cfg1", "bf16", dev)
+    m2.gumbel_override = g[rank::world].to(dev)
+    m2.backward_cuts = True
+    opt2 = FlatAdamW(m2, lr=1e-3, weight_decay=0.01, max_norm=1e9)
+    ar2 = dp.GradReducer(m2, opt2)
+    loss, _ = V.train_engine_SeqPAN(m2, shard, cfg, "train")
+    opt2.zero_grad(); ar2.backward(loss); ar2.finish(); opt2.step()
+    assert opt2.names == opt.names
+    opt2.arena.flat_p.copy_(p_full); opt2.m.copy_(m_start); opt2.v.copy_(v_start); opt2.step_t.copy_(t_start)
+    opt2.t = int(t_start.item())
+    opt2.sync_mirrors()
+    assert torch.equal(opt2.arena.flat_w, w_start)
+    step2 = GraphedTrainStep(m2, opt2, V.train_engine_SeqPAN, cfg, ar2, warmup=2)
+    # (capture() runs `warmup` eager steps first: restore the state after them)
+    step2.capture(shard)
+    opt2.arena.flat_p.copy_(p_full); opt2.m.copy_(m_start); opt2.v.copy_(v_start); opt2.step_t.copy_(t_start)
+    opt2.sync_mirrors()
+    for _ in range(2):
+        step2()
+    torch.cuda.synchronize()
+    d = (opt2.arena.flat_w.float() - w_sharded.float()).abs()
+    moved = (w_sharded.float() - w_start.float()).abs()
+    frac_equal = float((d == 0).float().mean())
+    assert float(moved.max()) > 0 and frac_equal > 0.995 and float(d.max()) <= 2 * float(moved.max()) * 0.02 + 1e-3, (frac_equal, float(d.max()))
+    torch.save({"w": res, "wg": A.flat_w.cpu(), "logits": step.out["slogits"].float().cpu(), "frac_equal": frac_equal},
+               os.path.join(outdir, f"sh{rank}.pt"))
     torch.distributed.destroy_process_group()
 
 

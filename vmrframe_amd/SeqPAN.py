@@ -293,9 +293,12 @@ class SeqPAN(nn.Module):
 
     def fp32_consumed(self):
         """Weight matrices some kernel reads from the fp32 MASTER rather than through the 16-bit mirror: the predictor's
-        positional table (ops.add_pos adds the fp32 rows).  optim.FlatArena keeps them in the all-reduced fp32 region
-        of their stage, so a sharded optimizer (dp.ShardedReducer) leaves a current copy on every rank."""
-        return ["predictor.feature_encoder.pos_embedding.position_embeddings.weight"]
+        positional table (ops.add_pos adds the fp32 rows) and the two input projections, whose K-padded compute copies
+        (V = 500 -> 512, 400 -> 512 columns) are cast from the master each step (ops.WeightCache.get).  optim.FlatArena
+        keeps them in the all-reduced fp32 region of their stage, so a sharded optimizer (dp.ShardedReducer) leaves a
+        current copy on every rank."""
+        return ["predictor.feature_encoder.pos_embedding.position_embeddings.weight",
+                "text_encoder.query_conv1d.conv1d.weight", "video_affine.video_conv1d.conv1d.weight"]
 
     # -- backward segments (data-parallel overlap) ---------------------------------
     SEGMENT_PREFIXES = (("text_encoder.", "video_affine.", "vfeat_encoder."), ("dual_attention_block_1.",),
