@@ -313,12 +313,17 @@ def main():
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="reduce-scatter + AdamW on the local 1/N slices + all-gather of the 16-bit mirrors (dp.ShardedReducer) "
                          "instead of all-reduce + replicated AdamW")
+    ap.add_argument("--timer-reps", type=int, default=3,
+                    help="back-to-back repeats of every timed GEMM launch in the two instrumented steps behind the timed region "
+                         "(1 under a profiler, so that the trace's per-step launch counts stay those of the step)")
     ap.add_argument("--force-split", action="store_true",
                     help="at --gpus 1: replay the multi-rank form of the step (one graph per backward stage + the optimizer "
                          "graph(s), reducer hand-over points on the host in between) so its host-hop cost is measured")
     ap.add_argument("--reduce-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="wire dtype of the gradient all-reduce (N > 1); fp32 = exact sum")
     args = ap.parse_args()
+    global TIMER_REPS
+    TIMER_REPS = max(1, args.timer_reps)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))            # nothing above this line has touched a GPU

@@ -51,18 +51,18 @@ def traffic(pat, label):
         if re.search(pat, r[0]): n += r[1]; t += r[1] * r[4]
     return {"kernel": label, "launches": nf, "FETCH_SIZE_KB": round(f, 2), "WRITE_SIZE_KB": round(w, 2),
             "hbm_bytes_per_launch": int((2 * f + w) * 1024), "mfma_util": round(t / n, 4) if n else None}
-tj = traffic(r"gemm_bf16_dma_kernel<false, false", "gemm_bf16_dma_kernel<false,false,64,2,{4|5}> (NT), all launches of one train step (mixed epilogues)")
+tj = traffic(r"gemm_(bf16_dma_kernel<false, false|e16_dma_kernelIDF16bLb0ELb0E)", "gemm_e16_dma_kernel<bf16,false,false,{4|5},*> (NT), all launches of one train step (mixed epilogues)")
 tj["source"] = ("rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE (three separate passes) over "
                 "`python bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline`; launch-weighted means (scratch/profile_round2.sh)")
 tj["correction"] = "gfx950: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact"
-tj["merged"] = traffic(r"gemm_bf16_dma2_kernel", "gemm_bf16_dma2_kernel<{4|5}> (dW slabs + dX + previous layer's slab reduction), all launches of one train step")
+tj["merged"] = traffic(r"gemm_(bf16|e16)_dma2_kernel", "gemm_e16_dma2_kernel<bf16,{4|5}> (dW slabs + dX + previous layer's slab reduction), all launches of one train step")
 tj["cq_apply_fwd"] = traffic(r"cq_apply_fwd", "cq_apply_fwd_{clong,cshort} (fused CQAttention apply stage)")
 tj["cq_score"] = traffic(r"cq_score_kernel", "cq_score_kernel")
 json.dump(tj, open(os.path.join(P, "gemm_traffic.json"), "w"), indent=1)
 with open(os.path.join(P, f"{tag}_summary.md"), "w") as o:
-    o.write(f"# Round 2, {tag} -- rocprofv3 of the default bench\n\n")
+    o.write(f"# {tag} -- rocprofv3 of the default bench\n\n")
     o.write("Commands (scratch/profile_round2.sh, 1x MI355X, cfg2, bf16, dropout 0.2): `rocprofv3 --kernel-trace --stats --output-format csv -- "
-            "python3 bench.py --steps 100 --warmup 2 --no-cpu-baseline` (hipGraph replay; 100 timed steps so that the one-time set-up kernels -- parameter init, arena build -- stay below 1 % of the totals); then three PMC-only passes over "
+            "python3 bench.py --steps 100 --warmup 2 --no-cpu-baseline --timer-reps 1` (hipGraph replay; 100 timed steps so that the one-time set-up kernels -- parameter init, arena build -- stay below 1 % of the totals); then three PMC-only passes over "
             "`python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline`: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, "
             "`--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_WAVE_CYCLES GRBM_GUI_ACTIVE`.\n\n")
     if bench:
