@@ -111,10 +111,10 @@ def run_ban(args, dev, rank, world):
                           "warmup": max(3, args.warmup), "ms_per_step": round(ms, 3), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                           "config": {"workload": "BAN (configs[4], next-row N2): B=64 clips/GPU, T=128, 20-word queries, vdim 1024, dim 256, "
-                                                 "2 LSTM layers, fuse_dim 512, 5376 map cells, 80 proposals; forward (host sampler "
+                                                 "2 LSTM layers, fuse_dim 512, 5376 map cells, 80 proposals; forward (proposal sampler on the device "
                                                  "included) + five losses + backward + clip + AdamW (" +
                                                  ("torch.optim" if torch_opt else "flat fused, loss scale %g" % opt.loss_scale()) +
-                                                 "); two hipGraphs around the sampler unless --no-graph; replicas only for N > 1",
+                                                 "); one hipGraph (VMR_BAN_DEVICE_SAMPLER=0: two, around the host sampler) unless --no-graph; replicas only for N > 1",
                                      "global_batch": B * world, "parallelism": f"dp{world}"},
                           "final_loss": round(float(loss.detach()), 4), "hipgraph": graphed, "roofline": None, "cpu_baseline": None}))
     return 0

@@ -647,6 +647,15 @@ int vmr_ban_sample_host(const float* scores, const int32_t* cells, int B, int C,
 int vmr_ban_sample(const float* scores, const int32_t* cells, int B, int C, float thresh, int topk, int neighbor,
                    int negative, int n_out, int64_t* out, int32_t* status, void* stream);
 
+/* sim[b, c] = <q_b, y_bc> / (max(|y_bc|, 1e-30) * (1 + 1e-8)) with q unit-normalised by the caller: the cosine similarity of
+ * BAN's ContrastLoss (reference models/BANlib/model.py:639-671) between the sentence projection and every compact map cell's
+ * projection, one pass over y [B, C, D] forward and one backward (dy written, dq [B, D] fp32 ACCUMULATED).  rnorm [B, C] =
+ * 1 / max(|y|, 1e-30) is kept for the backward.  D in {8, 16, 32, 64, 128}. */
+int vmr_cos_rows_supported(int D);
+int vmr_cos_rows_fwd(const float* q, const void* y, float* sim, float* rnorm, int B, int C, int D, int dtype, void* stream);
+int vmr_cos_rows_bwd(const float* q, const void* y, const float* sim, const float* rnorm, const float* dsim, void* dy,
+                     float* dq, int B, int C, int D, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,6 +145,9 @@ SIGNATURES = {
     "vmr_lstm_step_supported": [_I, _I],
     "vmr_ban_sample_host": [_P, _P, _I, _I, _F, _I, _I, _I, _I, _P],
     "vmr_ban_sample": [_P, _P, _I, _I, _F, _I, _I, _I, _I, _P, _P, _P],
+    "vmr_cos_rows_supported": [_I],
+    "vmr_cos_rows_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vmr_cos_rows_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vmr_lstm_step_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_lstm_step_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_add_pos_fwd": [_P, _P, _P, _L, _I, _I, _I, _P],

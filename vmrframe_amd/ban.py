@@ -28,6 +28,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .ban_head import BANHead
 from .ban_map import ProposalMap2D, infer_tmap
 from .ban_sampler import sample_proposals
@@ -169,6 +170,9 @@ class BAN(nn.Module):
         return out
 
 
+FUSED_COS = os.environ.get("VMR_BAN_FUSED_COS", "1") != "0"
+
+
 def temporal_difference_loss(td, position_mask):
     """reference models/BANlib/model.py:674-684"""
     logp = torch.log_softmax(td.float(), dim=-1)
@@ -181,9 +185,12 @@ def contrast_loss(sen_proj, proj_cells, pos_cells, neg_cells, tao=1.0):
     and one negative cell, -log(sum_pos exp(cos) / (sum_pos+neg exp(cos) + 1e-8)), averaged over those clips."""
     q = sen_proj.float()
     q = q / (torch.linalg.norm(q, dim=-1, keepdim=True) + 1e-8)
-    y = proj_cells.float()
-    y = y / torch.linalg.norm(y, dim=-1, keepdim=True).clamp(min=1e-30)
-    sim = torch.einsum("bd,bcd->bc", q, y) / (1.0 + 1e-8)
+    if FUSED_COS and ops.cos_rows_supported(proj_cells):
+        sim = ops.cos_rows(q, proj_cells)          # one pass over the [B, C, D] cells each way (csrc/cosine.hip)
+    else:
+        y = proj_cells.float()
+        y = y / torch.linalg.norm(y, dim=-1, keepdim=True).clamp(min=1e-30)
+        sim = torch.einsum("bd,bcd->bc", q, y) / (1.0 + 1e-8)
     e = torch.exp(sim / tao)
     pos, neg = pos_cells.float(), neg_cells.float()
     num = (e * pos).sum(-1)

@@ -1342,6 +1342,45 @@ def ln_dwconv(x, gamma, beta, w, eps, segs, tee=False, cache=None):
 
 
 # ---------------------------------------------------------------------------
+# cosine similarity of one unit vector per clip against every row of [B, C, D] (BAN ContrastLoss)
+# ---------------------------------------------------------------------------
+class _CosRows(torch.autograd.Function):
+    """sim [B, C] fp32 = <q_b, y_bc> / (max(|y_bc|, 1e-30) (1 + 1e-8)); q fp32 [B, D] unit rows, y [B, C, D] in the compute
+    dtype (reference models/BANlib/model.py:639-671).  One pass over y each way (csrc/cosine.hip)."""
+
+    @staticmethod
+    def forward(ctx, q, y):
+        L.require_gpu(q, y)
+        q = q.float().contiguous()
+        y = y.contiguous()
+        B, Cn, D = y.shape
+        sim = torch.empty(B, Cn, device=y.device, dtype=torch.float32)
+        rn = torch.empty_like(sim)
+        L.check(L.lib().vmr_cos_rows_fwd(q.data_ptr(), y.data_ptr(), sim.data_ptr(), rn.data_ptr(), B, Cn, D, L.dtype_code(y),
+                                         L.stream_ptr()), "vmr_cos_rows_fwd")
+        ctx.save_for_backward(q, y, sim, rn)
+        return sim
+
+    @staticmethod
+    def backward(ctx, dsim):
+        q, y, sim, rn = ctx.saved_tensors
+        B, Cn, D = y.shape
+        dy = torch.empty_like(y)
+        dq = torch.zeros_like(q)
+        L.check(L.lib().vmr_cos_rows_bwd(q.data_ptr(), y.data_ptr(), sim.data_ptr(), rn.data_ptr(), dsim.float().contiguous().data_ptr(),
+                                         dy.data_ptr(), dq.data_ptr(), B, Cn, D, L.dtype_code(y), L.stream_ptr()), "vmr_cos_rows_bwd")
+        return dq, dy
+
+
+def cos_rows_supported(y) -> bool:
+    return y.is_cuda and y.dim() == 3 and bool(L.lib().vmr_cos_rows_supported(int(y.shape[2])))
+
+
+def cos_rows(q, y):
+    return _CosRows.apply(q, y)
+
+
+# ---------------------------------------------------------------------------
 # the whole DepthwiseSeparableConvBlock as ONE autograd node (fused row-kernel backward)
 # ---------------------------------------------------------------------------
 FUSED_CONV_BLOCK = os.environ.get("VMR_FUSED_CONVBLOCK", "1") != "0"
