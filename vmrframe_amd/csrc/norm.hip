@@ -73,38 +73,51 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     Vec8<float>::load(gamma + ic, gam[c]);
     Vec8<float>::load(beta + ic, bet[c]);
   }
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
-    float v[MAXC][8], pv[MAXC][8];
-    load_row<T, MAXC>(x + row * D, D, lane, v);
-    if (pos) {
+  // TWO rows per wave and iteration, both requested before either is reduced (one row at a time left a single row's loads
+  // in flight per wave: 3.6 TB/s)
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t row0 = (int64_t)blockIdx.x * 4 + wid; row0 < rows; row0 += 2 * stride) {
+    float v[2][MAXC][8], pv[2][MAXC][8];
+    int64_t rw[2] = {row0, row0 + stride};
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) Vec8<T>::load(pos + (int64_t)(row % S) * D + min((c * 64 + lane) * 8, D - 8), pv[c]);
-    }
-    float mean, rstd;
-    row_stats<MAXC>(v, D, lane, eps, mean, rstd);
-    if (lane == 0) {
-      if (mean_o) mean_o[row] = mean;
-      if (rstd_o) rstd_o[row] = rstd;
-    }
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-      const int i = (c * 64 + lane) * 8;
-      if (i >= D) continue;
-      const float (&g)[8] = gam[c];
-      const float (&b)[8] = bet[c];
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
+    for (int u = 0; u < 2; ++u) {
+      const int64_t rc = min(rw[u], rows - 1);
+      load_row<T, MAXC>(x + rc * D, D, lane, v[u]);
       if (pos) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += pv[c][e];
+        for (int c = 0; c < MAXC; ++c) Vec8<T>::load(pos + (int64_t)(rc % S) * D + min((c * 64 + lane) * 8, D - 8), pv[u][c]);
       }
-      if (drop_p > 0.f) {
-        const uint32_t keep = vmr_keep8(seed, (uint64_t)row * D + i, thresh);
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = ((keep >> e) & 1) ? o[e] * dscale : 0.f;
+    for (int u = 0; u < 2; ++u) {
+      const int64_t row = rw[u];
+      if (row >= rows) continue;          // wave-uniform
+      float mean, rstd;
+      row_stats<MAXC>(v[u], D, lane, eps, mean, rstd);
+      if (lane == 0) {
+        if (mean_o) mean_o[row] = mean;
+        if (rstd_o) rstd_o[row] = rstd;
       }
-      Vec8<T>::store(y + row * D + i, o);
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const int i = (c * 64 + lane) * 8;
+        if (i >= D) continue;
+        const float (&g)[8] = gam[c];
+        const float (&b)[8] = bet[c];
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[u][c][e] - mean) * rstd * g[e] + b[e];
+        if (pos) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += pv[u][c][e];
+        }
+        if (drop_p > 0.f) {
+          const uint32_t keep = vmr_keep8(seed, (uint64_t)row * D + i, thresh);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = ((keep >> e) & 1) ? o[e] * dscale : 0.f;
+        }
+        Vec8<T>::store(y + row * D + i, o);
+      }
     }
   }
 }
@@ -587,7 +600,7 @@ extern "C" int vmr_layernorm_fwd(const void* x, const float* gamma, const float*
   VMR_CHECK(x && gamma && beta && y, "vmr_layernorm_fwd: null pointer");
   VMR_CHECK(!pos || S > 0, "vmr_layernorm_fwd: pos needs S > 0");
   if (rows == 0) return 0;
-  const int grid = (int)min((int64_t)4096, (rows + 3) / 4);
+  const int grid = (int)min((int64_t)4096, (rows + 7) / 8);      // (two rows per wave and pass)
   VMR_DISPATCH(dtype, T, LN_DISPATCH(D, hipLaunchKernelGGL((ln_fwd_kernel<T, MC>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                       (const T*)x, gamma, beta, eps, (const T*)pos, S, (T*)y, mean, rstd,
                                       rows, D, drop_p, drop_seed, drop_step)));
