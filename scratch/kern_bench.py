@@ -44,4 +44,4 @@ dS=torch.empty_like(P)
 timeit("softmax_bwd self (drop)", lambda: lib.vmr_softmax_bwd(S.data_ptr(),Pk.data_ptr(),dS.data_ptr(),B*H,T,T,T,T,0.0625,1,0.2,7,None,st()), B*H*T*T*8)
 pm=torch.zeros(65_000_000,device=dev); gg=torch.randn_like(pm); m1=torch.zeros_like(pm); v1=torch.zeros_like(pm); dec=torch.ones(pm.numel(),device=dev,dtype=torch.uint8); gs=torch.zeros(1,device=dev)
 timeit("sumsq 65M", lambda: lib.vmr_sumsq(gg.data_ptr(),gs.data_ptr(),pm.numel(),st()), pm.numel()*4, iters=5)
-timeit("adamw 65M", lambda: lib.vmr_adamw(pm.data_ptr(),gg.data_ptr(),m1.data_ptr(),v1.data_ptr(),dec.data_ptr(),None,gs.data_ptr(),1.0,1e-4,0.9,0.999,1e-8,0.01,1,None,0.0,0.0,pm.numel(),st()), pm.numel()*(7*4+1), iters=5)
+timeit("adamw 65M", lambda: lib.vmr_adamw(pm.data_ptr(),gg.data_ptr(),m1.data_ptr(),v1.data_ptr(),dec.data_ptr(),None,0,gs.data_ptr(),1.0,1e-4,0.9,0.999,1e-8,0.01,1,None,0.0,0.0,None,pm.numel(),st()), pm.numel()*(7*4+1), iters=5)
