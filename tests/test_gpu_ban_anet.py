@@ -123,7 +123,9 @@ def test_ban_anet_fp32_matches_the_reference(dev):
 # The per-tensor worst cases are bias vectors of the four stacked 128-step LSTMs: a bias gradient is a sum of B*T = 256
 # signed gate gradients that cancel ~16-fold, so the 16-bit rounding of each term (2^-9 / 2^-12) is amplified by that
 # factor; fp16's three extra mantissa bits show up as the 3-10x smaller errors throughout.
-BOUNDS = {torch.bfloat16: dict(tmap=0.12, small=6e-2, loss=2e-3, gnorm=0.6, gproj=1.8, agree=0.6, glob=0.55),
+# (bf16 loss: the five-term sum moves by a few 1e-3 with the summation order of the recurrence -- 4e-4 with per-step LSTM
+#  launches, 4.5e-3 with the one-launch recurrence, on a score map that is 6e-2 off either way; fp16 stays below 6e-4)
+BOUNDS = {torch.bfloat16: dict(tmap=0.12, small=6e-2, loss=1e-2, gnorm=0.6, gproj=1.8, agree=0.6, glob=0.55),
           torch.float16: dict(tmap=1.2e-2, small=8e-3, loss=2e-3, gnorm=0.15, gproj=0.6, agree=0.9, glob=0.16)}
 
 

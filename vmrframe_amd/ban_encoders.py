@@ -59,6 +59,75 @@ def seq_kernel_gave_up() -> bool:
     return any(int(t[8].item()) != 0 for t in _SYNC_LOG)
 
 
+def _recur_fwd(gx, w_hh, lens, act, cs, hp, y, B, T, H, Z, dt, dc) -> str:
+    """The recurrence over all T steps for Z directions (gx = the x-part of every step's gates, biases included): fills
+    act / cs / hp (saved for the backward pass) and scatters h into y.  Returns the form it ran in -- "seq": ONE persistent
+    launch; "fused": product + gates + state in one launch per step; "plain": a product and a cell launch per step."""
+    lib, dev = L.lib(), gx.device
+    fused = bool(FUSED_STEP and lib.vmr_lstm_step_supported(H, dc))
+    if fused and SEQ_KERNEL and lib.vmr_lstm_seq_supported(B, H, Z, dc):
+        nbytes = C.c_int64(0)
+        L.check(lib.vmr_lstm_seq_hist_bytes(T, H, Z, C.byref(nbytes)), "vmr_lstm_seq_hist_bytes")
+        hist = torch.empty(nbytes.value, device=dev, dtype=torch.uint8)
+        sync = torch.zeros(16, device=dev, dtype=torch.int32)
+        L.check(lib.vmr_lstm_seq_fwd(gx.data_ptr(), w_hh.data_ptr(), lens.data_ptr(), act.data_ptr(), cs.data_ptr(),
+                                     hp.data_ptr(), y.data_ptr(), hist.data_ptr(), sync.data_ptr(), B, T, H, Z, dc,
+                                     L.stream_ptr()), "vmr_lstm_seq_fwd")
+        _note_sync(sync)
+        return "seq"
+    c = torch.zeros(Z, B, H, device=dev)
+    if fused:                    # h ping-pongs between two buffers
+        hb = torch.zeros(2, Z, B, H, device=dev, dtype=dt)
+        for s in range(T):
+            L.check(lib.vmr_lstm_step_fwd(gx.data_ptr(), hb[s & 1].data_ptr(), w_hh.data_ptr(), lens.data_ptr(),
+                                          c.data_ptr(), hb[(s + 1) & 1].data_ptr(), act.data_ptr(), cs.data_ptr(),
+                                          hp.data_ptr(), y.data_ptr(), B, T, H, s, Z, dc, L.stream_ptr()),
+                    "vmr_lstm_step_fwd")
+        return "fused"
+    hs = torch.zeros(Z, B, H, device=dev, dtype=dt)
+    gh = torch.zeros(Z, B, 4 * H, device=dev)
+    f32out = L.EPI_OUT_F32 if dc != L.F32 else 0
+    for s in range(T):
+        if s > 0:                                                 # gh[z] = hs[z] . w_hh[z]^T, every direction
+            ops.gemm(hs, w_hh, gh, B, 4 * H, H, 0, 0, H, H, 4 * H, dtype=dc, flags=f32out, Z1=Z,
+                     sA=(B * H, 0), sB=(4 * H * H, 0), sC=(B * 4 * H, 0))
+        L.check(lib.vmr_lstm_cell_fwd(gx.data_ptr(), gh.data_ptr(), lens.data_ptr(), c.data_ptr(), hs.data_ptr(),
+                                      act.data_ptr(), cs.data_ptr(), hp.data_ptr(), y.data_ptr(), B, T, H, s, Z, dc,
+                                      L.stream_ptr()), "vmr_lstm_cell_fwd")
+    return "plain"
+
+
+def _recur_bwd(dy, act, cs, lens, w_hh, mode, B, T, H, Z, dt, dc) -> torch.Tensor:
+    """dg [Z, B, T, 4H] (gradient of every step's pre-activation gates) from dy [Z/2, B, T, 2H], in the form the forward ran in."""
+    lib, dev = L.lib(), dy.device
+    dg = torch.empty(Z, B, T, 4 * H, device=dev, dtype=dt)
+    if mode == "seq":
+        whht = w_hh.transpose(1, 2).contiguous()                      # [Z, H, 4H]: the K-contiguous operand of dg . W_hh
+        sync = torch.zeros(16, device=dev, dtype=torch.int32)
+        L.check(lib.vmr_lstm_seq_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), whht.data_ptr(),
+                                     dg.data_ptr(), sync.data_ptr(), B, T, H, Z, dc, L.stream_ptr()), "vmr_lstm_seq_bwd")
+        _note_sync(sync)
+        return dg
+    dcell = torch.zeros(Z, B, H, device=dev)
+    if mode == "fused":
+        whht = w_hh.transpose(1, 2).contiguous()
+        for s in range(T - 1, -1, -1):
+            L.check(lib.vmr_lstm_step_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), whht.data_ptr(),
+                                          dcell.data_ptr(), dg.data_ptr(), B, T, H, s, Z, dc, L.stream_ptr()),
+                    "vmr_lstm_step_bwd")
+        return dg
+    dh = torch.zeros(Z, B, H, device=dev)
+    f32out = L.EPI_OUT_F32 if dc != L.F32 else 0
+    for s in range(T - 1, -1, -1):
+        L.check(lib.vmr_lstm_cell_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), dh.data_ptr(),
+                                      dcell.data_ptr(), dg.data_ptr(), B, T, H, s, Z, dc, L.stream_ptr()),
+                "vmr_lstm_cell_bwd")
+        if s > 0:  # dh[z] = dg[z][:, s, :] . w_hh[z]   (A rows strided by T*4H; W_hh is the [K][N] operand)
+            ops.gemm(dg[:, :, s], w_hh, dh, B, H, 4 * H, 0, 1, T * 4 * H, H, H, dtype=dc, flags=f32out, Z1=Z,
+                     sA=(B * T * 4 * H, 0), sB=(4 * H * H, 0), sC=(B * H, 0))
+    return dg
+
+
 class _BiLSTM(torch.autograd.Function):
     """y [K, B, T, 2H] = K independent bi-LSTMs advanced together (x [K, B, T, I], lens int32 [B] shared);
     w_ih [2K, 4H, I], w_hh [2K, 4H, H], bias [2K, 4H] (= b_ih + b_hh; rows 2k / 2k + 1 = forward / reverse direction of LSTM k),
@@ -80,40 +149,11 @@ class _BiLSTM(torch.autograd.Function):
         bias32 = bias.float().contiguous()
         for z in range(Z):                                                # x-part of every step, biases in the epilogue
             ops.mm(xs[z].view(B * T, I), w_ih[z], 0, 0, out=gx[z].view(B * T, 4 * H), bias=bias32[z], flags=L.EPI_BIAS)
-        c = torch.zeros(Z, B, H, device=dev)
         act = torch.empty(Z, B, T, 4 * H, device=dev, dtype=dt)
         cs = torch.empty(Z, B, T, H, device=dev)
         hp = torch.empty(Z, B, T, H, device=dev, dtype=dt)
         y = torch.zeros(K, B, T, 2 * H, device=dev, dtype=dt)
-        ctx.fused = bool(FUSED_STEP and lib.vmr_lstm_step_supported(H, dc))
-        ctx.seq = bool(ctx.fused and SEQ_KERNEL and lib.vmr_lstm_seq_supported(B, H, Z, dc))
-        if ctx.seq:              # the whole recurrence in ONE launch: persistent workgroups, a counter barrier per step
-            nbytes = C.c_int64(0)
-            L.check(lib.vmr_lstm_seq_hist_bytes(T, H, Z, C.byref(nbytes)), "vmr_lstm_seq_hist_bytes")
-            hist = torch.empty(nbytes.value, device=dev, dtype=torch.uint8)
-            sync = torch.zeros(16, device=dev, dtype=torch.int32)
-            L.check(lib.vmr_lstm_seq_fwd(gx.data_ptr(), w_hh.data_ptr(), lens.data_ptr(), act.data_ptr(), cs.data_ptr(),
-                                         hp.data_ptr(), y.data_ptr(), hist.data_ptr(), sync.data_ptr(), B, T, H, Z, dc,
-                                         L.stream_ptr()), "vmr_lstm_seq_fwd")
-            _note_sync(sync)
-        elif ctx.fused:          # product + gates + state in one launch per step; h ping-pongs between two buffers
-            hb = torch.zeros(2, Z, B, H, device=dev, dtype=dt)
-            for s in range(T):
-                L.check(lib.vmr_lstm_step_fwd(gx.data_ptr(), hb[s & 1].data_ptr(), w_hh.data_ptr(), lens.data_ptr(),
-                                              c.data_ptr(), hb[(s + 1) & 1].data_ptr(), act.data_ptr(), cs.data_ptr(),
-                                              hp.data_ptr(), y.data_ptr(), B, T, H, s, Z, dc, L.stream_ptr()),
-                        "vmr_lstm_step_fwd")
-        else:
-            hs = torch.zeros(Z, B, H, device=dev, dtype=dt)
-            gh = torch.zeros(Z, B, 4 * H, device=dev)
-            f32out = L.EPI_OUT_F32 if dc != L.F32 else 0
-            for s in range(T):
-                if s > 0:                                                 # gh[z] = hs[z] . w_hh[z]^T, every direction
-                    ops.gemm(hs, w_hh, gh, B, 4 * H, H, 0, 0, H, H, 4 * H, dtype=dc, flags=f32out, Z1=Z,
-                             sA=(B * H, 0), sB=(4 * H * H, 0), sC=(B * 4 * H, 0))
-                L.check(lib.vmr_lstm_cell_fwd(gx.data_ptr(), gh.data_ptr(), lens.data_ptr(), c.data_ptr(), hs.data_ptr(),
-                                              act.data_ptr(), cs.data_ptr(), hp.data_ptr(), y.data_ptr(), B, T, H, s, Z, dc,
-                                              L.stream_ptr()), "vmr_lstm_cell_fwd")
+        ctx.mode = _recur_fwd(gx, w_hh, lens, act, cs, hp, y, B, T, H, Z, dt, dc)
         ctx.save_for_backward(xs, lens, w_ih, w_hh, act, cs, hp)
         ctx.mark_non_differentiable(lens)
         return y
@@ -125,45 +165,14 @@ class _BiLSTM(torch.autograd.Function):
         K, H = Z // 2, w_hh.shape[2]
         dt, dc = xs.dtype, L.dtype_code(xs)
         lib, dev = L.lib(), xs.device
-        dy = dy.contiguous()
-        dg = torch.empty(Z, B, T, 4 * H, device=dev, dtype=dt)
-        dcell = torch.zeros(Z, B, H, device=dev)
-        if ctx.seq:
-            whht = w_hh.transpose(1, 2).contiguous()                      # [Z, H, 4H]: the K-contiguous operand of dg . W_hh
-            sync = torch.zeros(16, device=dev, dtype=torch.int32)
-            L.check(lib.vmr_lstm_seq_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), whht.data_ptr(),
-                                         dg.data_ptr(), sync.data_ptr(), B, T, H, Z, dc, L.stream_ptr()), "vmr_lstm_seq_bwd")
-            _note_sync(sync)
-        elif ctx.fused:
-            whht = w_hh.transpose(1, 2).contiguous()                      # [Z, H, 4H]: the K-contiguous operand of dg . W_hh
-            for s in range(T - 1, -1, -1):
-                L.check(lib.vmr_lstm_step_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), whht.data_ptr(),
-                                              dcell.data_ptr(), dg.data_ptr(), B, T, H, s, Z, dc, L.stream_ptr()),
-                        "vmr_lstm_step_bwd")
-        else:
-            dh = torch.zeros(Z, B, H, device=dev)
-            f32out = L.EPI_OUT_F32 if dc != L.F32 else 0
-            for s in range(T - 1, -1, -1):
-                L.check(lib.vmr_lstm_cell_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), dh.data_ptr(),
-                                              dcell.data_ptr(), dg.data_ptr(), B, T, H, s, Z, dc, L.stream_ptr()),
-                        "vmr_lstm_cell_bwd")
-                if s > 0:  # dh[z] = dg[z][:, s, :] . w_hh[z]   (A rows strided by T*4H; W_hh is the [K][N] operand)
-                    ops.gemm(dg[:, :, s], w_hh, dh, B, H, 4 * H, 0, 1, T * 4 * H, H, H, dtype=dc, flags=f32out, Z1=Z,
-                             sA=(B * T * 4 * H, 0), sB=(4 * H * H, 0), sC=(B * H, 0))
+        dg = _recur_bwd(dy.contiguous(), act, cs, lens, w_hh, ctx.mode, B, T, H, Z, dt, dc)
         dg2 = dg.view(Z, B * T, 4 * H)
         dw_hh = torch.empty(Z, 4 * H, H, device=dev)
         dw_ih = torch.empty(Z, 4 * H, I, device=dev)
         dxs = torch.empty(Z, B, T, I, device=dev, dtype=dt)
-        def wgrad(a2, b2, out):      # out [4H, N] = a2^T . b2 over K = B*T: few output tiles, long K -> split-K slabs + one
-            r = ops.mm_few_tiles(a2, b2, 1, 1)     # reduce launch (bf16); the plain product otherwise (fp32, or many tiles)
-            if r is None:
-                ops.mm(a2, b2, 1, 1, out=out, out_f32=True)
-            else:
-                out.copy_(r)
-
         for z in range(Z):   # one product per weight over all steps (K = B*T); dx of each direction's step sequence
-            wgrad(dg2[z], hp[z].view(B * T, H), dw_hh[z])
-            wgrad(dg2[z], xs[z].view(B * T, I), dw_ih[z])
+            _wgrad(dg2[z], hp[z].view(B * T, H), dw_hh[z])
+            _wgrad(dg2[z], xs[z].view(B * T, I), dw_ih[z])
             ops.mm(dg2[z], w_ih[z], 0, 1, out=dxs[z].view(B * T, I))
         # bias gradient = column sums of dg over all (sample, step) rows: one column-sum launch per direction on the 16-bit
         # dg itself (as `dg2.float().sum(1)` it was an fp32 copy of dg + a reduction: 0.5 ms per BAN step)
@@ -187,6 +196,145 @@ def bilstm_multi(x, lens, w_ih, w_hh, bias):
     return _BiLSTM.apply(x.contiguous(), lens.clamp(min=0, max=x.shape[2]), w_ih, w_hh, bias)
 
 
+PARAM_DIRECT = os.environ.get("VMR_LSTM_PARAM_DIRECT", "1") != "0"   # A/B: the layer reads master parameters / arena mirrors itself
+
+
+def _w16(p: torch.Tensor, dt: torch.dtype, kpad: int = 0) -> torch.Tensor:
+    """A parameter matrix in the compute dtype without a torch op where possible: the 16-bit mirror the AdamW kernel keeps
+    in the flat arena (optim.FlatArena), the fp32 master itself for the fp32 path, one vmr_cast launch otherwise (also
+    when the K columns need zero padding to 16-byte rows)."""
+    K = p.shape[1]
+    Kp = max(K, kpad)
+    m = getattr(p, "_vmr_w16", None)
+    if m is not None and m.dtype == dt and Kp == K:
+        if p._version != getattr(p, "_vmr_synced_version", p._version):
+            p._vmr_arena.sync_mirrors()          # edited in place behind the optimizer's back (load_state_dict)
+        return m
+    if dt == torch.float32 and Kp == K:
+        return p.detach()
+    out = torch.empty(p.shape[0], Kp, device=p.device, dtype=dt)
+    src = p.detach()
+    L.check(L.lib().vmr_cast(src.data_ptr(), L.F32, out.data_ptr(), L.dtype_code(out), p.shape[0], K, K, Kp, 0.0, 0, None,
+                             L.stream_ptr()), "vmr_cast")
+    return out
+
+
+class _BiLSTMLayer(torch.autograd.Function):
+    """One bi-LSTM layer straight on its eight master parameters (nn.LSTM's weight_ih / weight_hh / bias_ih / bias_hh of
+    the forward and the reverse direction): y [B, T, 2H] from x [B, T, I] in the compute dtype.  Same kernels as _BiLSTM;
+    what differs is the glue around them -- no stacked / cast weight copies per step (arena mirrors), both bias vectors
+    added by the product's epilogue, and in the backward pass weight gradients reduced straight into the flat gradient
+    arena with the bias gradients as column sums riding on the same products (no autograd accumulation, no casts)."""
+
+    @staticmethod
+    def forward(ctx, x, lens, *params):
+        L.require_gpu(x, lens)
+        assert lens.dtype == torch.int32 and x.is_contiguous() and len(params) == 8
+        B, T, I = x.shape
+        H = params[1].shape[1]
+        Z = 2
+        dt, dc = x.dtype, L.dtype_code(x)
+        lib, dev = L.lib(), x.device
+        w_ih = [_w16(params[4 * z], dt, kpad=I) for z in range(Z)]          # (x may carry zero columns up to 16-byte rows)
+        w_hh = torch.stack([_w16(params[4 * z + 1], dt) for z in range(Z)])
+        xs = (x, _reverse_rows(x, lens))
+        gx = torch.empty(Z, B, T, 4 * H, device=dev, dtype=dt)
+        for z in range(Z):                                                # x-part of every step, b_ih + b_hh in the epilogue
+            ops.mm(xs[z].view(B * T, I), w_ih[z], 0, 0, out=gx[z].view(B * T, 4 * H), bias=params[4 * z + 2].detach(),
+                   bias2=params[4 * z + 3].detach(), flags=L.EPI_BIAS)
+        act = torch.empty(Z, B, T, 4 * H, device=dev, dtype=dt)
+        cs = torch.empty(Z, B, T, H, device=dev)
+        hp = torch.empty(Z, B, T, H, device=dev, dtype=dt)
+        y = torch.zeros(1, B, T, 2 * H, device=dev, dtype=dt)
+        ctx.mode = _recur_fwd(gx, w_hh, lens, act, cs, hp, y, B, T, H, Z, dt, dc)
+        ctx.save_for_backward(xs[0], xs[1], lens, w_hh, act, cs, hp, *w_ih)
+        ctx.params = params
+        ctx.mark_non_differentiable(lens)
+        return y[0]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, lens, w_hh, act, cs, hp, *w_ih = ctx.saved_tensors
+        params = ctx.params
+        xs = (x0, x1)
+        B, T, I = x0.shape
+        Z, H = 2, w_hh.shape[2]
+        dt, dc = x0.dtype, L.dtype_code(x0)
+        lib, dev = L.lib(), x0.device
+        dg = _recur_bwd(dy.contiguous().unsqueeze(0), act, cs, lens, w_hh, ctx.mode, B, T, H, Z, dt, dc)
+        dg2 = dg.view(Z, B * T, 4 * H)
+        dxs = torch.empty(Z, B, T, I, device=dev, dtype=dt)
+        grads = [None] * 8
+        for z in range(Z):
+            pih, phh, bih, bhh = params[4 * z:4 * z + 4]
+            slots = [ops.main_grad(q) for q in (pih, phh, bih, bhh)]
+            direct = all(s_ is not None for s_ in slots) and L.is_16bit(dt)
+            if direct:        # split-K slabs, ONE reduction each straight into the arena; bias gradients ride on the products
+                _wgrad_into(dg2[z], hp[z].view(B * T, H), slots[1], H, slots[3])
+                _wgrad_into(dg2[z], xs[z].view(B * T, I), slots[0], pih.shape[1], slots[2])
+            else:
+                dwh = torch.empty(4 * H, H, device=dev)
+                dwi = torch.empty(4 * H, I, device=dev)
+                _wgrad(dg2[z], hp[z].view(B * T, H), dwh)
+                _wgrad(dg2[z], xs[z].view(B * T, I), dwi)
+                db = torch.zeros(4 * H, device=dev)
+                L.check(lib.vmr_relu_bwd_bias(0, dg2[z].data_ptr(), None, None, db.data_ptr(), B * T, 4 * H, 4 * H, 1.0, dc, 0.0, 0,
+                                              None, None, 1.0, L.stream_ptr()), "vmr_relu_bwd_bias")
+                grads[4 * z:4 * z + 4] = [dwi[:, :pih.shape[1]], dwh, db, db]
+            ops.mm(dg2[z], w_ih[z], 0, 1, out=dxs[z].view(B * T, I))
+        dx = dxs[0] + _reverse_rows(dxs[1], lens)                          # (the reversal is its own inverse; zero past len)
+        return (dx, None, *grads)
+
+
+def _wgrad(a2, b2, out):
+    """out [4H, N] fp32 = a2^T . b2 over K = B*T: few output tiles, long K -> split-K slabs + one reduce launch (16-bit);
+    the plain product otherwise (fp32, or many tiles)."""
+    r = ops.mm_few_tiles(a2, b2, 1, 1)
+    if r is None:
+        ops.mm(a2, b2, 1, 1, out=out, out_f32=True)
+    else:
+        out.copy_(r)
+
+
+def _wgrad_into(a2, b2, slot, kcols, bslot):
+    """slot [4H, kcols] (fp32, gradient arena) += a2^T . b2, bslot [4H] += column sums of a2: K = B*T split into fp32
+    slabs over the idle CUs + one vmr_splitk_reduce straight into the arena (b2 may carry zero-padded columns: only the
+    first kcols of every slab row are reduced); short K: one accumulating product."""
+    K, M = a2.shape
+    N = b2.shape[1]
+    dc = L.dtype_code(a2)
+    if K >= 512 and N % 4 == 0:
+        tiles = ops._cdiv(M, 128) * ops._cdiv(N, 128)
+        sk = 2 if tiles >= 128 else max(2, min(8, K // 256 if tiles >= 32 else K // 128, ops._cdiv(320, tiles)))
+        ws = torch.empty(sk, M, N, device=a2.device, dtype=torch.float32)
+        ops.gemm(a2, b2, ws, M, N, K, 1, 1, a2.stride(0), b2.stride(0), N, dtype=dc, flags=L.EPI_SLAB, splitk=sk, a_colsum=bslot)
+        padded = kcols != N
+        L.check(L.lib().vmr_splitk_reduce(ws.data_ptr(), slot.data_ptr(), sk, M * N, N if padded else 0, kcols if padded else 0,
+                                          L.stream_ptr()), "vmr_splitk_reduce")
+    elif kcols == N:
+        ops.gemm(a2, b2, slot, M, N, K, 1, 1, a2.stride(0), b2.stride(0), N, dtype=dc, flags=L.EPI_ACCUM, a_colsum=bslot)
+    else:
+        slot.view(M, kcols).add_(ops.mm(a2, b2, 1, 1, out_f32=True, a_colsum=bslot)[:, :kcols])
+
+
+def lstm_layer(m: nn.LSTM, l: int, h: torch.Tensor, lens: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    """Layer l of the bidirectional nn.LSTM parameter holder m on h [B, T, I] (compute dtype): [B, T, 2H]."""
+    names = [f"{k}_l{l}{sfx}" for sfx in ("", "_reverse") for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    params = [getattr(m, n) for n in names]
+    pad = (-h.shape[2]) % 8                   # 16-byte rows: zero columns on both sides of the first product
+    if PARAM_DIRECT:
+        if pad:
+            h = torch.nn.functional.pad(h, (0, pad))
+        return _BiLSTMLayer.apply(h.contiguous(), lens.clamp(min=0, max=h.shape[1]), *params)
+    w_ih = torch.stack((params[0], params[4]))
+    w_hh = torch.stack((params[1], params[5]))
+    bias = torch.stack((params[2] + params[3], params[6] + params[7]))
+    if pad:
+        h = torch.nn.functional.pad(h, (0, pad))
+        w_ih = torch.nn.functional.pad(w_ih, (0, pad))
+    return bilstm(h.contiguous(), lens, w_ih.to(dt).contiguous(), w_hh.to(dt).contiguous(), bias.to(dt).contiguous())
+
+
 class _EncoderBase(nn.Module):
     """Parameter holder with nn.LSTM's key names under `biLSTM.` + the HIP forward (stacked layers: layer l + 1 reads layer
     l's [B, T, 2H] output with the same lengths -- what nn.LSTM does on a packed sequence; inter-layer dropout is 0.0 in
@@ -203,15 +351,7 @@ class _EncoderBase(nn.Module):
         m, dt = self.biLSTM, self.compute_dtype
         h = x.to(dt)
         for l in range(self.num_layers):
-            w_ih = torch.stack((getattr(m, f"weight_ih_l{l}"), getattr(m, f"weight_ih_l{l}_reverse")))
-            w_hh = torch.stack((getattr(m, f"weight_hh_l{l}"), getattr(m, f"weight_hh_l{l}_reverse")))
-            bias = torch.stack((getattr(m, f"bias_ih_l{l}") + getattr(m, f"bias_hh_l{l}"),
-                                getattr(m, f"bias_ih_l{l}_reverse") + getattr(m, f"bias_hh_l{l}_reverse")))
-            pad = (-h.shape[2]) % 8           # 16-byte rows: zero columns on both sides of the first product
-            if pad:
-                h = torch.nn.functional.pad(h, (0, pad))
-                w_ih = torch.nn.functional.pad(w_ih, (0, pad))
-            h = bilstm(h.contiguous(), lens, w_ih.to(dt).contiguous(), w_hh.to(dt).contiguous(), bias.to(dt).contiguous())
+            h = lstm_layer(m, l, h, lens, dt)
         vec = h.float().sum(1) / lens.clamp(min=1).unsqueeze(1).float()     # mean over the valid steps (zero past len)
         return vec.to(h.dtype), h
 

@@ -31,7 +31,7 @@ import torch.nn as nn
 
 from . import ops
 from .SeqPAN import cq_attention_core
-from .ban_encoders import QueryEncoder, VisualEncoder, bilstm, bilstm_multi
+from .ban_encoders import QueryEncoder, VisualEncoder, bilstm_multi, lstm_layer
 
 
 PAIRED = os.environ.get("VMR_LSTM_PAIR", "0") == "1"     # A/B: TemporalDifference's two LSTMs in the same launches
@@ -81,11 +81,7 @@ class TemporalDifference(nn.Module):
             for m in (mods if need_c else mods[:1]):
                 h = x
                 for l in range(self.layer_num):
-                    w_ih = torch.stack((getattr(m, f"weight_ih_l{l}"), getattr(m, f"weight_ih_l{l}_reverse")))
-                    w_hh = torch.stack((getattr(m, f"weight_hh_l{l}"), getattr(m, f"weight_hh_l{l}_reverse")))
-                    bias = torch.stack((getattr(m, f"bias_ih_l{l}") + getattr(m, f"bias_hh_l{l}"),
-                                        getattr(m, f"bias_ih_l{l}_reverse") + getattr(m, f"bias_hh_l{l}_reverse")))
-                    h = bilstm(h.contiguous(), lens, w_ih.to(dt).contiguous(), w_hh.to(dt).contiguous(), bias.to(dt).contiguous())
+                    h = lstm_layer(m, l, h, lens, dt)
                 outs.append(h)
             return outs[0], (outs[1] if need_c else None)
         h = torch.stack((x, x))                                            # [2, B, T, I]
