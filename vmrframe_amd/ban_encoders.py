@@ -318,14 +318,15 @@ def _wgrad_into(a2, b2, slot, kcols, bslot):
 
 
 def lstm_layer(m: nn.LSTM, l: int, h: torch.Tensor, lens: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
-    """Layer l of the bidirectional nn.LSTM parameter holder m on h [B, T, I] (compute dtype): [B, T, 2H]."""
+    """Layer l of the bidirectional nn.LSTM parameter holder m on h [B, T, I] (compute dtype): [B, T, 2H].  lens int32 [B]
+    must lie in [0, T] (the kernels index time by it): the callers clamp once per stack, not per layer."""
     names = [f"{k}_l{l}{sfx}" for sfx in ("", "_reverse") for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
     params = [getattr(m, n) for n in names]
     pad = (-h.shape[2]) % 8                   # 16-byte rows: zero columns on both sides of the first product
     if PARAM_DIRECT:
         if pad:
             h = torch.nn.functional.pad(h, (0, pad))
-        return _BiLSTMLayer.apply(h.contiguous(), lens.clamp(min=0, max=h.shape[1]), *params)
+        return _BiLSTMLayer.apply(h.contiguous(), lens, *params)
     w_ih = torch.stack((params[0], params[4]))
     w_hh = torch.stack((params[1], params[5]))
     bias = torch.stack((params[2] + params[3], params[6] + params[7]))
@@ -350,6 +351,7 @@ class _EncoderBase(nn.Module):
         """x [B, T, I] (any float dtype), lens int32 [B] on x's device -> (mean over valid steps [B, 2H], output [B, T, 2H])"""
         m, dt = self.biLSTM, self.compute_dtype
         h = x.to(dt)
+        lens = lens.clamp(min=0, max=x.shape[1])
         for l in range(self.num_layers):
             h = lstm_layer(m, l, h, lens, dt)
         vec = h.float().sum(1) / lens.clamp(min=1).unsqueeze(1).float()     # mean over the valid steps (zero past len)
@@ -368,7 +370,7 @@ class VisualEncoder(_EncoderBase):
         x = visual_data
         if x.shape[1] != max_seq_len:                                      # (pad_packed_sequence(total_length=...))
             x = x[:, :max_seq_len] if x.shape[1] > max_seq_len else torch.nn.functional.pad(x, (0, 0, 0, max_seq_len - x.shape[1]))
-        lens = visual_length.to(device=x.device, dtype=torch.int32).clamp(max=x.shape[1]).contiguous()
+        lens = visual_length.to(device=x.device, dtype=torch.int32).contiguous()
         return self._layers(x, lens)
 
 

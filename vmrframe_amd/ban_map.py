@@ -99,7 +99,9 @@ class ProposalMap2D(nn.Module):
                            residual=R.view(B * C, F), res_pre=True)
         # tmap = predictor(map2d)   (BAN.py:95)
         p = self.predictor.pred
-        h = ops.linear(map2d, p[0].weight, p[0].bias, c, relu=True, drop=dc.next("predictor"))
+        # (tee: map2d's other consumer is the gather at the sampled proposals (ban.forward_head); its gradient joins this
+        #  product's dX in the epilogue instead of a [B*C, F] add pass)
+        h, map2d = ops.linear(map2d, p[0].weight, p[0].bias, c, relu=True, drop=dc.next("predictor"), tee=True)
         tmap_cells = ops.narrow_linear(h, p[3].weight, p[3].bias, N=1).view(B, C)
         out = {"map2d_mask": lay.mask2d, "tmap_cells": tmap_cells, "map2d_cells": map2d.view(B, C, F),
                "map2d_proj_cells": proj_cells, "cells_i": lay.ii_t, "cells_j": lay.jj_t}
