@@ -410,38 +410,45 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
 // 256 CUs at H = 512), spread over the XCDs (the protocol does not care where they run).  512 threads: wave w takes the
 // k-steps w, w + 8, ... of K = 4H (4-8 sixteen-byte operand loads per lane), the eight partial 16 x 16 tiles are summed
 // through LDS; threads 0..63 then own (batch row, 4 units) cells; dc stays in registers over all steps.
-template <typename E, int HH>
+// Tile (UW units x RB batch rows) per workgroup.  What a step moves over the fabric in total is
+// (H / UW) slices x B rows x 4H x 2 B per direction -- every slice re-reads every row -- so wider slices are fewer bytes:
+// (16, 16) = 16.8 MB per step at H = 512 and B = 64, (32, 8) = 8.4 MB with the same 256 workgroups (the MFMA tile is then
+// half empty in M: rows >= RB load nothing) and 32 rows of W_hh^T (132 KB at H = 512) in LDS.
+template <typename E, int HH, int UW, int RB>
 __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(SeqArgs a) {
-  constexpr int H = HH, KT = 4 * HH / 32, KW = KT / 8, WPX = (HH / 16) * 4, LDW = 4 * HH + 8, LDP = 17;
+  constexpr int H = HH, KT = 4 * HH / 32, KW = KT / 8, NT = UW / 16, GPB = 64 / RB, WPX = (HH / UW) * GPB;
+  constexpr int LDW = 4 * HH + 8, LDP = UW + 1, QW = UW / 4;
+  static_assert(UW % 16 == 0 && (RB == 8 || RB == 16) && RB * QW <= 512, "tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  E* wT = reinterpret_cast<E*>(smem);                          // [16][LDW]: row n = W_hh^T row of unit u0 + n (K = 4H)
-  float* part = reinterpret_cast<float*>(wT + 16 * LDW);       // [8 waves][16][LDP]
+  E* wT = reinterpret_cast<E*>(smem);                          // [UW][LDW]: row n = W_hh^T row of unit u0 + n (K = 4H)
+  float* part = reinterpret_cast<float*>(wT + UW * LDW);       // [8 waves][RB][LDP]: the tile's real batch rows only
   __shared__ int dead;
   // affinity (speed only): blocks with equal blockIdx % 8 share an XCD; direction z takes `xpd` of the 8 groups
   const int grp = blockIdx.x & 7, kk = blockIdx.x >> 3;
   const int z = grp % a.ndir, role = grp / a.ndir + a.xpd * kk;
   if (grp / a.ndir >= a.xpd || role >= WPX) return;
-  const int slot = role >> 2, bq = role & 3;
+  const int slot = role / GPB, bq = role % GPB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kq = lane >> 4;
-  const int B = a.B, Tn = a.T, u0 = slot * 16, b0 = bq * 16;
+  const int B = a.B, Tn = a.T, u0 = slot * UW, b0 = bq * RB;
   const E* whht = reinterpret_cast<const E*>(a.whh);           // [Z][H][4H]
   const E* act = reinterpret_cast<const E*>(a.act);
   const E* dy = reinterpret_cast<const E*>(a.dy);
   E* dg = reinterpret_cast<E*>(a.dg);
-  for (int i = tid; i < 16 * (4 * H / 8); i += 512) {
+  for (int i = tid; i < UW * (4 * H / 8); i += 512) {
     const int row = i / (4 * H / 8), ch = i - row * (4 * H / 8);
     *reinterpret_cast<bf16x8*>(wT + row * LDW + ch * 8) =
         *reinterpret_cast<const bf16x8*>(whht + ((int64_t)z * H + u0 + row) * 4 * H + ch * 8);
   }
   if (tid == 0) dead = 0;
   __syncthreads();
-  const bool cell = tid < 64;
-  const int m = (tid & 63) >> 2, q = tid & 3, j0 = u0 + 4 * q;      // cell: batch row b0 + m, units j0 .. j0 + 3
+  const bool cell = tid < RB * QW;
+  const int m = min(tid / QW, RB - 1), q = tid % QW, j0 = u0 + 4 * q;      // cell: batch row b0 + m, units j0 .. j0 + 3
   const bool real = cell && b0 + m < B;
   const int bc = min(b0 + m, B - 1);
   const int64_t zb = (int64_t)z * B + bc;
   const int L = a.len[bc];
-  const int arow = min(b0 + r16, B - 1);                       // this lane's MFMA operand row (batch)
+  const bool arow_on = r16 < RB;                               // MFMA operand rows past the tile's batch rows: zero
+  const int arow = min(b0 + min(r16, RB - 1), B - 1);          // this lane's MFMA operand row (batch)
   typedef __attribute__((ext_vector_type(4))) E E4;
   float dcv[4] = {0.f, 0.f, 0.f, 0.f};
   for (int s = Tn - 1; s >= 0; --s) {
@@ -458,22 +465,35 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(SeqArgs a) {
       const int t = min(max((z & 1) == 0 ? s : L - 1 - s, 0), Tn - 1);
       dyv = *reinterpret_cast<const E4*>(dy + (((int64_t)(z >> 1) * B + bc) * Tn + t) * 2 * H + (z & 1) * H + j0);
     }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s + 1 < Tn) {        // dh = dg_{s+1} . W_hh (nothing flows into the last step)
       seq_wait(a.sync + z, (Tn - 1 - s) * WPX, a.sync + 8, &dead);
       const E* src = dg + (((int64_t)z * B + arow) * Tn + s + 1) * 4 * H + kq * 8;
       bf16x8 af[KW];
 #pragma unroll
-      for (int k = 0; k < KW; ++k) af[k] = ld16_sc1(src + (w + 8 * k) * 32);
+      for (int k = 0; k < KW; ++k) af[k] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (arow_on) {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) af[k] = ld16_sc1(src + (w + 8 * k) * 32);
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int k = 0; k < KW; ++k) asm volatile("" : "+v"(af[k]));
-      const E* wr = wT + r16 * LDW + kq * 8;
 #pragma unroll
-      for (int k = 0; k < KW; ++k) acc = mfma16<E>(af[k], *reinterpret_cast<const bf16x8*>(wr + (w + 8 * k) * 32), acc);
+      for (int nt = 0; nt < NT; ++nt) {
+        const E* wr = wT + (nt * 16 + r16) * LDW + kq * 8;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) acc[nt] = mfma16<E>(af[k], *reinterpret_cast<const bf16x8*>(wr + (w + 8 * k) * 32), acc[nt]);
+      }
     }
+    if (kq * 4 < RB) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part[(w * 16 + kq * 4 + r) * LDP + r16] = acc[r];      // D[batch kq*4 + r][unit r16]
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(w * RB + kq * 4 + r) * LDP + nt * 16 + r16] = acc[nt][r];    // D[batch kq*4 + r][unit]
+    }
     __syncthreads();
     if (cell) {
       E4 dgv[4];
@@ -486,7 +506,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(SeqArgs a) {
           const int n = 4 * q + e;
           float dht = (float)dyv[e];
 #pragma unroll
-          for (int ww = 0; ww < 8; ++ww) dht += part[(ww * 16 + m) * LDP + n];
+          for (int ww = 0; ww < 8; ++ww) dht += part[(ww * RB + m) * LDP + n];
           const float ig = (float)av[0][e], fg = (float)av[1][e], gg = (float)av[2][e], og = (float)av[3][e];
           const float cp = s > 0 ? cp4[e] : 0.f;
           const float th = tanh_f(cn4[e]);
@@ -652,25 +672,37 @@ extern "C" int vmr_lstm_seq_bwd(const void* dy, const void* act, const void* cs,
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.act = const_cast<void*>(act); a.cs = (float*)const_cast<void*>(cs); a.len = len; a.whh = whht; a.dg = dg; a.sync = sync;
   a.B = B; a.T = T; a.ndir = ndir;
-  const size_t lds = (size_t)16 * (4 * H + 8) * 2 + (size_t)8 * 16 * 17 * 4;
-  // roles per direction = (16-unit slice, 16-row batch quarter); a direction's workgroups are spread over its share of
+  // tile per workgroup (see the kernel): the BAN step at B = 64, T = 128 ran 16.57 ms with (16, 16), 15.83 with (32, 8),
+  // 15.59 with (64, 8) for the H = 256 layers; VMR_LSTM_SEQ_BWD_TILE = 0 / 1 / 2 for A/B
+  static int tile_env = -1;
+  if (tile_env < 0) { const char* e = getenv("VMR_LSTM_SEQ_BWD_TILE"); tile_env = e ? atoi(e) : 2; }
+  // 0: (16, 16); 1: (32, 8); 2: (64, 8) at H = 256 (its 64 rows of W_hh^T are 132 KB; at H = 512 they do not fit), (32, 8) otherwise
+  const int UW = tile_env == 0 ? 16 : (tile_env == 2 && H == 256 ? 64 : 32), RB = tile_env == 0 ? 16 : 8;
+  const size_t lds = (size_t)UW * (4 * H + 8) * 2 + (size_t)8 * RB * (UW + 1) * 4;
+  // roles per direction = (UW-unit slice, RB-row batch group); a direction's workgroups are spread over its share of
   // the eight XCD groups
-  const int roles = (H / 16) * 4;
+  const int roles = (H / UW) * (64 / RB);
   static int xpd_env = -1;
   if (xpd_env < 0) { const char* e = getenv("VMR_LSTM_SEQ_XPD"); xpd_env = e ? atoi(e) : 0; }
   a.xpd = xpd_env > 0 ? xpd_env : 8 / ndir;      // (measured at H = 256: all 64 workgroups on one XCD 652 us per layer, spread over four 415)
   if (a.xpd * ndir > 8) a.xpd = 8 / ndir;
   const dim3 grid(8 * ((roles + a.xpd - 1) / a.xpd));
-#define VMR_LSTM_SEQ_BWD(HH)                                                                                           \
+#define VMR_LSTM_SEQ_BWD(HH, UW_, RB_)                                                                                 \
   VMR_DISPATCH16(dtype, E, do {                                                                                        \
-    const void* fn = (const void*)lstm_seq_bwd_kernel<E, HH>;                                                          \
+    const void* fn = (const void*)lstm_seq_bwd_kernel<E, HH, UW_, RB_>;                                               \
     if (lds > 64 * 1024) {                                                                                             \
       hipError_t e_ = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
       if (e_ != hipSuccess) return vmr_fail(-5, "vmr_lstm_seq_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e_));   \
     }                                                                                                                  \
-    hipLaunchKernelGGL((lstm_seq_bwd_kernel<E, HH>), grid, dim3(512), lds, (hipStream_t)stream, a);                    \
+    hipLaunchKernelGGL((lstm_seq_bwd_kernel<E, HH, UW_, RB_>), grid, dim3(512), lds, (hipStream_t)stream, a);          \
   } while (0))
-  if (H == 256) VMR_LSTM_SEQ_BWD(256); else VMR_LSTM_SEQ_BWD(512);
+  if (UW == 64) {
+    VMR_LSTM_SEQ_BWD(256, 64, 8);
+  } else if (UW == 32) {
+    if (H == 256) VMR_LSTM_SEQ_BWD(256, 32, 8); else VMR_LSTM_SEQ_BWD(512, 32, 8);
+  } else {
+    if (H == 256) VMR_LSTM_SEQ_BWD(256, 16, 16); else VMR_LSTM_SEQ_BWD(512, 16, 16);
+  }
 #undef VMR_LSTM_SEQ_BWD
   VMR_LAUNCH_CHECK();
   return 0;
