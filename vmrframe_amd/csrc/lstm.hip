@@ -447,8 +447,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(SeqArgs a) {
   const int bc = min(b0 + m, B - 1);
   const int64_t zb = (int64_t)z * B + bc;
   const int L = a.len[bc];
-  const bool arow_on = r16 < RB;                               // MFMA operand rows past the tile's batch rows: zero
-  const int arow = min(b0 + min(r16, RB - 1), B - 1);          // this lane's MFMA operand row (batch)
+  const int arow = min(b0 + (r16 & (RB - 1)), B - 1);          // this lane's MFMA operand row (batch)
   typedef __attribute__((ext_vector_type(4))) E E4;
   float dcv[4] = {0.f, 0.f, 0.f, 0.f};
   for (int s = Tn - 1; s >= 0; --s) {
@@ -471,21 +470,45 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(SeqArgs a) {
     if (s + 1 < Tn) {        // dh = dg_{s+1} . W_hh (nothing flows into the last step)
       seq_wait(a.sync + z, (Tn - 1 - s) * WPX, a.sync + 8, &dead);
       const E* src = dg + (((int64_t)z * B + arow) * Tn + s + 1) * 4 * H + kq * 8;
-      bf16x8 af[KW];
+      if constexpr (RB == 8) {
+        // Only 8 of the MFMA tile's 16 operand rows are real: lanes r16 >= 8 fetch the NEXT k-step of row r16 - 8, so one
+        // load instruction covers two adjacent k-steps = 128 contiguous bytes of every row (64 with the idle half), and
+        // half as many load instructions.  Wave w takes the k-step pairs (2w, 2w + 1) + 16j.  The even product uses the
+        // fragment as loaded, the odd one after a rotation by 8 lanes within each 16-lane row (DPP row_ror:8); the
+        // other half of the tile then holds the wrong k-step's rows -- they only reach D rows 8..15, which nobody reads.
+        constexpr int KP = KW / 2;
+        bf16x8 af[KP];
 #pragma unroll
-      for (int k = 0; k < KW; ++k) af[k] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      if (arow_on) {
+        for (int j = 0; j < KP; ++j) af[j] = ld16_sc1(src + (2 * w + (r16 >> 3) + 16 * j) * 32);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < KP; ++j) asm volatile("" : "+v"(af[j]));
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+          u32x4 raw = __builtin_bit_cast(u32x4, af[j]), rot;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rot[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw[i], 0x128, 0xF, 0xF, false);
+          const bf16x8 ao = __builtin_bit_cast(bf16x8, rot);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const E* wr = wT + (nt * 16 + r16) * LDW + kq * 8 + (2 * w + 16 * j) * 32;
+            acc[nt] = mfma16<E>(af[j], *reinterpret_cast<const bf16x8*>(wr), acc[nt]);
+            acc[nt] = mfma16<E>(ao, *reinterpret_cast<const bf16x8*>(wr + 32), acc[nt]);
+          }
+        }
+      } else {
+        bf16x8 af[KW];
 #pragma unroll
         for (int k = 0; k < KW; ++k) af[k] = ld16_sc1(src + (w + 8 * k) * 32);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int k = 0; k < KW; ++k) asm volatile("" : "+v"(af[k]));
+        for (int k = 0; k < KW; ++k) asm volatile("" : "+v"(af[k]));
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const E* wr = wT + (nt * 16 + r16) * LDW + kq * 8;
+        for (int nt = 0; nt < NT; ++nt) {
+          const E* wr = wT + (nt * 16 + r16) * LDW + kq * 8;
 #pragma unroll
-        for (int k = 0; k < KW; ++k) acc[nt] = mfma16<E>(af[k], *reinterpret_cast<const bf16x8*>(wr + (w + 8 * k) * 32), acc[nt]);
+          for (int k = 0; k < KW; ++k) acc[nt] = mfma16<E>(af[k], *reinterpret_cast<const bf16x8*>(wr + (w + 8 * k) * 32), acc[nt]);
+        }
       }
     }
     if (kq * 4 < RB) {
@@ -685,6 +708,9 @@ extern "C" int vmr_lstm_seq_bwd(const void* dy, const void* act, const void* cs,
   static int xpd_env = -1;
   if (xpd_env < 0) { const char* e = getenv("VMR_LSTM_SEQ_XPD"); xpd_env = e ? atoi(e) : 0; }
   a.xpd = xpd_env > 0 ? xpd_env : 8 / ndir;      // (measured at H = 256: all 64 workgroups on one XCD 652 us per layer, spread over four 415)
+  // every workgroup must be RESIDENT (one per CU with these LDS tiles, 32 CUs per XCD): a narrower spread than this leaves
+  // workgroups undispatched behind pollers -- every step then runs into the poll bound (measured: 1.4 s per BAN step)
+  if (a.xpd < (roles + 31) / 32) a.xpd = (roles + 31) / 32;
   if (a.xpd * ndir > 8) a.xpd = 8 / ndir;
   const dim3 grid(8 * ((roles + a.xpd - 1) / a.xpd));
 #define VMR_LSTM_SEQ_BWD(HH, UW_, RB_)                                                                                 \
