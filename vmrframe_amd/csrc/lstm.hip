@@ -381,6 +381,11 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
         av[0][e] = (E)ig; av[1][e] = (E)fg; av[2][e] = (E)gg; av[3][e] = (E)og;
       }
     }
+    // the exchange first: publish h_s and arrive, THEN the records nobody waits for (seq_arrive's vmcnt(0) would
+    // otherwise sit out the acknowledgements of seven plain stores every step); they and the next step's gx loads
+    // drain under the next poll
+    st8_sc1(hz + (int64_t)s * (H * 64) + (slot * 64 + m) * 16 + 4 * q, __builtin_bit_cast(u32x2, hn));
+    if (s + 1 < Tn) seq_arrive(a.sync + z);
     if (real) {
       *reinterpret_cast<E4*>(hp + ca) = hprev;
 #pragma unroll
@@ -392,9 +397,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
       }
     }
     hprev = hn;
-    st8_sc1(hz + (int64_t)s * (H * 64) + (slot * 64 + m) * 16 + 4 * q, __builtin_bit_cast(u32x2, hn));
     if (s + 1 < Tn) {
-      seq_arrive(a.sync + z);
 #pragma unroll
       for (int g = 0; g < 4; ++g) gxv[g] = *reinterpret_cast<const E4*>(gx + (zb * Tn + s + 1) * 4 * H + g * H + j0);
     }
