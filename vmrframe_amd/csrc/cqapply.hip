@@ -493,6 +493,185 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
 }
 
 // =====================================================================================================================
+// backward, context = SHORT stream, on MFMA (Lq <= 128, Lc <= 32).  The register kernel above does its six small
+// contractions (K = Lc or K = Lq, N = 128 channels) as v_pk_fma on wave-uniform probabilities: 2.4 GFLOP of fp32 VALU work
+// per launch at two waves per SIMD = 120 us for 84 MB of traffic.  Here every operand is a 16-bit LDS image and every
+// contraction a handful of 16x16x32 MFMAs (the probabilities rounded to the element type, as the fused attention kernels
+// do with P):
+//   images   Qi [128][IMG_LD] (later dmid), midI [128][IMG_LD], dQ stage [128][IMG_LD], Ci / X1i / X2i [32][IMG_LD]
+//            (X1 = dc2q = g2 + g3*C, X2 = dq2c = g4*C), P1i / P2i [128][PLD] = S_ / S_t as [q][c]; rows / columns past
+//            the real lengths are ZERO in every image (no reliance on clamped rows);
+//   K = c    (mid = P2.C, dQ = P1.X1, dmid = P1.X2): A = a P image row (k contiguous), B = a [c][d] image read transposed;
+//   K = q    (c2q = P1^T.Q, q2c = P1^T.mid, dCm = P2^T.dmid): A = a P image read transposed, B = a [q][d] image read
+//            transposed; wave w owns channel tiles 2w, 2w + 1 of all three, so dC = g1 + g3*c2q + g4*q2c + dCm is formed
+//            in registers;
+//   then the shared mfma_phase (dS_ / dS_t partials) on the mid / dmid images.
+// =====================================================================================================================
+constexpr int PLD = 40;          // P image row: 32 columns + 8 (80 B: 16-byte aligned rows, 8-byte transposed reads)
+
+// 16 x 32 fragment (lane & 15 -> column `t * 16 + .` of the image, 8 consecutive image ROWS ks * 32 + 8 * (lane >> 4) ..) from a
+// row-major 16-bit image with `rb` bytes per row: two ds_read_b64_tr_b16 (common.h lds_read_tr: the caller waits and pins)
+__device__ __forceinline__ bf16x8 img_frag_tr(const bf16_t* img, int rb, int t, int ks, int lane) {
+  const int g = lane >> 4, ii = lane & 15, qq = ii >> 2, p = ii & 3;
+  const int r = ks * 32 + 8 * g + qq;
+  const unsigned char* base = reinterpret_cast<const unsigned char*>(img) + (t << 5) + p * 8;
+  union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+  u.s.l = lds_read_tr(base + r * rb);
+  u.s.h = lds_read_tr(base + (r + 4) * rb);
+  return u.v;
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void cq_apply_bwd_cshort_mfma(ApplyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int RB = IMG_LD * 2, RBP = PLD * 2;
+  bf16_t* Qi = reinterpret_cast<bf16_t*>(smem);          // [128][IMG_LD]; dmid after c2q is done
+  bf16_t* midI = Qi + 128 * IMG_LD;
+  bf16_t* dQs = midI + 128 * IMG_LD;
+  bf16_t* Ci = dQs + 128 * IMG_LD;                       // [32][IMG_LD]
+  bf16_t* X1i = Ci + 32 * IMG_LD;
+  bf16_t* X2i = X1i + 32 * IMG_LD;
+  bf16_t* P1i = X2i + 32 * IMG_LD;                       // [128][PLD]
+  bf16_t* P2i = P1i + 128 * PLD;
+  const int tid = threadIdx.x, lane = tid & 63, w = WAVE_ID();
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y, slice = blockIdx.x, D = a.D, Lc = a.Lc, Lq = a.Lq;
+  const bf16_t* Cb = a.C + (int64_t)b * Lc * D + slice * DS;
+  const bf16_t* Qb = a.Q + (int64_t)b * Lq * D + slice * DS;
+  const bf16_t* gb = a.g + (int64_t)b * Lc * 4 * D + slice * DS;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  // ---- stage every operand
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {                          // Q slice: 128 rows x 16 chunks of 16 B
+    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
+    bf16x8 v = zero8;
+    if (row < Lq) v = ldfrag(Qb + (int64_t)row * D + ch);
+    *reinterpret_cast<bf16x8*>(Qi + row * IMG_LD + ch) = v;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {                          // C, X1, X2: 32 rows x 16 chunks
+    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
+    bf16x8 c8 = zero8, x1 = zero8, x2 = zero8;
+    if (row < Lc) {
+      const bf16_t* gr = gb + (int64_t)row * 4 * D + ch;
+      c8 = ldfrag(Cb + (int64_t)row * D + ch);
+      const bf16x8 g2 = ldfrag(gr + D), g3 = ldfrag(gr + 2 * D), g4 = ldfrag(gr + 3 * D);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float cf = frag_get<E>(c8, e);
+        x1[e] = bits_from_f<E>(frag_get<E>(g2, e) + frag_get<E>(g3, e) * cf);
+        x2[e] = bits_from_f<E>(frag_get<E>(g4, e) * cf);
+      }
+    }
+    *reinterpret_cast<bf16x8*>(Ci + row * IMG_LD + ch) = c8;
+    *reinterpret_cast<bf16x8*>(X1i + row * IMG_LD + ch) = x1;
+    *reinterpret_cast<bf16x8*>(X2i + row * IMG_LD + ch) = x2;
+  }
+  {
+    const int SP = (Lc + 7) / 8 * 8;                     // the probability rows' length (cqscore.hip: columns >= Lc are exactly 0)
+    const float* A1 = a.A1 + (int64_t)b * Lq * SP;
+    const float* A2 = a.A2 + (int64_t)b * Lq * SP;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                        // P images: 128 rows x 4 groups of 8 columns
+      const int i = tid + 256 * j, row = i >> 2, cg = (i & 3) * 8;
+      bf16x8 p1 = zero8, p2 = zero8;
+      if (row < Lq && cg < SP) {
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(A1 + (int64_t)row * SP + cg), u1 = *reinterpret_cast<const f32x4*>(A1 + (int64_t)row * SP + cg + 4);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(A2 + (int64_t)row * SP + cg), v1 = *reinterpret_cast<const f32x4*>(A2 + (int64_t)row * SP + cg + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          p1[e] = bits_from_f<E>(u0[e]); p1[4 + e] = bits_from_f<E>(u1[e]);
+          p2[e] = bits_from_f<E>(v0[e]); p2[4 + e] = bits_from_f<E>(v1[e]);
+        }
+      }
+      *reinterpret_cast<bf16x8*>(P1i + row * PLD + cg) = p1;
+      *reinterpret_cast<bf16x8*>(P2i + row * PLD + cg) = p2;
+    }
+  }
+  __syncthreads();
+  // ---- K = c products: out[q][d] = sum_c P[q][c] X[c][d]; wave w: q tiles 2w, 2w + 1, all eight channel tiles
+  auto rows_x_short = [&](const bf16_t* Pi, const bf16_t* Xi, bf16_t* dst) {
+    bf16x8 fb[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) fb[nt] = img_frag_tr(Xi, RB, nt, 0, lane);
+    lgkm_wait<0>();
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) frag_pin(fb[nt]);
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+      const int mt = 2 * w + mm;
+      const bf16x8 fa = ldfrag(Pi + (mt * 16 + r16) * PLD + kq * 8);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const f32x4 acc = mfma16<E>(fa, fb[nt], (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(mt * 16 + kq * 4 + r) * IMG_LD + nt * 16 + r16] = bits_from_f<E>(acc[r]);
+      }
+    }
+  };
+  rows_x_short(P2i, Ci, midI);                           // mid = S_t^T-side rows . C
+  rows_x_short(P1i, X1i, dQs);                           // dQ = S_ . dc2q
+  __syncthreads();
+  // ---- K = q products: out[c][d] = sum_q P[q][c] Y[q][d]; wave w: channel tiles 2w, 2w + 1, both c tiles
+  auto short_x_rows = [&](const bf16_t* Pi, const bf16_t* Yi, f32x4 (&acc)[2][2]) {
+    bf16x8 fa[2][4], fb[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) fa[mt][ks] = img_frag_tr(Pi, RBP, mt, ks, lane);
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn) fb[nn][ks] = img_frag_tr(Yi, RB, 2 * w + nn, ks, lane);
+    }
+    lgkm_wait<0>();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { frag_pin(fa[i][ks]); frag_pin(fb[i][ks]); }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) acc[mt][nn] = mfma16<E>(fa[mt][ks], fb[nn][ks], acc[mt][nn]);
+  };
+  f32x4 c2q[2][2], q2c[2][2], dcm[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) c2q[i][j] = q2c[i][j] = dcm[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  short_x_rows(P1i, Qi, c2q);
+  short_x_rows(P1i, midI, q2c);
+  // the staged dQ rows leave with 16-byte stores
+  bf16_t* dQb = a.dQ + (int64_t)b * Lq * D + slice * DS;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
+    if (row < Lq) *reinterpret_cast<bf16x8*>(dQb + (int64_t)row * D + ch) = *reinterpret_cast<const bf16x8*>(dQs + row * IMG_LD + ch);
+  }
+  __syncthreads();                                       // every wave is done with Qi
+  bf16_t* dmidI = Qi;
+  rows_x_short(P1i, X2i, dmidI);                         // dmid = S_ . dq2c
+  __syncthreads();
+  short_x_rows(P2i, dmidI, dcm);                         // dC through mid: S_t . dmid
+  bf16_t* dCb = a.dC + (int64_t)b * Lc * D + slice * DS;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = mt * 16 + kq * 4 + r, d = (2 * w + nn) * 16 + r16;
+        if (c < Lc) {
+          const bf16_t* gr = gb + (int64_t)c * 4 * D + d;
+          const float g1 = bits_to_f<E>(gr[0]), g3 = bits_to_f<E>(gr[2 * D]), g4 = bits_to_f<E>(gr[3 * D]);
+          dCb[(int64_t)c * D + d] = bits_from_f<E>(g1 + g3 * c2q[mt][nn][r] + g4 * q2c[mt][nn][r] + dcm[mt][nn][r]);
+        }
+      }
+  mfma_phase<E>(a, b, slice, midI, dmidI, lane, w);
+}
+
+// =====================================================================================================================
 // both softmax backwards on the summed per-slice partials, everything long-major [Ll][SP] (l = long index, s = short):
 //   context long  (c = l, q = s): dS = S_ (dS_ - rowdot_l(dS_ S_)) + S_t (dS_t - coldot_s(dS_t S_t))
 //   context short (c = s, q = l): dS = S_ (dS_ - coldot_s(dS_ S_)) + S_t (dS_t - rowdot_l(dS_t S_t))
@@ -724,6 +903,22 @@ extern "C" int vmr_cq_apply_bwd(const void* dcat4, const void* ctx, const void* 
                    hipLaunchKernelGGL(fn, grid, dim3(256), lds, (hipStream_t)stream, a);)
   } else {
     const int SP = sp_of(Lc);
+    static int mfma_env = -1;
+    if (mfma_env < 0) { const char* e = getenv("VMR_CQ_MFMA"); mfma_env = e ? atoi(e) : 1; }      // A/B: 0 = the register kernel
+    if (mfma_env && Lq <= 128 && Lc <= 32) {
+      const size_t ldsm = (size_t)(3 * 128 + 3 * 32) * IMG_LD * 2 + (size_t)2 * 128 * PLD * 2;
+      if (dtype == VMR_F16) {
+        auto fn = cq_apply_bwd_cshort_mfma<f16_t>;
+        if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_apply_bwd")) return rc;
+        hipLaunchKernelGGL(fn, grid, dim3(256), ldsm, (hipStream_t)stream, a);
+      } else {
+        auto fn = cq_apply_bwd_cshort_mfma<bf16_t>;
+        if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_apply_bwd")) return rc;
+        hipLaunchKernelGGL(fn, grid, dim3(256), ldsm, (hipStream_t)stream, a);
+      }
+      VMR_LAUNCH_CHECK();
+      return 0;
+    }
     const size_t lds = (size_t)4 * SP * DS * 4 + img;
     VMR_CHECK(lds <= 160 * 1024, "vmr_cq_apply_bwd: does not fit LDS (%zu B)", lds);
     CQ_DISPATCH_SP(SP, cq_apply_bwd_cshort, if (int rc = set_lds((const void*)fn, lds, "vmr_cq_apply_bwd")) return rc;
