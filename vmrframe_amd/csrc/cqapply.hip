@@ -521,38 +521,82 @@ __device__ __forceinline__ bf16x8 img_frag_tr(const bf16_t* img, int rb, int t, 
   return u.v;
 }
 
+// ---- the two product shapes, images in LDS (long stream: 128 rows, short: 32 rows; P: [long][short cols]) ----------------
+// out[l][d] = sum_s P[l][s] X[s][d] (K = 32 short rows): wave w owns long tiles 2w, 2w + 1 and all eight channel tiles;
+// the result goes straight into the 16-bit image dst [128][IMG_LD]
 template <typename E>
-__global__ __launch_bounds__(256) void cq_apply_bwd_cshort_mfma(ApplyArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int RB = IMG_LD * 2, RBP = PLD * 2;
-  bf16_t* Qi = reinterpret_cast<bf16_t*>(smem);          // [128][IMG_LD]; dmid after c2q is done
-  bf16_t* midI = Qi + 128 * IMG_LD;
-  bf16_t* dQs = midI + 128 * IMG_LD;
-  bf16_t* Ci = dQs + 128 * IMG_LD;                       // [32][IMG_LD]
-  bf16_t* X1i = Ci + 32 * IMG_LD;
-  bf16_t* X2i = X1i + 32 * IMG_LD;
-  bf16_t* P1i = X2i + 32 * IMG_LD;                       // [128][PLD]
-  bf16_t* P2i = P1i + 128 * PLD;
-  const int tid = threadIdx.x, lane = tid & 63, w = WAVE_ID();
+__device__ __forceinline__ void prod_long_rows(const bf16_t* Pi, const bf16_t* Xi, bf16_t* dst, int w, int lane) {
   const int r16 = lane & 15, kq = lane >> 4;
-  const int b = blockIdx.y, slice = blockIdx.x, D = a.D, Lc = a.Lc, Lq = a.Lq;
-  const bf16_t* Cb = a.C + (int64_t)b * Lc * D + slice * DS;
-  const bf16_t* Qb = a.Q + (int64_t)b * Lq * D + slice * DS;
-  const bf16_t* gb = a.g + (int64_t)b * Lc * 4 * D + slice * DS;
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  // ---- stage every operand
+  bf16x8 fb[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {                          // Q slice: 128 rows x 16 chunks of 16 B
-    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
-    bf16x8 v = zero8;
-    if (row < Lq) v = ldfrag(Qb + (int64_t)row * D + ch);
-    *reinterpret_cast<bf16x8*>(Qi + row * IMG_LD + ch) = v;
+  for (int nt = 0; nt < 8; ++nt) fb[nt] = img_frag_tr(Xi, IMG_LD * 2, nt, 0, lane);
+  lgkm_wait<0>();
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) frag_pin(fb[nt]);
+#pragma unroll
+  for (int mm = 0; mm < 2; ++mm) {
+    const int mt = 2 * w + mm;
+    const bf16x8 fa = ldfrag(Pi + (mt * 16 + r16) * PLD + kq * 8);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const f32x4 acc = mfma16<E>(fa, fb[nt], (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(mt * 16 + kq * 4 + r) * IMG_LD + nt * 16 + r16] = bits_from_f<E>(acc[r]);
+    }
+  }
+}
+// acc[st][nn] (+)= sum_l P[l][s] Y[l][d] (K = 128 long rows): wave w owns channel tiles 2w, 2w + 1 and both short tiles;
+// lane (r16, kq) holds rows s = st * 16 + kq * 4 + r, channel d = (2w + nn) * 16 + r16
+template <typename E>
+__device__ __forceinline__ void prod_short_rows(const bf16_t* Pi, const bf16_t* Yi, f32x4 (&acc)[2][2], int w, int lane) {
+  bf16x8 fa[2][4], fb[2][4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) fa[mt][ks] = img_frag_tr(Pi, PLD * 2, mt, ks, lane);
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) fb[nn][ks] = img_frag_tr(Yi, IMG_LD * 2, 2 * w + nn, ks, lane);
+  }
+  lgkm_wait<0>();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { frag_pin(fa[i][ks]); frag_pin(fb[i][ks]); }
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {                          // C, X1, X2: 32 rows x 16 chunks
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn) acc[mt][nn] = mfma16<E>(fa[mt][ks], fb[nn][ks], acc[mt][nn]);
+}
+__device__ __forceinline__ void zero22(f32x4 (&acc)[2][2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+// a [rows <= 128][128-channel slice] global matrix -> image (rows >= n zero), 16-byte chunks; NR = image rows (32 or 128)
+template <int NR>
+__device__ __forceinline__ void stage_rows(const bf16_t* src, int64_t ld, int n, bf16_t* img, int tid) {
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < NR / 16; ++j) {
+    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
+    bf16x8 v = zero8;
+    if (row < n) v = ldfrag(src + (int64_t)row * ld + ch);
+    *reinterpret_cast<bf16x8*>(img + row * IMG_LD + ch) = v;
+  }
+}
+// context rows -> Ci, X1i = dc2q = g2 + g3*C, X2i = dq2c = g4*C (rows >= n zero)
+template <typename E, int NR>
+__device__ __forceinline__ void stage_ctx(const bf16_t* Cb, const bf16_t* gb, int D, int n, bf16_t* Ci, bf16_t* X1i, bf16_t* X2i, int tid) {
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < NR / 16; ++j) {
     const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
     bf16x8 c8 = zero8, x1 = zero8, x2 = zero8;
-    if (row < Lc) {
+    if (row < n) {
       const bf16_t* gr = gb + (int64_t)row * 4 * D + ch;
       c8 = ldfrag(Cb + (int64_t)row * D + ch);
       const bf16x8 g2 = ldfrag(gr + D), g3 = ldfrag(gr + 2 * D), g4 = ldfrag(gr + 3 * D);
@@ -567,81 +611,77 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort_mfma(ApplyArgs a) {
     *reinterpret_cast<bf16x8*>(X1i + row * IMG_LD + ch) = x1;
     *reinterpret_cast<bf16x8*>(X2i + row * IMG_LD + ch) = x2;
   }
-  {
-    const int SP = (Lc + 7) / 8 * 8;                     // the probability rows' length (cqscore.hip: columns >= Lc are exactly 0)
-    const float* A1 = a.A1 + (int64_t)b * Lq * SP;
-    const float* A2 = a.A2 + (int64_t)b * Lq * SP;
+}
+// fp32 long-major [nl][SP] rows -> 16-bit image [128][PLD] (rows >= nl and columns >= SP zero)
+template <typename E>
+__device__ __forceinline__ void stage_probs(const float* A, int nl, int SP, bf16_t* Pi, int tid) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {                        // P images: 128 rows x 4 groups of 8 columns
-      const int i = tid + 256 * j, row = i >> 2, cg = (i & 3) * 8;
-      bf16x8 p1 = zero8, p2 = zero8;
-      if (row < Lq && cg < SP) {
-        const f32x4 u0 = *reinterpret_cast<const f32x4*>(A1 + (int64_t)row * SP + cg), u1 = *reinterpret_cast<const f32x4*>(A1 + (int64_t)row * SP + cg + 4);
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(A2 + (int64_t)row * SP + cg), v1 = *reinterpret_cast<const f32x4*>(A2 + (int64_t)row * SP + cg + 4);
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + 256 * j, row = i >> 2, cg = (i & 3) * 8;
+    bf16x8 p = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < nl && cg < SP) {
+      const f32x4 u0 = *reinterpret_cast<const f32x4*>(A + (int64_t)row * SP + cg), u1 = *reinterpret_cast<const f32x4*>(A + (int64_t)row * SP + cg + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          p1[e] = bits_from_f<E>(u0[e]); p1[4 + e] = bits_from_f<E>(u1[e]);
-          p2[e] = bits_from_f<E>(v0[e]); p2[4 + e] = bits_from_f<E>(v1[e]);
-        }
-      }
-      *reinterpret_cast<bf16x8*>(P1i + row * PLD + cg) = p1;
-      *reinterpret_cast<bf16x8*>(P2i + row * PLD + cg) = p2;
+      for (int e = 0; e < 4; ++e) { p[e] = bits_from_f<E>(u0[e]); p[4 + e] = bits_from_f<E>(u1[e]); }
     }
+    *reinterpret_cast<bf16x8*>(Pi + row * PLD + cg) = p;
   }
-  __syncthreads();
-  // ---- K = c products: out[q][d] = sum_c P[q][c] X[c][d]; wave w: q tiles 2w, 2w + 1, all eight channel tiles
-  auto rows_x_short = [&](const bf16_t* Pi, const bf16_t* Xi, bf16_t* dst) {
-    bf16x8 fb[8];
+}
+// short-side accumulators -> a [32][IMG_LD] image / a global [n][D] matrix (2-byte stores: 32 rows only)
+template <typename E>
+__device__ __forceinline__ void put_short_img(const f32x4 (&acc)[2][2], bf16_t* img, int w, int lane) {
+  const int r16 = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) fb[nt] = img_frag_tr(Xi, RB, nt, 0, lane);
-    lgkm_wait<0>();
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) frag_pin(fb[nt]);
+    for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-    for (int mm = 0; mm < 2; ++mm) {
-      const int mt = 2 * w + mm;
-      const bf16x8 fa = ldfrag(Pi + (mt * 16 + r16) * PLD + kq * 8);
+      for (int r = 0; r < 4; ++r) img[(mt * 16 + kq * 4 + r) * IMG_LD + (2 * w + nn) * 16 + r16] = bits_from_f<E>(acc[mt][nn][r]);
+}
+template <typename E>
+__device__ __forceinline__ void put_short_global(const f32x4 (&acc)[2][2], bf16_t* dst, int64_t ld, int n, int w, int lane) {
+  const int r16 = lane & 15, kq = lane >> 4;
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        const f32x4 acc = mfma16<E>(fa, fb[nt], (f32x4){0.f, 0.f, 0.f, 0.f});
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(mt * 16 + kq * 4 + r) * IMG_LD + nt * 16 + r16] = bits_from_f<E>(acc[r]);
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int srow = mt * 16 + kq * 4 + r;
+        if (srow < n) dst[(int64_t)srow * ld + (2 * w + nn) * 16 + r16] = bits_from_f<E>(acc[mt][nn][r]);
       }
-    }
-  };
-  rows_x_short(P2i, Ci, midI);                           // mid = S_t^T-side rows . C
-  rows_x_short(P1i, X1i, dQs);                           // dQ = S_ . dc2q
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void cq_apply_bwd_cshort_mfma(ApplyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Qi = reinterpret_cast<bf16_t*>(smem);          // [128][IMG_LD]; dmid after c2q is done
+  bf16_t* midI = Qi + 128 * IMG_LD;
+  bf16_t* dQs = midI + 128 * IMG_LD;
+  bf16_t* Ci = dQs + 128 * IMG_LD;                       // [32][IMG_LD]
+  bf16_t* X1i = Ci + 32 * IMG_LD;
+  bf16_t* X2i = X1i + 32 * IMG_LD;
+  bf16_t* P1i = X2i + 32 * IMG_LD;                       // [128][PLD]
+  bf16_t* P2i = P1i + 128 * PLD;
+  const int tid = threadIdx.x, lane = tid & 63, w = WAVE_ID();
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y, slice = blockIdx.x, D = a.D, Lc = a.Lc, Lq = a.Lq;
+  const bf16_t* Cb = a.C + (int64_t)b * Lc * D + slice * DS;
+  const bf16_t* Qb = a.Q + (int64_t)b * Lq * D + slice * DS;
+  const bf16_t* gb = a.g + (int64_t)b * Lc * 4 * D + slice * DS;
+  const int SP = (Lc + 7) / 8 * 8;                       // the probability rows' length (cqscore.hip: columns >= Lc are exactly 0)
+  stage_rows<128>(Qb, D, Lq, Qi, tid);
+  stage_ctx<E, 32>(Cb, gb, D, Lc, Ci, X1i, X2i, tid);
+  stage_probs<E>(a.A1 + (int64_t)b * Lq * SP, Lq, SP, P1i, tid);
+  stage_probs<E>(a.A2 + (int64_t)b * Lq * SP, Lq, SP, P2i, tid);
   __syncthreads();
-  // ---- K = q products: out[c][d] = sum_q P[q][c] Y[q][d]; wave w: channel tiles 2w, 2w + 1, both c tiles
-  auto short_x_rows = [&](const bf16_t* Pi, const bf16_t* Yi, f32x4 (&acc)[2][2]) {
-    bf16x8 fa[2][4], fb[2][4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) fa[mt][ks] = img_frag_tr(Pi, RBP, mt, ks, lane);
-#pragma unroll
-      for (int nn = 0; nn < 2; ++nn) fb[nn][ks] = img_frag_tr(Yi, RB, 2 * w + nn, ks, lane);
-    }
-    lgkm_wait<0>();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) { frag_pin(fa[i][ks]); frag_pin(fb[i][ks]); }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn) acc[mt][nn] = mfma16<E>(fa[mt][ks], fb[nn][ks], acc[mt][nn]);
-  };
+  prod_long_rows<E>(P2i, Ci, midI, w, lane);             // mid[q] = sum_c S_t[c,q] C[c]
+  prod_long_rows<E>(P1i, X1i, dQs, w, lane);             // dQ[q]  = sum_c S_[c,q] dc2q[c]
+  __syncthreads();
   f32x4 c2q[2][2], q2c[2][2], dcm[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) c2q[i][j] = q2c[i][j] = dcm[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  short_x_rows(P1i, Qi, c2q);
-  short_x_rows(P1i, midI, q2c);
+  zero22(c2q); zero22(q2c); zero22(dcm);
+  prod_short_rows<E>(P1i, Qi, c2q, w, lane);
+  prod_short_rows<E>(P1i, midI, q2c, w, lane);
   // the staged dQ rows leave with 16-byte stores
   bf16_t* dQb = a.dQ + (int64_t)b * Lq * D + slice * DS;
 #pragma unroll
@@ -651,9 +691,9 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort_mfma(ApplyArgs a) {
   }
   __syncthreads();                                       // every wave is done with Qi
   bf16_t* dmidI = Qi;
-  rows_x_short(P1i, X2i, dmidI);                         // dmid = S_ . dq2c
+  prod_long_rows<E>(P1i, X2i, dmidI, w, lane);           // dmid[q] = sum_c S_[c,q] dq2c[c]
   __syncthreads();
-  short_x_rows(P2i, dmidI, dcm);                         // dC through mid: S_t . dmid
+  prod_short_rows<E>(P2i, dmidI, dcm, w, lane);          // dC through mid: sum_q S_t[c,q] dmid[q]
   bf16_t* dCb = a.dC + (int64_t)b * Lc * D + slice * DS;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -668,6 +708,66 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort_mfma(ApplyArgs a) {
           dCb[(int64_t)c * D + d] = bits_from_f<E>(g1 + g3 * c2q[mt][nn][r] + g4 * q2c[mt][nn][r] + dcm[mt][nn][r]);
         }
       }
+  mfma_phase<E>(a, b, slice, midI, dmidI, lane, w);
+}
+
+// backward, context = LONG stream (Lc <= 128, Lq <= 32), same two product shapes wired the other way round:
+//   mid = S_t^T.C, dQ = S_^T.dc2q, dmid = S_^T.dq2c   (K = the 128 context rows)   -> 32-row images / global dQ
+//   c2q = S_.Q, q2c = S_.mid, dCm = S_t.dmid            (K = the 32 query rows)      -> three 128-row images over the dead
+//   Ci / X1i / X2i regions; a cooperative epilogue then forms dC = g1 + g3*c2q + g4*q2c + dCm with 16-byte accesses.
+template <typename E>
+__global__ __launch_bounds__(256) void cq_apply_bwd_clong_mfma(ApplyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Ci = reinterpret_cast<bf16_t*>(smem);          // [128][IMG_LD]; dCm after mid is done
+  bf16_t* X1i = Ci + 128 * IMG_LD;                       // ... c2q
+  bf16_t* X2i = X1i + 128 * IMG_LD;                      // ... q2c
+  bf16_t* Qi = X2i + 128 * IMG_LD;                       // [32][IMG_LD]
+  bf16_t* midI = Qi + 32 * IMG_LD;
+  bf16_t* dmidI = midI + 32 * IMG_LD;
+  bf16_t* P1i = dmidI + 32 * IMG_LD;                     // [128][PLD]: rows = context, columns = query
+  bf16_t* P2i = P1i + 128 * PLD;
+  const int tid = threadIdx.x, lane = tid & 63, w = WAVE_ID();
+  const int b = blockIdx.y, slice = blockIdx.x, D = a.D, Lc = a.Lc, Lq = a.Lq;
+  const bf16_t* Cb = a.C + (int64_t)b * Lc * D + slice * DS;
+  const bf16_t* Qb = a.Q + (int64_t)b * Lq * D + slice * DS;
+  const bf16_t* gb = a.g + (int64_t)b * Lc * 4 * D + slice * DS;
+  const int SP = (Lq + 7) / 8 * 8;
+  stage_ctx<E, 128>(Cb, gb, D, Lc, Ci, X1i, X2i, tid);
+  stage_rows<32>(Qb, D, Lq, Qi, tid);
+  stage_probs<E>(a.A1 + (int64_t)b * Lc * SP, Lc, SP, P1i, tid);
+  stage_probs<E>(a.A2 + (int64_t)b * Lc * SP, Lc, SP, P2i, tid);
+  __syncthreads();
+  {
+    f32x4 mid[2][2], dq[2][2], dmid[2][2];
+    zero22(mid); zero22(dq); zero22(dmid);
+    prod_short_rows<E>(P2i, Ci, mid, w, lane);
+    prod_short_rows<E>(P1i, X1i, dq, w, lane);
+    prod_short_rows<E>(P1i, X2i, dmid, w, lane);
+    put_short_img<E>(mid, midI, w, lane);
+    put_short_img<E>(dmid, dmidI, w, lane);
+    put_short_global<E>(dq, a.dQ + (int64_t)b * Lq * D + slice * DS, D, Lq, w, lane);
+  }
+  __syncthreads();                                       // mid / dmid complete; Ci, X1i, X2i free
+  prod_long_rows<E>(P1i, Qi, X1i, w, lane);              // c2q
+  prod_long_rows<E>(P1i, midI, X2i, w, lane);            // q2c
+  prod_long_rows<E>(P2i, dmidI, Ci, w, lane);            // dC through mid
+  __syncthreads();
+  bf16_t* dCb = a.dC + (int64_t)b * Lc * D + slice * DS;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
+    if (row < Lc) {
+      const bf16_t* gr = gb + (int64_t)row * 4 * D + ch;
+      const bf16x8 g1 = ldfrag(gr), g3 = ldfrag(gr + 2 * D), g4 = ldfrag(gr + 3 * D);
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(X1i + row * IMG_LD + ch), y = *reinterpret_cast<const bf16x8*>(X2i + row * IMG_LD + ch);
+      const bf16x8 z = *reinterpret_cast<const bf16x8*>(Ci + row * IMG_LD + ch);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o[e] = bits_from_f<E>(frag_get<E>(g1, e) + frag_get<E>(g3, e) * frag_get<E>(x, e) + frag_get<E>(g4, e) * frag_get<E>(y, e) + frag_get<E>(z, e));
+      *reinterpret_cast<bf16x8*>(dCb + (int64_t)row * D + ch) = o;
+    }
+  }
   mfma_phase<E>(a, b, slice, midI, dmidI, lane, w);
 }
 
@@ -824,7 +924,44 @@ __global__ __launch_bounds__(256) void cq_score_bwd_kernel(ScoreBwdArgs a) {
   }
 }
 
+// The same on MFMA (bf16, Ll <= 128, Ls <= 32): dS rounded to the element type as a [long][short] image,
+//   d(long)  = dS . short      (K = 32)  -> staged image, 16-byte stores
+//   d(short) = dS^T . long     (K = 128) -> registers, 2-byte stores (32 rows)
+template <typename E>
+__global__ __launch_bounds__(256) void cq_score_bwd_mfma(ScoreBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Li = reinterpret_cast<bf16_t*>(smem);          // [128][IMG_LD]
+  bf16_t* dLs = Li + 128 * IMG_LD;                       // [128][IMG_LD]
+  bf16_t* Si = dLs + 128 * IMG_LD;                       // [32][IMG_LD]
+  bf16_t* Pi = Si + 32 * IMG_LD;                         // [128][PLD]
+  const int tid = threadIdx.x, lane = tid & 63, w = WAVE_ID();
+  const int b = blockIdx.y, slice = blockIdx.x, D = a.D, Ll = a.Ll, Ls = a.Ls;
+  const int SP = (Ls + 7) / 8 * 8;
+  stage_rows<128>(a.lng + (int64_t)b * Ll * D + slice * DS, D, Ll, Li, tid);
+  stage_rows<32>(a.sht + (int64_t)b * Ls * D + slice * DS, D, Ls, Si, tid);
+  stage_probs<E>(a.dS + (int64_t)b * Ll * SP, Ll, SP, Pi, tid);
+  __syncthreads();
+  prod_long_rows<E>(Pi, Si, dLs, w, lane);
+  f32x4 ds[2][2];
+  zero22(ds);
+  prod_short_rows<E>(Pi, Li, ds, w, lane);
+  put_short_global<E>(ds, a.dsht + (int64_t)b * Ls * D + slice * DS, D, Ls, w, lane);
+  __syncthreads();
+  bf16_t* dLb = a.dlng + (int64_t)b * Ll * D + slice * DS;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
+    if (row < Ll) *reinterpret_cast<bf16x8*>(dLb + (int64_t)row * D + ch) = *reinterpret_cast<const bf16x8*>(dLs + row * IMG_LD + ch);
+  }
+}
+
 inline int sp_of(int n) { return n <= 8 ? 8 : (n <= 16 ? 16 : (n <= 24 ? 24 : 32)); }
+
+int cq_mfma_on() {      // A/B: VMR_CQ_MFMA=0 keeps the register kernels
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("VMR_CQ_MFMA"); on = e ? atoi(e) : 1; }
+  return on;
+}
 
 int set_lds(const void* fn, size_t bytes, const char* what) {
   if (bytes <= 64 * 1024) return 0;
@@ -897,15 +1034,27 @@ extern "C" int vmr_cq_apply_bwd(const void* dcat4, const void* ctx, const void* 
   const size_t img = (size_t)2 * a.LqP * IMG_LD * 2;
   if (Lq <= Lc) {
     const int SP = sp_of(Lq);
+    if (cq_mfma_on() && Lc <= 128 && Lq <= 32) {
+      const size_t ldsm = (size_t)(3 * 128 + 3 * 32) * IMG_LD * 2 + (size_t)2 * 128 * PLD * 2;
+      if (dtype == VMR_F16) {
+        auto fn = cq_apply_bwd_clong_mfma<f16_t>;
+        if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_apply_bwd")) return rc;
+        hipLaunchKernelGGL(fn, grid, dim3(256), ldsm, (hipStream_t)stream, a);
+      } else {
+        auto fn = cq_apply_bwd_clong_mfma<bf16_t>;
+        if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_apply_bwd")) return rc;
+        hipLaunchKernelGGL(fn, grid, dim3(256), ldsm, (hipStream_t)stream, a);
+      }
+      VMR_LAUNCH_CHECK();
+      return 0;
+    }
     const size_t lds = (size_t)8 * SP * DS * 4 + img;
     VMR_CHECK(lds <= 160 * 1024, "vmr_cq_apply_bwd: does not fit LDS (%zu B)", lds);
     CQ_DISPATCH_SP(SP, cq_apply_bwd_clong, if (int rc = set_lds((const void*)fn, lds, "vmr_cq_apply_bwd")) return rc;
                    hipLaunchKernelGGL(fn, grid, dim3(256), lds, (hipStream_t)stream, a);)
   } else {
     const int SP = sp_of(Lc);
-    static int mfma_env = -1;
-    if (mfma_env < 0) { const char* e = getenv("VMR_CQ_MFMA"); mfma_env = e ? atoi(e) : 1; }      // A/B: 0 = the register kernel
-    if (mfma_env && Lq <= 128 && Lc <= 32) {
+    if (cq_mfma_on() && Lq <= 128 && Lc <= 32) {
       const size_t ldsm = (size_t)(3 * 128 + 3 * 32) * IMG_LD * 2 + (size_t)2 * 128 * PLD * 2;
       if (dtype == VMR_F16) {
         auto fn = cq_apply_bwd_cshort_mfma<f16_t>;
@@ -963,6 +1112,14 @@ extern "C" int vmr_cq_score_bwd(const void* lng, const void* sht, const float* d
   a.Ll = Ll; a.Ls = Ls; a.D = D;
   const dim3 grid(D / DS, B);
   const int SP = sp_of(Ls);
+  if (cq_mfma_on() && dtype == VMR_BF16 && Ll <= 128) {      // (fp16 keeps dS in fp32: a scaled gradient may not fit the element type)
+    const size_t ldsm = (size_t)(2 * 128 + 32) * IMG_LD * 2 + (size_t)128 * PLD * 2;
+    auto fn = cq_score_bwd_mfma<bf16_t>;
+    if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_score_bwd")) return rc;
+    hipLaunchKernelGGL(fn, grid, dim3(256), ldsm, (hipStream_t)stream, a);
+    VMR_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = (size_t)4 * SP * DS * 4;
   CQ_DISPATCH_SP(SP, cq_score_bwd_kernel, if (int rc = set_lds((const void*)fn, lds, "vmr_cq_score_bwd")) return rc;
                  hipLaunchKernelGGL(fn, grid, dim3(256), lds, (hipStream_t)stream, a);)
