@@ -521,6 +521,14 @@ __device__ __forceinline__ bf16x8 img_frag_tr(const bf16_t* img, int rb, int t, 
   return u.v;
 }
 
+// four consecutive elements from an accumulator quad, one 8-byte store
+template <typename E> __device__ __forceinline__ void st4(bf16_t* p, const f32x4& v) {
+  typedef __attribute__((ext_vector_type(4))) bf16_t b4;
+  b4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = bits_from_f<E>(v[r]);
+  *reinterpret_cast<b4*>(p) = o;
+}
 // ---- the two product shapes, images in LDS (long stream: 128 rows, short: 32 rows; P: [long][short cols]) ----------------
 // out[l][d] = sum_s P[l][s] X[s][d] (K = 32 short rows): wave w owns long tiles 2w, 2w + 1 and all eight channel tiles;
 // the result goes straight into the 16-bit image dst [128][IMG_LD]
@@ -539,14 +547,15 @@ __device__ __forceinline__ void prod_long_rows(const bf16_t* Pi, const bf16_t* X
     const bf16x8 fa = ldfrag(Pi + (mt * 16 + r16) * PLD + kq * 8);
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      const f32x4 acc = mfma16<E>(fa, fb[nt], (f32x4){0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(mt * 16 + kq * 4 + r) * IMG_LD + nt * 16 + r16] = bits_from_f<E>(acc[r]);
+      // (the transposed product X^T . P^T: a lane then holds FOUR consecutive channels of one row -- one 8-byte store per
+      //  tile instead of four 2-byte ones)
+      const f32x4 acc = mfma16<E>(fb[nt], fa, (f32x4){0.f, 0.f, 0.f, 0.f});
+      st4<E>(dst + (mt * 16 + r16) * IMG_LD + nt * 16 + kq * 4, acc);
     }
   }
 }
-// acc[st][nn] (+)= sum_l P[l][s] Y[l][d] (K = 128 long rows): wave w owns channel tiles 2w, 2w + 1 and both short tiles;
-// lane (r16, kq) holds rows s = st * 16 + kq * 4 + r, channel d = (2w + nn) * 16 + r16
+// acc[st][nn] (+)= sum_l P[l][s] Y[l][d] (K = 128 long rows), as the transposed product Y^T . P: wave w owns channel tiles
+// 2w, 2w + 1 and both short tiles; lane (r16, kq) holds row s = st * 16 + r16, channels d = (2w + nn) * 16 + kq * 4 + r
 template <typename E>
 __device__ __forceinline__ void prod_short_rows(const bf16_t* Pi, const bf16_t* Yi, f32x4 (&acc)[2][2], int w, int lane) {
   bf16x8 fa[2][4], fb[2][4];
@@ -568,7 +577,7 @@ __device__ __forceinline__ void prod_short_rows(const bf16_t* Pi, const bf16_t* 
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nn = 0; nn < 2; ++nn) acc[mt][nn] = mfma16<E>(fa[mt][ks], fb[nn][ks], acc[mt][nn]);
+      for (int nn = 0; nn < 2; ++nn) acc[mt][nn] = mfma16<E>(fb[nn][ks], fa[mt][ks], acc[mt][nn]);
 }
 __device__ __forceinline__ void zero22(f32x4 (&acc)[2][2]) {
 #pragma unroll
@@ -634,9 +643,7 @@ __device__ __forceinline__ void put_short_img(const f32x4 (&acc)[2][2], bf16_t* 
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) img[(mt * 16 + kq * 4 + r) * IMG_LD + (2 * w + nn) * 16 + r16] = bits_from_f<E>(acc[mt][nn][r]);
+    for (int nn = 0; nn < 2; ++nn) st4<E>(img + (mt * 16 + r16) * IMG_LD + (2 * w + nn) * 16 + kq * 4, acc[mt][nn]);
 }
 template <typename E>
 __device__ __forceinline__ void put_short_global(const f32x4 (&acc)[2][2], bf16_t* dst, int64_t ld, int n, int w, int lane) {
@@ -644,12 +651,43 @@ __device__ __forceinline__ void put_short_global(const f32x4 (&acc)[2][2], bf16_
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn)
+    for (int nn = 0; nn < 2; ++nn) {
+      const int srow = mt * 16 + r16;
+      if (srow < n) st4<E>(dst + (int64_t)srow * ld + (2 * w + nn) * 16 + kq * 4, acc[mt][nn]);
+    }
+}
+
+// mfma_phase with the context side (C, dc2q, dq2c) read from the LDS images the MFMA kernels hold anyway (k = channels is the
+// contiguous index of every image row: plain 16-byte fragment reads, no global re-read, no conversions); the query rows
+// from the image Qi when it is still alive (QIMG), else from global.
+template <typename E, bool QIMG>
+__device__ __forceinline__ void mfma_phase_img(const ApplyArgs& a, int b, int slice, const bf16_t* Qi, const bf16_t* midI,
+                                               const bf16_t* dmidI, const bf16_t* Ci, const bf16_t* X1i, const bf16_t* X2i,
+                                               int lane, int w) {
+  const int D = a.D, mt_n = a.LqP / 16, nt_n = a.LcP / 16;
+  const int kq = (lane >> 4) * 8;
+  const bf16_t* Qb = a.Q + (int64_t)b * a.Lq * D + slice * DS;
+  float* pb = a.parts + ((int64_t)b * gridDim.x + slice) * 2 * a.LcP * a.LqP;
+  for (int t = w; t < mt_n * nt_n; t += 4) {
+    const int mt = t % mt_n, nt = t / mt_n;
+    const int qrow = mt * 16 + (lane & 15), crow = nt * 16 + (lane & 15);
+    const int qg = min(qrow, a.Lq - 1);
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int srow = mt * 16 + kq * 4 + r;
-        if (srow < n) dst[(int64_t)srow * ld + (2 * w + nn) * 16 + r16] = bits_from_f<E>(acc[mt][nn][r]);
-      }
+    for (int ks = 0; ks < DS / 32; ++ks) {
+      const int k = ks * 32 + kq;
+      const bf16x8 fq = QIMG ? ldfrag(Qi + qrow * IMG_LD + k) : ldfrag(Qb + (int64_t)qg * D + k);
+      const bf16x8 fm = ldfrag(midI + qrow * IMG_LD + k);
+      const bf16x8 fd = ldfrag(dmidI + qrow * IMG_LD + k);
+      acc1 = mfma16<E>(fq, ldfrag(X1i + crow * IMG_LD + k), acc1);
+      acc1 = mfma16<E>(fm, ldfrag(X2i + crow * IMG_LD + k), acc1);
+      acc2 = mfma16<E>(fd, ldfrag(Ci + crow * IMG_LD + k), acc2);
+    }
+    const int q0 = mt * 16 + (lane >> 4) * 4;
+    float* p1 = pb + (int64_t)crow * a.LqP + q0;
+    *reinterpret_cast<f32x4*>(p1) = acc1;
+    *reinterpret_cast<f32x4*>(p1 + (int64_t)a.LcP * a.LqP) = acc2;
+  }
 }
 
 template <typename E>
@@ -698,17 +736,106 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort_mfma(ApplyArgs a) {
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn)
+    for (int nn = 0; nn < 2; ++nn) {
+      const int c = mt * 16 + r16, d = (2 * w + nn) * 16 + kq * 4;       // this lane: row c, four channels from d
+      if (c < Lc) {
+        typedef __attribute__((ext_vector_type(4))) bf16_t b4;
+        const bf16_t* gr = gb + (int64_t)c * 4 * D + d;
+        const b4 g1 = *reinterpret_cast<const b4*>(gr), g3 = *reinterpret_cast<const b4*>(gr + 2 * D), g4 = *reinterpret_cast<const b4*>(gr + 3 * D);
+        f32x4 o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = mt * 16 + kq * 4 + r, d = (2 * w + nn) * 16 + r16;
-        if (c < Lc) {
-          const bf16_t* gr = gb + (int64_t)c * 4 * D + d;
-          const float g1 = bits_to_f<E>(gr[0]), g3 = bits_to_f<E>(gr[2 * D]), g4 = bits_to_f<E>(gr[3 * D]);
-          dCb[(int64_t)c * D + d] = bits_from_f<E>(g1 + g3 * c2q[mt][nn][r] + g4 * q2c[mt][nn][r] + dcm[mt][nn][r]);
-        }
+        for (int r = 0; r < 4; ++r)
+          o[r] = bits_to_f<E>(g1[r]) + bits_to_f<E>(g3[r]) * c2q[mt][nn][r] + bits_to_f<E>(g4[r]) * q2c[mt][nn][r] + dcm[mt][nn][r];
+        st4<E>(dCb + (int64_t)c * D + d, o);
       }
-  mfma_phase<E>(a, b, slice, midI, dmidI, lane, w);
+    }
+  mfma_phase_img<E, false>(a, b, slice, nullptr, midI, dmidI, Ci, X1i, X2i, lane, w);
+}
+
+// the 4-way concat of NR context rows from the images Ci (context), Xi (c2q), Yi (q2c): [C | c2q | C*c2q | C*q2c], 16-byte stores
+template <typename E, int NR>
+__device__ __forceinline__ void put_cat4(const bf16_t* Ci, const bf16_t* Xi, const bf16_t* Yi, bf16_t* ob, int D, int n, int tid) {
+#pragma unroll
+  for (int j = 0; j < NR / 16; ++j) {
+    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
+    if (row < n) {
+      const bf16x8 c8 = *reinterpret_cast<const bf16x8*>(Ci + row * IMG_LD + ch), x = *reinterpret_cast<const bf16x8*>(Xi + row * IMG_LD + ch);
+      const bf16x8 y = *reinterpret_cast<const bf16x8*>(Yi + row * IMG_LD + ch);
+      bf16x8 cx, cy;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float cf = frag_get<E>(c8, e);
+        cx[e] = bits_from_f<E>(cf * frag_get<E>(x, e));
+        cy[e] = bits_from_f<E>(cf * frag_get<E>(y, e));
+      }
+      bf16_t* o = ob + (int64_t)row * 4 * D + ch;
+      *reinterpret_cast<bf16x8*>(o) = c8;
+      *reinterpret_cast<bf16x8*>(o + D) = x;
+      *reinterpret_cast<bf16x8*>(o + 2 * D) = cx;
+      *reinterpret_cast<bf16x8*>(o + 3 * D) = cy;
+    }
+  }
+}
+
+// forward on MFMA, context = SHORT stream (Lq <= 128, Lc <= 32): mid = P2.C (K = 32), c2q = P1^T.Q, q2c = P1^T.mid (K = 128)
+template <typename E>
+__global__ __launch_bounds__(256) void cq_apply_fwd_cshort_mfma(ApplyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Qi = reinterpret_cast<bf16_t*>(smem);          // [128][IMG_LD]
+  bf16_t* midI = Qi + 128 * IMG_LD;                      // [128][IMG_LD]
+  bf16_t* Ci = midI + 128 * IMG_LD;                      // [32][IMG_LD]
+  bf16_t* Xi = Ci + 32 * IMG_LD;
+  bf16_t* Yi = Xi + 32 * IMG_LD;
+  bf16_t* P1i = Yi + 32 * IMG_LD;                        // [128][PLD]
+  bf16_t* P2i = P1i + 128 * PLD;
+  const int tid = threadIdx.x, lane = tid & 63, w = WAVE_ID();
+  const int b = blockIdx.y, slice = blockIdx.x, D = a.D, Lc = a.Lc, Lq = a.Lq;
+  const int SP = (Lc + 7) / 8 * 8;
+  stage_rows<128>(a.Q + (int64_t)b * Lq * D + slice * DS, D, Lq, Qi, tid);
+  stage_rows<32>(a.C + (int64_t)b * Lc * D + slice * DS, D, Lc, Ci, tid);
+  stage_probs<E>(a.A1 + (int64_t)b * Lq * SP, Lq, SP, P1i, tid);
+  stage_probs<E>(a.A2 + (int64_t)b * Lq * SP, Lq, SP, P2i, tid);
+  __syncthreads();
+  prod_long_rows<E>(P2i, Ci, midI, w, lane);
+  f32x4 c2q[2][2], q2c[2][2];
+  zero22(c2q); zero22(q2c);
+  prod_short_rows<E>(P1i, Qi, c2q, w, lane);
+  put_short_img<E>(c2q, Xi, w, lane);
+  __syncthreads();
+  prod_short_rows<E>(P1i, midI, q2c, w, lane);
+  put_short_img<E>(q2c, Yi, w, lane);
+  __syncthreads();
+  put_cat4<E, 32>(Ci, Xi, Yi, a.out + (int64_t)b * Lc * 4 * D + slice * DS, D, Lc, tid);
+}
+
+// forward on MFMA, context = LONG stream (Lc <= 128, Lq <= 32): c2q = P1.Q, mid = P2^T.C, q2c = P1.mid
+template <typename E>
+__global__ __launch_bounds__(256) void cq_apply_fwd_clong_mfma(ApplyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Ci = reinterpret_cast<bf16_t*>(smem);          // [128][IMG_LD]
+  bf16_t* Xi = Ci + 128 * IMG_LD;
+  bf16_t* Yi = Xi + 128 * IMG_LD;
+  bf16_t* Qi = Yi + 128 * IMG_LD;                        // [32][IMG_LD]
+  bf16_t* midI = Qi + 32 * IMG_LD;
+  bf16_t* P1i = midI + 32 * IMG_LD;                      // [128][PLD]
+  bf16_t* P2i = P1i + 128 * PLD;
+  const int tid = threadIdx.x, lane = tid & 63, w = WAVE_ID();
+  const int b = blockIdx.y, slice = blockIdx.x, D = a.D, Lc = a.Lc, Lq = a.Lq;
+  const int SP = (Lq + 7) / 8 * 8;
+  stage_rows<128>(a.C + (int64_t)b * Lc * D + slice * DS, D, Lc, Ci, tid);
+  stage_rows<32>(a.Q + (int64_t)b * Lq * D + slice * DS, D, Lq, Qi, tid);
+  stage_probs<E>(a.A1 + (int64_t)b * Lc * SP, Lc, SP, P1i, tid);
+  stage_probs<E>(a.A2 + (int64_t)b * Lc * SP, Lc, SP, P2i, tid);
+  __syncthreads();
+  f32x4 mid[2][2];
+  zero22(mid);
+  prod_short_rows<E>(P2i, Ci, mid, w, lane);
+  put_short_img<E>(mid, midI, w, lane);
+  prod_long_rows<E>(P1i, Qi, Xi, w, lane);
+  __syncthreads();
+  prod_long_rows<E>(P1i, midI, Yi, w, lane);
+  __syncthreads();
+  put_cat4<E, 128>(Ci, Xi, Yi, a.out + (int64_t)b * Lc * 4 * D + slice * DS, D, Lc, tid);
 }
 
 // backward, context = LONG stream (Lc <= 128, Lq <= 32), same two product shapes wired the other way round:
@@ -747,7 +874,9 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong_mfma(ApplyArgs a) {
     put_short_img<E>(dmid, dmidI, w, lane);
     put_short_global<E>(dq, a.dQ + (int64_t)b * Lq * D + slice * DS, D, Lq, w, lane);
   }
-  __syncthreads();                                       // mid / dmid complete; Ci, X1i, X2i free
+  __syncthreads();                                       // mid / dmid complete
+  mfma_phase_img<E, true>(a, b, slice, Qi, midI, dmidI, Ci, X1i, X2i, lane, w);     // dS_ / dS_t partials, all operands in LDS
+  __syncthreads();                                       // Ci, X1i, X2i free
   prod_long_rows<E>(P1i, Qi, X1i, w, lane);              // c2q
   prod_long_rows<E>(P1i, midI, X2i, w, lane);            // q2c
   prod_long_rows<E>(P2i, dmidI, Ci, w, lane);            // dC through mid
@@ -768,7 +897,6 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_clong_mfma(ApplyArgs a) {
       *reinterpret_cast<bf16x8*>(dCb + (int64_t)row * D + ch) = o;
     }
   }
-  mfma_phase<E>(a, b, slice, midI, dmidI, lane, w);
 }
 
 // =====================================================================================================================
@@ -965,8 +1093,15 @@ int cq_mfma_on() {      // A/B: VMR_CQ_MFMA=0 keeps the register kernels
 
 int set_lds(const void* fn, size_t bytes, const char* what) {
   if (bytes <= 64 * 1024) return 0;
+  // once per kernel and size (the attribute call is tens of microseconds of host time: it showed in eager loops)
+  static thread_local const void* done_fn[64];
+  static thread_local size_t done_bytes[64];
+  static thread_local int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done_fn[i] == fn && done_bytes[i] >= bytes) return 0;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return vmr_fail(-5, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+  if (ndone < 64) { done_fn[ndone] = fn; done_bytes[ndone] = bytes; ++ndone; }
   return 0;
 }
 
@@ -1002,6 +1137,23 @@ extern "C" int vmr_cq_apply_fwd(const void* ctx, const void* qry, const float* S
   a.C = (const bf16_t*)ctx; a.Q = (const bf16_t*)qry; a.A1 = S_lm; a.A2 = St_lm; a.out = (bf16_t*)out;
   a.Lc = Lc; a.Lq = Lq; a.D = D;
   const dim3 grid(D / DS, B);
+  static int fwd_env = -1;      // VMR_CQ_MFMA_FWD: bit 0 = context-short forward, bit 1 = context-long forward on MFMA
+  if (fwd_env < 0) { const char* e = getenv("VMR_CQ_MFMA_FWD"); fwd_env = e ? atoi(e) : 3; }
+  const int shortc = Lq > Lc;
+  if (cq_mfma_on() && (fwd_env & (shortc ? 1 : 2)) && (shortc ? (Lq <= 128 && Lc <= 32) : (Lc <= 128 && Lq <= 32))) {
+    const size_t ldsm = (size_t)(shortc ? 2 * 128 + 3 * 32 : 3 * 128 + 2 * 32) * IMG_LD * 2 + (size_t)2 * 128 * PLD * 2;
+#define CQ_FWD_MFMA(KERNEL, E)                                                                \
+    do {                                                                                      \
+      auto fn = KERNEL<E>;                                                                    \
+      if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_apply_fwd")) return rc;             \
+      hipLaunchKernelGGL(fn, grid, dim3(256), ldsm, (hipStream_t)stream, a);                  \
+    } while (0)
+    if (shortc) { if (dtype == VMR_F16) CQ_FWD_MFMA(cq_apply_fwd_cshort_mfma, f16_t); else CQ_FWD_MFMA(cq_apply_fwd_cshort_mfma, bf16_t); }
+    else { if (dtype == VMR_F16) CQ_FWD_MFMA(cq_apply_fwd_clong_mfma, f16_t); else CQ_FWD_MFMA(cq_apply_fwd_clong_mfma, bf16_t); }
+#undef CQ_FWD_MFMA
+    VMR_LAUNCH_CHECK();
+    return 0;
+  }
   if (Lq <= Lc) {
     const int SP = sp_of(Lq);
     const size_t lds = (size_t)4 * SP * DS * 4;
