@@ -622,6 +622,12 @@ int vmr_lstm_step_bwd(const void* dy, const void* act, const void* cs, const int
  * transposed, [ndir][H][4H]. */
 int vmr_lstm_seq_supported(int B, int H, int ndir, int dtype);
 int vmr_lstm_seq_hist_bytes(int T, int H, int ndir, int64_t* bytes);
+/* 1: vmr_lstm_seq_fwd exchanges h through `hist` itself (no arrival counter): the caller fills hist with the 16-bit
+ * pattern 0x7FFF ("not yet written": a NaN no arithmetic produces) before EVERY launch; 0: counters, hist need not be
+ * initialised. */
+int vmr_lstm_seq_sentinel(void);
+/* the same for vmr_lstm_seq_bwd and its exchange buffer dg (every row of dg is written by the launch) */
+int vmr_lstm_seq_bwd_sentinel(void);
 int vmr_lstm_seq_fwd(const void* gx, const void* whh, const int* len, void* act, void* cs, void* hp, void* y, void* hist,
                      int* sync, int B, int T, int H, int ndir, int dtype, void* stream);
 int vmr_lstm_seq_bwd(const void* dy, const void* act, const void* cs, const int* len, const void* whht, void* dg,

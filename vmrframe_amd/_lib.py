@@ -82,6 +82,8 @@ SIGNATURES = {
     "vmr_dwconv_bwd2": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vmr_lstm_seq_supported": [_I, _I, _I, _I],
     "vmr_lstm_seq_hist_bytes": [_I, _I, _I, _P],
+    "vmr_lstm_seq_sentinel": [],
+    "vmr_lstm_seq_bwd_sentinel": [],
     "vmr_lstm_seq_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vmr_lstm_seq_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vmr_convblock_bwd_supported": [_I, _I],

@@ -68,7 +68,9 @@ def _recur_fwd(gx, w_hh, lens, act, cs, hp, y, B, T, H, Z, dt, dc) -> str:
     if fused and SEQ_KERNEL and lib.vmr_lstm_seq_supported(B, H, Z, dc):
         nbytes = C.c_int64(0)
         L.check(lib.vmr_lstm_seq_hist_bytes(T, H, Z, C.byref(nbytes)), "vmr_lstm_seq_hist_bytes")
-        hist = torch.empty(nbytes.value, device=dev, dtype=torch.uint8)
+        hist = torch.empty(nbytes.value // 2, device=dev, dtype=torch.int16)
+        if lib.vmr_lstm_seq_sentinel():      # the exchange reads readiness off the history itself: "not yet written" everywhere
+            hist.fill_(0x7FFF)
         sync = torch.zeros(16, device=dev, dtype=torch.int32)
         L.check(lib.vmr_lstm_seq_fwd(gx.data_ptr(), w_hh.data_ptr(), lens.data_ptr(), act.data_ptr(), cs.data_ptr(),
                                      hp.data_ptr(), y.data_ptr(), hist.data_ptr(), sync.data_ptr(), B, T, H, Z, dc,
@@ -102,6 +104,8 @@ def _recur_bwd(dy, act, cs, lens, w_hh, mode, B, T, H, Z, dt, dc) -> torch.Tenso
     lib, dev = L.lib(), dy.device
     dg = torch.empty(Z, B, T, 4 * H, device=dev, dtype=dt)
     if mode == "seq":
+        if lib.vmr_lstm_seq_bwd_sentinel():      # dg is the exchange buffer and carries its own readiness
+            dg.view(torch.int16).fill_(0x7FFF)
         whht = w_hh.transpose(1, 2).contiguous()                      # [Z, H, 4H]: the K-contiguous operand of dg . W_hh
         sync = torch.zeros(16, device=dev, dtype=torch.int32)
         L.check(lib.vmr_lstm_seq_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), whht.data_ptr(),

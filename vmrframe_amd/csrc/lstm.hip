@@ -262,7 +262,10 @@ struct SeqArgs {
   void* hist;                               // [Z][T][H/16][64][16] (fwd: h after step s; bwd: unused)
   int* sync;                                // [0..7] arrival counters per direction, [8] error flag; zeroed by the caller
   int B, T, ndir, xpd;
+  int mode;                                 // bit 0 (forward): the history carries its own readiness (sentinel exchange), no counter
 };
+
+constexpr uint32_t SEQ_NOT_YET = 0x7FFFu;   // a NaN no arithmetic produces (bf16 and fp16 alike): "this element has not been written"
 
 __device__ __forceinline__ bf16x8 ld16_sc1(const void* p) {
   bf16x8 v;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
   constexpr int H = HH, KS = HH / 32, WPX = HH / 16, LDW = HH + 8, LDT = 68;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   E* wS = reinterpret_cast<E*>(smem);                          // [64][LDW]: rows g * 16 + n = gate g of unit u0 + n
-  float* tile = reinterpret_cast<float*>(wS + 64 * LDW);       // [64][LDT]: pre-activations, [batch row][g * 16 + n]
+  float* tile0 = reinterpret_cast<float*>(wS + 64 * LDW);      // [2][64][LDT]: pre-activations, [batch row][g * 16 + n], by step parity
   __shared__ int dead;
   // affinity (speed only): blocks with equal blockIdx % 8 share an XCD; direction z takes `xpd` of the 8 groups
   const int grp = blockIdx.x & 7, kk = blockIdx.x >> 3;
@@ -302,6 +305,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
   if (grp / a.ndir >= a.xpd || slot >= WPX) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kq = lane >> 4;
   const int B = a.B, Tn = a.T, u0 = slot * 16;
+  const bool sent = (a.mode & 1) != 0;
   const E* gx = reinterpret_cast<const E*>(a.gx);
   const E* whh = reinterpret_cast<const E*>(a.whh);
   E* act = reinterpret_cast<E*>(a.act);
@@ -332,18 +336,39 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float* tile = tile0 + (s & 1) * (64 * LDT);
     if (s > 0) {          // (h_{-1} = 0: step 0 has no recurrent part; s is uniform)
-      seq_wait(a.sync + z, s * WPX, a.sync + 8, &dead);
+      if (!sent) seq_wait(a.sync + z, s * WPX, a.sync + 8, &dead);
       const E* hsrc = hz + (int64_t)(s - 1) * (H * 64);
       bf16x8 af[KS];
+      for (int tries = 0;; ++tries) {
 #pragma unroll
-      for (int k = 0; k < KS; ++k) {
-        const int kk = k * 32 + kq * 8;
-        af[k] = ld16_sc1(hsrc + ((kk >> 4) * 64 + w * 16 + r16) * 16 + (kk & 15));
+        for (int k = 0; k < KS; ++k) {
+          const int kk = k * 32 + kq * 8;
+          af[k] = ld16_sc1(hsrc + ((kk >> 4) * 64 + w * 16 + r16) * 16 + (kk & 15));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(af[k]));
+        if (!sent) break;
+        // Sentinel exchange: the history was filled with SEQ_NOT_YET before the launch, a producer's 8-byte store (four
+        // units of one row, first element never SEQ_NOT_YET) replaces it atomically: a fragment is complete when the first
+        // element of both its 8-byte halves is not the sentinel.  No counter, no store acknowledgement on the producer's
+        // critical path; the poll IS the operand fetch.  Bounded like seq_wait.
+        uint32_t bad = 0u;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const u32x4 raw = __builtin_bit_cast(u32x4, af[k]);
+          bad |= (uint32_t)((raw[0] & 0xFFFFu) == SEQ_NOT_YET) | (uint32_t)((raw[2] & 0xFFFFu) == SEQ_NOT_YET);
+        }
+        if (!__builtin_amdgcn_ballot_w64(bad != 0u)) break;
+        if (*reinterpret_cast<volatile int*>(&dead)) break;
+        if (tries > (1 << 16)) {
+          if (lane == 0) { dead = 1; __hip_atomic_store(a.sync + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(af[k]));
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -384,8 +409,12 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
     // the exchange first: publish h_s and arrive, THEN the records nobody waits for (seq_arrive's vmcnt(0) would
     // otherwise sit out the acknowledgements of seven plain stores every step); they and the next step's gx loads
     // drain under the next poll
-    st8_sc1(hz + (int64_t)s * (H * 64) + (slot * 64 + m) * 16 + 4 * q, __builtin_bit_cast(u32x2, hn));
-    if (s + 1 < Tn) seq_arrive(a.sync + z);
+    {
+      u32x2 hb = __builtin_bit_cast(u32x2, hn);
+      if (sent && (hb[0] & 0xFFFFu) == SEQ_NOT_YET) hb[0] ^= 1u;       // (a NaN with exactly the sentinel's payload: another NaN)
+      st8_sc1(hz + (int64_t)s * (H * 64) + (slot * 64 + m) * 16 + 4 * q, hb);
+    }
+    if (s + 1 < Tn && !sent) seq_arrive(a.sync + z);
     if (real) {
       *reinterpret_cast<E4*>(hp + ca) = hprev;
 #pragma unroll
@@ -433,6 +462,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(SeqArgs a) {
   const int slot = role / GPB, bq = role % GPB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kq = lane >> 4;
   const int B = a.B, Tn = a.T, u0 = slot * UW, b0 = bq * RB;
+  const bool sent = RB == 8 && (a.mode & 1) != 0;      // (the 16-row tile keeps the counters)
   const E* whht = reinterpret_cast<const E*>(a.whh);           // [Z][H][4H]
   const E* act = reinterpret_cast<const E*>(a.act);
   const E* dy = reinterpret_cast<const E*>(a.dy);
@@ -471,7 +501,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(SeqArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s + 1 < Tn) {        // dh = dg_{s+1} . W_hh (nothing flows into the last step)
-      seq_wait(a.sync + z, (Tn - 1 - s) * WPX, a.sync + 8, &dead);
+      if (!sent) seq_wait(a.sync + z, (Tn - 1 - s) * WPX, a.sync + 8, &dead);
       const E* src = dg + (((int64_t)z * B + arow) * Tn + s + 1) * 4 * H + kq * 8;
       if constexpr (RB == 8) {
         // Only 8 of the MFMA tile's 16 operand rows are real: lanes r16 >= 8 fetch the NEXT k-step of row r16 - 8, so one
@@ -481,11 +511,29 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(SeqArgs a) {
         // other half of the tile then holds the wrong k-step's rows -- they only reach D rows 8..15, which nobody reads.
         constexpr int KP = KW / 2;
         bf16x8 af[KP];
+        for (int tries = 0;; ++tries) {
 #pragma unroll
-        for (int j = 0; j < KP; ++j) af[j] = ld16_sc1(src + (2 * w + (r16 >> 3) + 16 * j) * 32);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          for (int j = 0; j < KP; ++j) af[j] = ld16_sc1(src + (2 * w + (r16 >> 3) + 16 * j) * 32);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < KP; ++j) asm volatile("" : "+v"(af[j]));
+          for (int j = 0; j < KP; ++j) asm volatile("" : "+v"(af[j]));
+          if (!sent) break;
+          // sentinel exchange (see the forward kernel): dg itself was filled with SEQ_NOT_YET before the launch; a cell's
+          // 8-byte store (four units of one gate) replaces it atomically, its first element never the sentinel
+          uint32_t bad = 0u;
+#pragma unroll
+          for (int j = 0; j < KP; ++j) {
+            const u32x4 raw = __builtin_bit_cast(u32x4, af[j]);
+            bad |= (uint32_t)((raw[0] & 0xFFFFu) == SEQ_NOT_YET) | (uint32_t)((raw[2] & 0xFFFFu) == SEQ_NOT_YET);
+          }
+          if (!__builtin_amdgcn_ballot_w64(bad != 0u)) break;
+          if (*reinterpret_cast<volatile int*>(&dead)) break;
+          if (tries > (1 << 16)) {
+            if (lane == 0) { dead = 1; __hip_atomic_store(a.sync + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
           u32x4 raw = __builtin_bit_cast(u32x4, af[j]), rot;
@@ -546,10 +594,17 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(SeqArgs a) {
       }
       if (real) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) st8_sc1(dg + ga + g * H, __builtin_bit_cast(u32x2, dgv[g]));
+        for (int g = 0; g < 4; ++g) {
+          u32x2 v = __builtin_bit_cast(u32x2, dgv[g]);
+          if (sent && (v[0] & 0xFFFFu) == SEQ_NOT_YET) v[0] ^= 1u;
+          st8_sc1(dg + ga + g * H, v);
+        }
       }
     }
-    if (s > 0) seq_arrive(a.sync + z);     // (also the barrier that frees `part` for the next step)
+    if (s > 0) {
+      if (!sent) seq_arrive(a.sync + z);     // (also the barrier that frees `part` for the next step)
+      else __syncthreads();                  // `part` is free for the next step
+    }
   }
 }
 
@@ -648,6 +703,25 @@ extern "C" int vmr_lstm_seq_supported(int B, int H, int ndir, int dtype) {
          ndir * (H / 16) * 4 <= 256;
 }
 
+// 1: vmr_lstm_seq_fwd exchanges h through the history itself -- the caller fills `hist` with the 16-bit pattern 0x7FFF
+// ("not yet written") before every launch; 0: arrival counters (VMR_LSTM_SEQ_SENTINEL=0)
+extern "C" int vmr_lstm_seq_sentinel(void) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("VMR_LSTM_SEQ_SENTINEL"); on = e ? (atoi(e) != 0) : 1; }
+  return on;
+}
+
+// 1: vmr_lstm_seq_bwd reads readiness off dg itself: the caller fills dg with the 16-bit pattern 0x7FFF before the launch
+// (every row of dg is written by the launch); 0: counters (VMR_LSTM_SEQ_SENTINEL=0, or the (16, 16) tile)
+extern "C" int vmr_lstm_seq_bwd_sentinel(void) {
+  static int on = -1;
+  if (on < 0) {
+    const char* t = getenv("VMR_LSTM_SEQ_BWD_TILE");
+    on = vmr_lstm_seq_sentinel() && !(t && atoi(t) == 0);
+  }
+  return on;
+}
+
 extern "C" int vmr_lstm_seq_hist_bytes(int T, int H, int ndir, int64_t* bytes) {
   VMR_CHECK(bytes && T > 0 && H > 0 && ndir > 0, "vmr_lstm_seq_hist_bytes: bad argument");
   *bytes = (int64_t)ndir * T * H * 64 * 2;
@@ -665,7 +739,8 @@ extern "C" int vmr_lstm_seq_fwd(const void* gx, const void* whh, const int* len,
   memset(&a, 0, sizeof(a));
   a.gx = gx; a.whh = whh; a.len = len; a.act = act; a.cs = (float*)cs; a.hp = hp; a.y = y; a.hist = hist; a.sync = sync;
   a.B = B; a.T = T; a.ndir = ndir;
-  const size_t lds = (size_t)64 * (H + 8) * 2 + (size_t)64 * 68 * 4;
+  a.mode = vmr_lstm_seq_sentinel();
+  const size_t lds = (size_t)64 * (H + 8) * 2 + (size_t)2 * 64 * 68 * 4;
   // a direction's H/16 workgroups share ONE XCD group here (measured at H = 256: 340 us per layer against 388 spread
   // over four; the backward, with four times the workgroups and payload, is the other way round: 652 against 415)
   static int xpd_env = -1;
@@ -698,6 +773,7 @@ extern "C" int vmr_lstm_seq_bwd(const void* dy, const void* act, const void* cs,
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.act = const_cast<void*>(act); a.cs = (float*)const_cast<void*>(cs); a.len = len; a.whh = whht; a.dg = dg; a.sync = sync;
   a.B = B; a.T = T; a.ndir = ndir;
+  a.mode = vmr_lstm_seq_bwd_sentinel();
   // tile per workgroup (see the kernel): the BAN step at B = 64, T = 128 ran 16.57 ms with (16, 16), 15.83 with (32, 8),
   // 15.59 with (64, 8) for the H = 256 layers; VMR_LSTM_SEQ_BWD_TILE = 0 / 1 / 2 for A/B
   static int tile_env = -1;
