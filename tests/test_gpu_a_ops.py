@@ -327,15 +327,17 @@ def test_linear_fwd_bwd(dev):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2), (torch.float16, 3e-2)])
-def test_layernorm_fwd_bwd(dev, dt, tol):
+@pytest.mark.parametrize("rows,D,S", [(96, 256, 12), (9472, 1024, 128), (4101, 2048, 3), (7, 512, 7), (130, 1536, 13)])
+def test_layernorm_fwd_bwd(dev, dt, tol, rows, D, S):
+    """(D = 2048 / 1536: the four- and three-chunk instantiations of ln_bwd, whose software prefetch keeps the most
+    registers live across its hand-written wait; odd row counts: the two-rows-per-wave forward's tail)"""
     ops = _ops()
     torch.manual_seed(1)
-    rows, D, S = 96, 256, 12
     cache = ops.WeightCache()
     x = torch.randn(rows, D, device=dev).to(dt).requires_grad_(True)
     gamma = (1 + 0.1 * torch.randn(D, device=dev)).requires_grad_(True)
     beta = (0.1 * torch.randn(D, device=dev)).requires_grad_(True)
-    pos = torch.randn(16, D, device=dev, requires_grad=True)
+    pos = torch.randn(max(16, S), D, device=dev, requires_grad=True)
     y = ops.layer_norm(x, gamma, beta, 1e-6, cache, pos=pos, S=S)
     xr = x.detach().float().requires_grad_(True)
     posr = pos.detach().to(dt).float().requires_grad_(True)
