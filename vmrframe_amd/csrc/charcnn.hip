@@ -79,10 +79,10 @@ __device__ __forceinline__ void stage_chars(const CharCnnArgs& a, float* ce, int
 
 template <typename T, int K, int CM>
 __device__ __forceinline__ void conv_fwd(const CharCnnArgs& a, const T* Wt, const float* ce, int w0, int nw, T* out, int64_t ldo,
-                                         int8_t* amax) {
+                                         int8_t* amax, int tid, int nthr) {
   const int kk = K - 1, oc = a.oc[kk], np = a.C - K + 1;
   const T* wt = Wt + a.woff[kk];
-  for (int item = threadIdx.x; item < oc * nw; item += blockDim.x) {
+  for (int item = tid; item < oc * nw; item += nthr) {
     const int o = item % oc, wl = item / oc;
     const float* cw = ce + wl * CM * a.CD;
     float acc[CM];
@@ -128,10 +128,21 @@ __global__ __launch_bounds__(1024) void char_cnn_fwd_kernel(CharCnnArgs a, T* __
   stage_weights<T>(a, Wt);
   stage_chars<T, CM>(a, ce, w0, nw, seed, thresh, dscale);
   __syncthreads();
-  conv_fwd<T, 1, CM>(a, Wt, ce, w0, nw, out, ldo, amax);
-  conv_fwd<T, 2, CM>(a, Wt, ce, w0, nw, out, ldo, amax);
-  conv_fwd<T, 3, CM>(a, Wt, ce, w0, nw, out, ldo, amax);
-  conv_fwd<T, 4, CM>(a, Wt, ce, w0, nw, out, ldo, amax);
+  // one item = (output channel, word): 80 .. 320 items per width at 8 words -- run one after the other they kept 2 .. 5 of the
+  // 16 waves busy for a sum of four passes; with a wave range per width (2 + 3 + 4 + 5 = 14 waves) the four run side by side
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int n1 = (a.oc[0] * nw + 63) >> 6, n2 = (a.oc[1] * nw + 63) >> 6, n3 = (a.oc[2] * nw + 63) >> 6, n4 = (a.oc[3] * nw + 63) >> 6;
+  if (n1 + n2 + n3 + n4 <= (int)(blockDim.x >> 6)) {
+    if (wv < n1) conv_fwd<T, 1, CM>(a, Wt, ce, w0, nw, out, ldo, amax, wv * 64 + ln, n1 * 64);
+    else if (wv < n1 + n2) conv_fwd<T, 2, CM>(a, Wt, ce, w0, nw, out, ldo, amax, (wv - n1) * 64 + ln, n2 * 64);
+    else if (wv < n1 + n2 + n3) conv_fwd<T, 3, CM>(a, Wt, ce, w0, nw, out, ldo, amax, (wv - n1 - n2) * 64 + ln, n3 * 64);
+    else if (wv < n1 + n2 + n3 + n4) conv_fwd<T, 4, CM>(a, Wt, ce, w0, nw, out, ldo, amax, (wv - n1 - n2 - n3) * 64 + ln, n4 * 64);
+  } else {
+    conv_fwd<T, 1, CM>(a, Wt, ce, w0, nw, out, ldo, amax, threadIdx.x, blockDim.x);
+    conv_fwd<T, 2, CM>(a, Wt, ce, w0, nw, out, ldo, amax, threadIdx.x, blockDim.x);
+    conv_fwd<T, 3, CM>(a, Wt, ce, w0, nw, out, ldo, amax, threadIdx.x, blockDim.x);
+    conv_fwd<T, 4, CM>(a, Wt, ce, w0, nw, out, ldo, amax, threadIdx.x, blockDim.x);
+  }
 }
 
 // ---- backward: partial row of workgroup g = [W_1 | W_2 | W_3 | W_4 | b (OT)]  (wtot + OT floats)
@@ -190,29 +201,44 @@ __global__ __launch_bounds__(1024) void char_cnn_bwd_kernel(CharCnnArgs a, const
     for (int wl = 0; wl < nw; ++wl) s += G[wl * a.OT + o];
     prow[a.wtot + o] = s;
   }
-  // gradient of the (dropped-out) character rows -> table rows: one thread per (word, position, channel), channel
-  // fastest, so a wave shares (word, position): the arg-max / gradient reads broadcast and the branch is uniform
+  // gradient of the (dropped-out) character rows -> table rows.  Scatter form: a thread owns the (word, channel) column of
+  // an LDS image [word][position][channel] (over the character rows, which the weight-gradient phase is done with) and walks
+  // the word's output channels once -- each live one (ReLU kills about half) adds its k taps at its arg-max position.
+  // (Before: one thread per (word, position, channel) walked ALL output channels and kept the few whose window covered
+  // its position: 100 broadcast LDS reads + branches per element, 2500 LDS reads per thread -- a third of the kernel.)
+  // Same summation order per element as before ((width, channel) ascending), so the table gradient is bit-identical.
   if (dtable) {
+    __syncthreads();                                             // every wave is done with ce
+    float* dce = ce;                                             // [nw][CP][CD]
+    for (int i = threadIdx.x; i < nw * CP * a.CD; i += blockDim.x) dce[i] = 0.f;
+    __syncthreads();
+    for (int item = threadIdx.x; item < nw * a.CD; item += blockDim.x) {
+      const int wl = item / a.CD, c = item - wl * a.CD;
+      float* col = dce + (wl * CP) * a.CD + c;
+#pragma unroll
+      for (int kk = 0; kk < CC_NK; ++kk) {
+        const int k = kk + 1, oc = a.oc[kk];
+        const T* wt = Wt + a.woff[kk] + c;
+        const float* Gk = G + wl * a.OT + a.coff[kk];
+        const int* Ak = A + wl * a.OT + a.coff[kk];
+        for (int o = 0; o < oc; ++o) {
+          const float g = Gk[o];
+          if (g != 0.f) {
+            const int p = Ak[o];
+#pragma unroll
+            for (int j = 0; j < k; ++j) col[(p + j) * a.CD] += g * to_f<T>(wt[(o * k + j) * a.CD]);
+          }
+        }
+      }
+    }
+    __syncthreads();
     for (int item = threadIdx.x; item < nw * a.CD * a.C; item += blockDim.x) {
       const int wl = item / (a.CD * a.C), r = item - wl * (a.CD * a.C), q = r / a.CD, c = r - q * a.CD;
       const int64_t word = w0 + wl;
       const int64_t id = a.ids[word * a.C + q];
-      float d = 0.f;
-      if (id != 0) {                                            // padding_idx 0 receives no gradient
-#pragma unroll
-        for (int kk = 0; kk < CC_NK; ++kk) {
-          const int k = kk + 1, oc = a.oc[kk];
-          const T* wt = Wt + a.woff[kk];
-          const float* Gk = G + wl * a.OT + a.coff[kk];
-          const int* Ak = A + wl * a.OT + a.coff[kk];
-          for (int o = 0; o < oc; ++o) {
-            const float g = Gk[o];
-            const int j = q - Ak[o];
-            if (g != 0.f && j >= 0 && j < k) d += g * to_f<T>(wt[(o * k + j) * a.CD + c]);
-          }
-        }
-        if (a.drop_p > 0.f && !vmr_keep(seed, (uint64_t)(word * a.C + q) * a.CD + c, thresh)) d = 0.f;
-      }
+      float d = dce[(wl * CP + q) * a.CD + c];
+      if (id == 0) d = 0.f;                                      // padding_idx 0 receives no gradient
+      else if (a.drop_p > 0.f && !vmr_keep(seed, (uint64_t)(word * a.C + q) * a.CD + c, thresh)) d = 0.f;
       if (d != 0.f) atomicAdd(&dtable[id * a.CD + c], d * dscale);
     }
   }
