@@ -104,6 +104,11 @@ def run_ban(args, dev, rank, world):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # outside the timed region: no workgroup of a one-launch recurrence ran into its poll bound (a result computed after
+    # that is garbage: fail loudly), and the loss is a number
+    from vmrframe_amd import ban_encoders as _enc
+    assert not _enc.seq_kernel_gave_up(), "a one-launch LSTM recurrence gave up waiting for its exchange (error word raised)"
+    assert np.isfinite(float(loss.detach())), "BAN training diverged"
     if rank == 0:
         ms = dt / args.steps * 1e3
         print(json.dumps({"metric": "clips/sec (train step), BAN at T=128 (128x128 score map), anet model sizes",

@@ -113,3 +113,11 @@ class GraphedBANStep:
             self._host()
             self.gB.replay()
         return self.loss
+
+    def recurrence_ok(self) -> bool:
+        """False if a workgroup of a one-launch LSTM recurrence ever ran into its poll bound (csrc/lstm.hip raises an
+        error word instead of hanging; everything computed after that is garbage).  One device read: call it where the
+        loss is read anyway (end of an epoch, a logging step), not per step."""
+        from .ban_encoders import seq_kernel_gave_up
+        return not seq_kernel_gave_up()
+
