@@ -49,6 +49,23 @@ SEQ_KERNEL = os.environ.get("VMR_LSTM_SEQ", "1") != "0"     # one persistent lau
 _SYNC_LOG = []       # the sync words of the most recent sequence launches (tests read word 8: a workgroup gave up waiting)
 
 
+_ERR_WORDS = {}      # device -> the shared, never-reset sync words of the sentinel-exchange launches (only word 8, the error flag, is ever written)
+
+
+def _sync_words(dev, counters: bool):
+    """The 16 sync words of one sequence launch: fresh zeros when the launch counts arrivals in them; with the sentinel
+    exchange only the error word is used (written on a poll timeout, sticky), so every launch shares one buffer -- no
+    fill launch per recurrence."""
+    if counters:
+        return torch.zeros(16, device=dev, dtype=torch.int32)
+    t = _ERR_WORDS.get(dev)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():      # (a graph's private pool is no home for a process-wide buffer)
+            return torch.zeros(16, device=dev, dtype=torch.int32)
+        t = _ERR_WORDS[dev] = torch.zeros(16, device=dev, dtype=torch.int32)
+    return t
+
+
 def _note_sync(sync):
     _SYNC_LOG.append(sync)
     del _SYNC_LOG[:-64]
@@ -71,7 +88,7 @@ def _recur_fwd(gx, w_hh, lens, act, cs, hp, y, B, T, H, Z, dt, dc) -> str:
         hist = torch.empty(nbytes.value // 2, device=dev, dtype=torch.int16)
         if lib.vmr_lstm_seq_sentinel():      # the exchange reads readiness off the history itself: "not yet written" everywhere
             hist.fill_(0x7FFF)
-        sync = torch.zeros(16, device=dev, dtype=torch.int32)
+        sync = _sync_words(dev, counters=not lib.vmr_lstm_seq_sentinel())
         L.check(lib.vmr_lstm_seq_fwd(gx.data_ptr(), w_hh.data_ptr(), lens.data_ptr(), act.data_ptr(), cs.data_ptr(),
                                      hp.data_ptr(), y.data_ptr(), hist.data_ptr(), sync.data_ptr(), B, T, H, Z, dc,
                                      L.stream_ptr()), "vmr_lstm_seq_fwd")
@@ -107,7 +124,7 @@ def _recur_bwd(dy, act, cs, lens, w_hh, mode, B, T, H, Z, dt, dc) -> torch.Tenso
         if lib.vmr_lstm_seq_bwd_sentinel():      # dg is the exchange buffer and carries its own readiness
             dg.view(torch.int16).fill_(0x7FFF)
         whht = w_hh.transpose(1, 2).contiguous()                      # [Z, H, 4H]: the K-contiguous operand of dg . W_hh
-        sync = torch.zeros(16, device=dev, dtype=torch.int32)
+        sync = _sync_words(dev, counters=not lib.vmr_lstm_seq_bwd_sentinel())
         L.check(lib.vmr_lstm_seq_bwd(dy.data_ptr(), act.data_ptr(), cs.data_ptr(), lens.data_ptr(), whht.data_ptr(),
                                      dg.data_ptr(), sync.data_ptr(), B, T, H, Z, dc, L.stream_ptr()), "vmr_lstm_seq_bwd")
         _note_sync(sync)
