@@ -2013,7 +2013,9 @@ def cq_block_supported(Lc, Lq, D, dtype):
 
 
 def cq_block(ctx, qry, lng, short_op, shortterm, mask_long, mask_short, orient):
-    """cat4 [B*Lc, 4D] of CQAttention from the context / query streams and the two score operands."""
+    """cat4 [B*Lc, 4D] of CQAttention from the context / query streams and the two score operands.  orient 0: the context
+    is the long stream (Lq <= Lc), 1: the short one (Lq > Lc) -- the apply kernels derive the same from the lengths, so a
+    tie is orient 0 (SeqPAN.cq_attention_core does exactly that)."""
     return _CQBlock.apply(ctx, qry, lng, short_op, shortterm, mask_long.contiguous(), mask_short.contiguous(), orient)
 
 
