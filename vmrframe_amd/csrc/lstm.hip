@@ -292,17 +292,20 @@ __device__ __forceinline__ void seq_arrive(int* ctr) {
   if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename E, int HH>
-__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
-  constexpr int H = HH, KS = HH / 32, WPX = HH / 16, LDW = HH + 8, LDT = 68;
+// RB = batch rows per workgroup (64, 32 or 16: RB / 16 waves, 4 * RB threads); a unit slice's row groups are separate
+// workgroups, each fetching only its own rows of h (the per-CU fetch is what a step waits for, see the backward kernel)
+template <typename E, int HH, int RB>
+__global__ __launch_bounds__(4 * RB) void lstm_seq_fwd_kernel(SeqArgs a) {
+  constexpr int H = HH, KS = HH / 32, GPB = 64 / RB, WPX = (HH / 16) * GPB, LDW = HH + 8, LDT = 68, NTH = 4 * RB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   E* wS = reinterpret_cast<E*>(smem);                          // [64][LDW]: rows g * 16 + n = gate g of unit u0 + n
-  float* tile0 = reinterpret_cast<float*>(wS + 64 * LDW);      // [2][64][LDT]: pre-activations, [batch row][g * 16 + n], by step parity
+  float* tile0 = reinterpret_cast<float*>(wS + 64 * LDW);      // [2][RB][LDT]: pre-activations, [batch row][g * 16 + n], by step parity
   __shared__ int dead;
   // affinity (speed only): blocks with equal blockIdx % 8 share an XCD; direction z takes `xpd` of the 8 groups
   const int grp = blockIdx.x & 7, kk = blockIdx.x >> 3;
-  const int z = grp % a.ndir, slot = grp / a.ndir + a.xpd * kk;
-  if (grp / a.ndir >= a.xpd || slot >= WPX) return;
+  const int z = grp % a.ndir, role = grp / a.ndir + a.xpd * kk;
+  if (grp / a.ndir >= a.xpd || role >= WPX) return;
+  const int slot = role / GPB, b0 = (role % GPB) * RB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kq = lane >> 4;
   const int B = a.B, Tn = a.T, u0 = slot * 16;
   const bool sent = (a.mode & 1) != 0;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
   E* hp = reinterpret_cast<E*>(a.hp);
   E* y = reinterpret_cast<E*>(a.y);
   E* hz = reinterpret_cast<E*>(a.hist) + (int64_t)z * Tn * (H * 64);
-  for (int i = tid; i < 64 * (H / 8); i += 256) {
+  for (int i = tid; i < 64 * (H / 8); i += NTH) {
     const int row = i / (H / 8), ch = i - row * (H / 8);
     *reinterpret_cast<bf16x8*>(wS + row * LDW + ch * 8) =
         *reinterpret_cast<const bf16x8*>(whh + ((int64_t)z * 4 * H + (row >> 4) * H + u0 + (row & 15)) * H + ch * 8);
@@ -321,9 +324,9 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
   __syncthreads();
   // this thread's cells: batch row m, units j0 .. j0 + 3 (all four gates); rows past B repeat row B - 1 (never stored,
   // except into the history, whose rows other workgroups read as MFMA operand rows: they must be finite)
-  const int m = tid >> 2, q = tid & 3, j0 = u0 + 4 * q;
-  const bool real = m < B;
-  const int bc = min(m, B - 1);
+  const int m = tid >> 2, q = tid & 3, j0 = u0 + 4 * q;      // (m: row within the group, batch row b0 + m)
+  const bool real = b0 + m < B;
+  const int bc = min(b0 + m, B - 1);
   const int64_t zb = (int64_t)z * B + bc;
   const int L = a.len[bc];
   typedef __attribute__((ext_vector_type(4))) E E4;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float* tile = tile0 + (s & 1) * (64 * LDT);
+    float* tile = tile0 + (s & 1) * (RB * LDT);
     if (s > 0) {          // (h_{-1} = 0: step 0 has no recurrent part; s is uniform)
       if (!sent) seq_wait(a.sync + z, s * WPX, a.sync + 8, &dead);
       const E* hsrc = hz + (int64_t)(s - 1) * (H * 64);
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
           const int kk = k * 32 + kq * 8;
-          af[k] = ld16_sc1(hsrc + ((kk >> 4) * 64 + w * 16 + r16) * 16 + (kk & 15));
+          af[k] = ld16_sc1(hsrc + ((kk >> 4) * 64 + b0 + w * 16 + r16) * 16 + (kk & 15));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
     {
       u32x2 hb = __builtin_bit_cast(u32x2, hn);
       if (sent && (hb[0] & 0xFFFFu) == SEQ_NOT_YET) hb[0] ^= 1u;       // (a NaN with exactly the sentinel's payload: another NaN)
-      st8_sc1(hz + (int64_t)s * (H * 64) + (slot * 64 + m) * 16 + 4 * q, hb);
+      st8_sc1(hz + (int64_t)s * (H * 64) + (slot * 64 + b0 + m) * 16 + 4 * q, hb);
     }
     if (s + 1 < Tn && !sent) seq_arrive(a.sync + z);
     if (real) {
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqArgs a) {
       *reinterpret_cast<f32x4*>(a.cs + ca) = cn4;
       if (s < L) {
         const int t = (z & 1) == 0 ? s : L - 1 - s;
-        *reinterpret_cast<E4*>(y + (((int64_t)(z >> 1) * B + m) * Tn + t) * 2 * H + (z & 1) * H + j0) = hn;
+        *reinterpret_cast<E4*>(y + (((int64_t)(z >> 1) * B + b0 + m) * Tn + t) * 2 * H + (z & 1) * H + j0) = hn;
       }
     }
     hprev = hn;
@@ -740,24 +743,35 @@ extern "C" int vmr_lstm_seq_fwd(const void* gx, const void* whh, const int* len,
   a.gx = gx; a.whh = whh; a.len = len; a.act = act; a.cs = (float*)cs; a.hp = hp; a.y = y; a.hist = hist; a.sync = sync;
   a.B = B; a.T = T; a.ndir = ndir;
   a.mode = vmr_lstm_seq_sentinel();
-  const size_t lds = (size_t)64 * (H + 8) * 2 + (size_t)2 * 64 * 68 * 4;
-  // a direction's H/16 workgroups share ONE XCD group here (measured at H = 256: 340 us per layer against 388 spread
-  // over four; the backward, with four times the workgroups and payload, is the other way round: 652 against 415)
+  // batch rows per workgroup: 64 (one workgroup per unit slice) / 32 / 16 (VMR_LSTM_SEQ_FWD_ROWS; default below)
+  static int rows_env = -1;
+  if (rows_env < 0) { const char* e = getenv("VMR_LSTM_SEQ_FWD_ROWS"); rows_env = e ? atoi(e) : 32; }
+  int RB = rows_env == 16 ? 16 : (rows_env == 64 ? 64 : 32);
+  while (RB < 64 && ndir * (H / 16) * (64 / RB) > 256) RB *= 2;      // every workgroup resident at once
+  const size_t lds = (size_t)64 * (H + 8) * 2 + (size_t)2 * RB * 68 * 4;
+  const int roles = (H / 16) * (64 / RB);
+  // a direction's workgroups share ONE XCD group where they all fit (measured at H = 256, 16 workgroups: 340 us per layer
+  // against 388 spread over four; the backward, with four times the workgroups and payload, is the other way round);
+  // every workgroup must be resident: at most 32 CUs per XCD x the workgroups of this LDS size a CU holds
   static int xpd_env = -1;
   if (xpd_env < 0) { const char* e = getenv("VMR_LSTM_SEQ_XPD_FWD"); xpd_env = e ? atoi(e) : 0; }
   a.xpd = xpd_env > 0 ? xpd_env : 1;
+  const int per_cu = (int)((size_t)160 * 1024 / (lds + 1024)) < 1 ? 1 : (int)((size_t)160 * 1024 / (lds + 1024));
+  const int cap = 32 * (per_cu > 2 ? 2 : per_cu);
+  if (a.xpd < (roles + cap - 1) / cap) a.xpd = (roles + cap - 1) / cap;
   if (a.xpd * ndir > 8) a.xpd = 8 / ndir;
-  const dim3 grid(8 * ((H / 16 + a.xpd - 1) / a.xpd));
-#define VMR_LSTM_SEQ_FWD(HH)                                                                                           \
+  const dim3 grid(8 * ((roles + a.xpd - 1) / a.xpd));
+#define VMR_LSTM_SEQ_FWD(HH, RBV)                                                                                      \
   VMR_DISPATCH16(dtype, E, do {                                                                                        \
-    const void* fn = (const void*)lstm_seq_fwd_kernel<E, HH>;                                                          \
+    const void* fn = (const void*)lstm_seq_fwd_kernel<E, HH, RBV>;                                                     \
     if (lds > 64 * 1024) {                                                                                             \
       hipError_t e_ = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
       if (e_ != hipSuccess) return vmr_fail(-5, "vmr_lstm_seq_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e_));   \
     }                                                                                                                  \
-    hipLaunchKernelGGL((lstm_seq_fwd_kernel<E, HH>), grid, dim3(256), lds, (hipStream_t)stream, a);                    \
+    hipLaunchKernelGGL((lstm_seq_fwd_kernel<E, HH, RBV>), grid, dim3(4 * RBV), lds, (hipStream_t)stream, a);           \
   } while (0))
-  if (H == 256) VMR_LSTM_SEQ_FWD(256); else VMR_LSTM_SEQ_FWD(512);
+  if (H == 256) { if (RB == 64) VMR_LSTM_SEQ_FWD(256, 64); else if (RB == 32) VMR_LSTM_SEQ_FWD(256, 32); else VMR_LSTM_SEQ_FWD(256, 16); }
+  else { if (RB == 64) VMR_LSTM_SEQ_FWD(512, 64); else if (RB == 32) VMR_LSTM_SEQ_FWD(512, 32); else VMR_LSTM_SEQ_FWD(512, 16); }
 #undef VMR_LSTM_SEQ_FWD
   VMR_LAUNCH_CHECK();
   return 0;
