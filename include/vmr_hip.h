@@ -624,7 +624,8 @@ int vmr_lstm_seq_supported(int B, int H, int ndir, int dtype);
 int vmr_lstm_seq_hist_bytes(int T, int H, int ndir, int64_t* bytes);
 /* 1: vmr_lstm_seq_fwd exchanges h through `hist` itself (no arrival counter): the caller fills hist with the 16-bit
  * pattern 0x7FFF ("not yet written": a NaN no arithmetic produces) before EVERY launch; 0: counters, hist need not be
- * initialised. */
+ * initialised.  Under hipGraph capture fill with a kernel, not hipMemsetAsync (memset nodes have been seen to run out of
+ * order with their neighbours on replay). */
 int vmr_lstm_seq_sentinel(void);
 /* the same for vmr_lstm_seq_bwd and its exchange buffer dg (every row of dg is written by the launch) */
 int vmr_lstm_seq_bwd_sentinel(void);
