@@ -391,6 +391,8 @@ int vmr_splitk_reduce_cast(const float* slab, int nsplit, int64_t rows, int cols
  * (P_t = softmax over t, P_v = softmax over v; columns t >= Ls are 0) -- what the fused apply kernels read row by
  * row with scalar loads, in both orientations. */
 int vmr_cq_score_supported(int Ll, int Ls, int D, int dtype);
+/* 1 if vmr_cq_score_fwd_ws takes the shape in its row-split form (128 < Ll <= 256 included): fp32 pair + workspace only */
+int vmr_cq_score_split_supported(int Ll, int Ls, int D, int dtype);
 int vmr_cq_score_fwd(const void* lng, const void* short_op, const float* shortterm, const float* mask_long,
                      const float* mask_short, void* Srow, void* Scol, float* Pt_lm, float* Pv_lm, int B, int Ll,
                      int Ls, int D, int ldP, int orient, int dtype, void* stream);
@@ -417,8 +419,9 @@ int vmr_cq_score_fwd_ws(const void* lng, const void* short_op, const float* shor
  * vmr_cq_softmax_bwd_parts: sums the slices and applies both softmax backwards: dS_lm fp32 long-major [B, Ll, SP]
  *   and dterm[b, s] = sum_l dS (the gradient of the rank-1 term on the short stream).
  * vmr_cq_score_bwd: S2[l,s] = lng[l,:].sht[s,:] => dlng = dS.sht, dsht = dS^T.lng (the two score operands). */
+/* (one partial tile pair per channel slice: 128-channel slices, 64-channel ones when the longer stream has more than 128 rows) */
 #define VMR_CQ_APPLY_PARTS_FLOATS(B, Lc, Lq, D) \
-  ((int64_t)(B) * ((D) / 128) * 2 * (((Lc) + 15) / 16 * 16) * (((Lq) + 15) / 16 * 16))
+  ((int64_t)(B) * ((D) / (((Lc) > 128 || (Lq) > 128) ? 64 : 128)) * 2 * (((Lc) + 15) / 16 * 16) * (((Lq) + 15) / 16 * 16))
 int vmr_cq_apply_supported(int Lc, int Lq, int D, int dtype);
 int vmr_cq_apply_fwd(const void* ctx, const void* qry, const float* S_lm, const float* St_lm, void* out, int B, int Lc,
                      int Lq, int D, int dtype, void* stream);

@@ -798,7 +798,8 @@ def test_cq_score_kernel_matches_composed_path(dev, dims, orient, dt):
 
 
 @pytest.mark.parametrize("dims", [(64, 128, 20, 1024), (3, 70, 9, 256), (2, 128, 32, 512), (2, 33, 1, 256), (5, 128, 17, 768),
-                                  (2, 16, 16, 256), (3, 2, 1, 256), (2, 100, 24, 1024)])
+                                  (2, 16, 16, 256), (3, 2, 1, 256), (2, 100, 24, 1024),
+                                  (2, 256, 20, 512), (3, 200, 9, 256), (64, 256, 20, 1024), (2, 129, 32, 256)])
 @pytest.mark.parametrize("orient", [0, 1])
 @pytest.mark.parametrize("dt", DT16)
 def test_fused_cq_block_matches_torch(dev, dims, orient, dt):
@@ -844,6 +845,8 @@ def test_fused_cq_block_matches_torch(dev, dims, orient, dt):
     for a, b, name in zip(ga, gb, ("dctx", "dqry", "dlong", "dshort", "dterm")):
         _close(a, b, 4e-2, name)
     # the composed path (score kernel + three batched GEMMs + cat4) on the same inputs
+    if Ll > 128:        # (its bf16-pair score kernel stops at 128 long rows; the fp32 torch comparison above stands)
+        return
     Sp, Stp = ops.cq_score(lng, sht, term, ml, ms, orient)
     c2 = ops.bmm(Sp, qry, 0, 1); mid = ops.bmm(Stp, ctx, 1, 1); q2 = ops.bmm(Sp, mid, 0, 1)
     comp = ops.cat4(ctx.reshape(B * Lc, D), c2.reshape(B * Lc, D), q2.reshape(B * Lc, D))

@@ -22,7 +22,7 @@ MATCH_LOSS_SCRATCH = 512   # == VMR_MATCH_LOSS_SCRATCH
 
 def cq_apply_parts_floats(B: int, Lc: int, Lq: int, D: int) -> int:
     """== VMR_CQ_APPLY_PARTS_FLOATS(B, Lc, Lq, D)"""
-    return B * (D // 128) * 2 * ((Lc + 15) // 16 * 16) * ((Lq + 15) // 16 * 16)
+    return B * (D // (64 if max(Lc, Lq) > 128 else 128)) * 2 * ((Lc + 15) // 16 * 16) * ((Lq + 15) // 16 * 16)
 
 
 def ln_bwd_ws_floats(rows: int, D: int) -> int:
@@ -113,6 +113,7 @@ SIGNATURES = {
     "vmr_char_cnn_bwd": [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U, _P, _P],
     "vmr_resample_pad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     "vmr_cq_score_supported": [_I, _I, _I, _I],
+    "vmr_cq_score_split_supported": [_I, _I, _I, _I],
     "vmr_cq_score_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vmr_cq_score_ws_floats": [_I],
     "vmr_debug_set_cq_split": [_I],

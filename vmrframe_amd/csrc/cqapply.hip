@@ -507,7 +507,17 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort(ApplyArgs a) {
 //            in registers;
 //   then the shared mfma_phase (dS_ / dS_t partials) on the mid / dmid images.
 // =====================================================================================================================
-constexpr int PLD = 40;          // P image row: 32 columns + 8 (80 B: 16-byte aligned rows, 8-byte transposed reads)
+// Geometry of the MFMA kernels: the long stream has at most NL rows; a workgroup takes a DSV-channel slice so that a long image
+// is always 16 K elements: NL = 128 -> 128 channels ([128][136] images, P rows of 32 + 8), NL = 256 (BaseFast's T = 256) ->
+// 64 channels ([256][72] images, P rows of 32: 157 KB of LDS in the largest kernel).
+template <int NL> struct Geo {
+  static constexpr int DSV = NL == 256 ? 64 : 128;     // channels per workgroup
+  static constexpr int IMG = DSV + 8;                  // image row (elements): 16-byte aligned, rows on different bank groups
+  static constexpr int PLD = NL == 256 ? 32 : 40;      // P image row (elements)
+  static constexpr int CT = DSV / 16, LT = NL / 16, KSL = NL / 32;
+  static constexpr int NN = CT / 4;                    // channel tiles per wave in the K = long products
+  static constexpr int MM = LT / 4;                    // long tiles per wave in the K = short products
+};
 
 // 16 x 32 fragment (lane & 15 -> column `t * 16 + .` of the image, 8 consecutive image ROWS ks * 32 + 8 * (lane >> 4) ..) from a
 // row-major 16-bit image with `rb` bytes per row: two ds_read_b64_tr_b16 (common.h lds_read_tr: the caller waits and pins)
@@ -529,81 +539,95 @@ template <typename E> __device__ __forceinline__ void st4(bf16_t* p, const f32x4
   for (int r = 0; r < 4; ++r) o[r] = bits_from_f<E>(v[r]);
   *reinterpret_cast<b4*>(p) = o;
 }
-// ---- the two product shapes, images in LDS (long stream: 128 rows, short: 32 rows; P: [long][short cols]) ----------------
-// out[l][d] = sum_s P[l][s] X[s][d] (K = 32 short rows): wave w owns long tiles 2w, 2w + 1 and all eight channel tiles;
-// the result goes straight into the 16-bit image dst [128][IMG_LD]
-template <typename E>
-__device__ __forceinline__ void prod_long_rows(const bf16_t* Pi, const bf16_t* Xi, bf16_t* dst, int w, int lane) {
+// ---- the two product shapes, images in LDS (long stream: NL rows, short: 32 rows; P: [long][short cols]) -----------------
+// out[l][d] = sum_s P[l][s] X[s][d] (K = 32 short rows): wave w owns long tiles MM*w .. and all channel tiles; issued as the
+// transposed product X^T . P^T, so a lane holds FOUR consecutive channels of one row -- one 8-byte store per tile (four
+// 2-byte ones otherwise).  The result goes into the image dst [NL][IMG], or (GLB) to global rows of length ld, rows < n.
+template <typename E, int NL, bool GLB = false>
+__device__ __forceinline__ void prod_long_rows(const bf16_t* Pi, const bf16_t* Xi, bf16_t* dst, int w, int lane, int64_t ld = 0,
+                                               int n = 0) {
+  typedef Geo<NL> G;
   const int r16 = lane & 15, kq = lane >> 4;
-  bf16x8 fb[8];
+  bf16x8 fb[G::CT];
 #pragma unroll
-  for (int nt = 0; nt < 8; ++nt) fb[nt] = img_frag_tr(Xi, IMG_LD * 2, nt, 0, lane);
+  for (int nt = 0; nt < G::CT; ++nt) fb[nt] = img_frag_tr(Xi, G::IMG * 2, nt, 0, lane);
   lgkm_wait<0>();
 #pragma unroll
-  for (int nt = 0; nt < 8; ++nt) frag_pin(fb[nt]);
+  for (int nt = 0; nt < G::CT; ++nt) frag_pin(fb[nt]);
 #pragma unroll
-  for (int mm = 0; mm < 2; ++mm) {
-    const int mt = 2 * w + mm;
-    const bf16x8 fa = ldfrag(Pi + (mt * 16 + r16) * PLD + kq * 8);
+  for (int mm = 0; mm < G::MM; ++mm) {
+    const int mt = G::MM * w + mm, row = mt * 16 + r16;
+    const bf16x8 fa = ldfrag(Pi + row * G::PLD + kq * 8);
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) {
-      // (the transposed product X^T . P^T: a lane then holds FOUR consecutive channels of one row -- one 8-byte store per
-      //  tile instead of four 2-byte ones)
+    for (int nt = 0; nt < G::CT; ++nt) {
       const f32x4 acc = mfma16<E>(fb[nt], fa, (f32x4){0.f, 0.f, 0.f, 0.f});
-      st4<E>(dst + (mt * 16 + r16) * IMG_LD + nt * 16 + kq * 4, acc);
+      if constexpr (GLB) {
+        if (row < n) st4<E>(dst + (int64_t)row * ld + nt * 16 + kq * 4, acc);
+      } else {
+        st4<E>(dst + row * G::IMG + nt * 16 + kq * 4, acc);
+      }
     }
   }
 }
-// acc[st][nn] (+)= sum_l P[l][s] Y[l][d] (K = 128 long rows), as the transposed product Y^T . P: wave w owns channel tiles
-// 2w, 2w + 1 and both short tiles; lane (r16, kq) holds row s = st * 16 + r16, channels d = (2w + nn) * 16 + kq * 4 + r
-template <typename E>
-__device__ __forceinline__ void prod_short_rows(const bf16_t* Pi, const bf16_t* Yi, f32x4 (&acc)[2][2], int w, int lane) {
-  bf16x8 fa[2][4], fb[2][4];
+// acc[st][nn] (+)= sum_l P[l][s] Y[l][d] (K = NL long rows), as the transposed product Y^T . P: wave w owns channel tiles
+// NN*w .. and both short tiles; lane (r16, kq) holds row s = st * 16 + r16, channels d = (NN*w + nn) * 16 + kq * 4 + r
+template <typename E, int NL>
+__device__ __forceinline__ void prod_short_rows(const bf16_t* Pi, const bf16_t* Yi, f32x4 (&acc)[2][Geo<NL>::NN], int w, int lane) {
+  typedef Geo<NL> G;
+  bf16x8 fa[2][G::KSL], fb[G::NN][G::KSL];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
+  for (int ks = 0; ks < G::KSL; ++ks) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) fa[mt][ks] = img_frag_tr(Pi, PLD * 2, mt, ks, lane);
+    for (int mt = 0; mt < 2; ++mt) fa[mt][ks] = img_frag_tr(Pi, G::PLD * 2, mt, ks, lane);
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) fb[nn][ks] = img_frag_tr(Yi, IMG_LD * 2, 2 * w + nn, ks, lane);
+    for (int nn = 0; nn < G::NN; ++nn) fb[nn][ks] = img_frag_tr(Yi, G::IMG * 2, G::NN * w + nn, ks, lane);
   }
   lgkm_wait<0>();
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
+  for (int ks = 0; ks < G::KSL; ++ks) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { frag_pin(fa[i][ks]); frag_pin(fb[i][ks]); }
+    for (int i = 0; i < 2; ++i) frag_pin(fa[i][ks]);
+#pragma unroll
+    for (int i = 0; i < G::NN; ++i) frag_pin(fb[i][ks]);
   }
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
+  for (int ks = 0; ks < G::KSL; ++ks)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nn = 0; nn < 2; ++nn) acc[mt][nn] = mfma16<E>(fb[nn][ks], fa[mt][ks], acc[mt][nn]);
+      for (int nn = 0; nn < G::NN; ++nn) acc[mt][nn] = mfma16<E>(fb[nn][ks], fa[mt][ks], acc[mt][nn]);
 }
-__device__ __forceinline__ void zero22(f32x4 (&acc)[2][2]) {
+template <int NN> __device__ __forceinline__ void zero2n(f32x4 (&acc)[2][NN]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
-// a [rows <= 128][128-channel slice] global matrix -> image (rows >= n zero), 16-byte chunks; NR = image rows (32 or 128)
-template <int NR>
+// a [rows <= NR][DSV-channel slice] global matrix -> image (rows >= n zero), 16-byte chunks; NR = image rows (32 or NL)
+template <int NL, int NR>
 __device__ __forceinline__ void stage_rows(const bf16_t* src, int64_t ld, int n, bf16_t* img, int tid) {
+  typedef Geo<NL> G;
+  constexpr int CPR = G::DSV / 8;
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int j = 0; j < NR / 16; ++j) {
-    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
+  for (int j = 0; j < (NR * CPR + 255) / 256; ++j) {
+    const int i = tid + 256 * j, row = i / CPR, ch = (i % CPR) * 8;
+    if (NR * CPR % 256 != 0 && row >= NR) break;
     bf16x8 v = zero8;
     if (row < n) v = ldfrag(src + (int64_t)row * ld + ch);
-    *reinterpret_cast<bf16x8*>(img + row * IMG_LD + ch) = v;
+    *reinterpret_cast<bf16x8*>(img + row * G::IMG + ch) = v;
   }
 }
 // context rows -> Ci, X1i = dc2q = g2 + g3*C, X2i = dq2c = g4*C (rows >= n zero)
-template <typename E, int NR>
+template <typename E, int NL, int NR>
 __device__ __forceinline__ void stage_ctx(const bf16_t* Cb, const bf16_t* gb, int D, int n, bf16_t* Ci, bf16_t* X1i, bf16_t* X2i, int tid) {
+  typedef Geo<NL> G;
+  constexpr int CPR = G::DSV / 8;
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int j = 0; j < NR / 16; ++j) {
-    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
+  for (int j = 0; j < (NR * CPR + 255) / 256; ++j) {
+    const int i = tid + 256 * j, row = i / CPR, ch = (i % CPR) * 8;
+    if (NR * CPR % 256 != 0 && row >= NR) break;
     bf16x8 c8 = zero8, x1 = zero8, x2 = zero8;
     if (row < n) {
       const bf16_t* gr = gb + (int64_t)row * 4 * D + ch;
@@ -616,16 +640,17 @@ __device__ __forceinline__ void stage_ctx(const bf16_t* Cb, const bf16_t* gb, in
         x2[e] = bits_from_f<E>(frag_get<E>(g4, e) * cf);
       }
     }
-    *reinterpret_cast<bf16x8*>(Ci + row * IMG_LD + ch) = c8;
-    *reinterpret_cast<bf16x8*>(X1i + row * IMG_LD + ch) = x1;
-    *reinterpret_cast<bf16x8*>(X2i + row * IMG_LD + ch) = x2;
+    *reinterpret_cast<bf16x8*>(Ci + row * G::IMG + ch) = c8;
+    *reinterpret_cast<bf16x8*>(X1i + row * G::IMG + ch) = x1;
+    *reinterpret_cast<bf16x8*>(X2i + row * G::IMG + ch) = x2;
   }
 }
-// fp32 long-major [nl][SP] rows -> 16-bit image [128][PLD] (rows >= nl and columns >= SP zero)
-template <typename E>
+// fp32 long-major [nl][SP] rows -> 16-bit image [NL][PLD] (rows >= nl and columns >= SP zero)
+template <typename E, int NL>
 __device__ __forceinline__ void stage_probs(const float* A, int nl, int SP, bf16_t* Pi, int tid) {
+  typedef Geo<NL> G;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NL * 4 / 256; ++j) {
     const int i = tid + 256 * j, row = i >> 2, cg = (i & 3) * 8;
     bf16x8 p = {0, 0, 0, 0, 0, 0, 0, 0};
     if (row < nl && cg < SP) {
@@ -633,40 +658,43 @@ __device__ __forceinline__ void stage_probs(const float* A, int nl, int SP, bf16
 #pragma unroll
       for (int e = 0; e < 4; ++e) { p[e] = bits_from_f<E>(u0[e]); p[4 + e] = bits_from_f<E>(u1[e]); }
     }
-    *reinterpret_cast<bf16x8*>(Pi + row * PLD + cg) = p;
+    *reinterpret_cast<bf16x8*>(Pi + row * G::PLD + cg) = p;
   }
 }
-// short-side accumulators -> a [32][IMG_LD] image / a global [n][D] matrix (2-byte stores: 32 rows only)
-template <typename E>
-__device__ __forceinline__ void put_short_img(const f32x4 (&acc)[2][2], bf16_t* img, int w, int lane) {
+// short-side accumulators -> a [32][IMG] image / a global [n][D] matrix (8-byte stores)
+template <typename E, int NL>
+__device__ __forceinline__ void put_short_img(const f32x4 (&acc)[2][Geo<NL>::NN], bf16_t* img, int w, int lane) {
+  typedef Geo<NL> G;
   const int r16 = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) st4<E>(img + (mt * 16 + r16) * IMG_LD + (2 * w + nn) * 16 + kq * 4, acc[mt][nn]);
+    for (int nn = 0; nn < G::NN; ++nn) st4<E>(img + (mt * 16 + r16) * G::IMG + (G::NN * w + nn) * 16 + kq * 4, acc[mt][nn]);
 }
-template <typename E>
-__device__ __forceinline__ void put_short_global(const f32x4 (&acc)[2][2], bf16_t* dst, int64_t ld, int n, int w, int lane) {
+template <typename E, int NL>
+__device__ __forceinline__ void put_short_global(const f32x4 (&acc)[2][Geo<NL>::NN], bf16_t* dst, int64_t ld, int n, int w, int lane) {
+  typedef Geo<NL> G;
   const int r16 = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
+    for (int nn = 0; nn < G::NN; ++nn) {
       const int srow = mt * 16 + r16;
-      if (srow < n) st4<E>(dst + (int64_t)srow * ld + (2 * w + nn) * 16 + kq * 4, acc[mt][nn]);
+      if (srow < n) st4<E>(dst + (int64_t)srow * ld + (G::NN * w + nn) * 16 + kq * 4, acc[mt][nn]);
     }
 }
 
 // mfma_phase with the context side (C, dc2q, dq2c) read from the LDS images the MFMA kernels hold anyway (k = channels is the
 // contiguous index of every image row: plain 16-byte fragment reads, no global re-read, no conversions); the query rows
 // from the image Qi when it is still alive (QIMG), else from global.
-template <typename E, bool QIMG>
+template <typename E, int NL, bool QIMG>
 __device__ __forceinline__ void mfma_phase_img(const ApplyArgs& a, int b, int slice, const bf16_t* Qi, const bf16_t* midI,
                                                const bf16_t* dmidI, const bf16_t* Ci, const bf16_t* X1i, const bf16_t* X2i,
                                                int lane, int w) {
+  typedef Geo<NL> G;
   const int D = a.D, mt_n = a.LqP / 16, nt_n = a.LcP / 16;
   const int kq = (lane >> 4) * 8;
-  const bf16_t* Qb = a.Q + (int64_t)b * a.Lq * D + slice * DS;
+  const bf16_t* Qb = a.Q + (int64_t)b * a.Lq * D + slice * G::DSV;
   float* pb = a.parts + ((int64_t)b * gridDim.x + slice) * 2 * a.LcP * a.LqP;
   for (int t = w; t < mt_n * nt_n; t += 4) {
     const int mt = t % mt_n, nt = t / mt_n;
@@ -674,14 +702,14 @@ __device__ __forceinline__ void mfma_phase_img(const ApplyArgs& a, int b, int sl
     const int qg = min(qrow, a.Lq - 1);
     f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < DS / 32; ++ks) {
+    for (int ks = 0; ks < G::DSV / 32; ++ks) {
       const int k = ks * 32 + kq;
-      const bf16x8 fq = QIMG ? ldfrag(Qi + qrow * IMG_LD + k) : ldfrag(Qb + (int64_t)qg * D + k);
-      const bf16x8 fm = ldfrag(midI + qrow * IMG_LD + k);
-      const bf16x8 fd = ldfrag(dmidI + qrow * IMG_LD + k);
-      acc1 = mfma16<E>(fq, ldfrag(X1i + crow * IMG_LD + k), acc1);
-      acc1 = mfma16<E>(fm, ldfrag(X2i + crow * IMG_LD + k), acc1);
-      acc2 = mfma16<E>(fd, ldfrag(Ci + crow * IMG_LD + k), acc2);
+      const bf16x8 fq = QIMG ? ldfrag(Qi + qrow * G::IMG + k) : ldfrag(Qb + (int64_t)qg * D + k);
+      const bf16x8 fm = ldfrag(midI + qrow * G::IMG + k);
+      const bf16x8 fd = ldfrag(dmidI + qrow * G::IMG + k);
+      acc1 = mfma16<E>(fq, ldfrag(X1i + crow * G::IMG + k), acc1);
+      acc1 = mfma16<E>(fm, ldfrag(X2i + crow * G::IMG + k), acc1);
+      acc2 = mfma16<E>(fd, ldfrag(Ci + crow * G::IMG + k), acc2);
     }
     const int q0 = mt * 16 + (lane >> 4) * 4;
     float* p1 = pb + (int64_t)crow * a.LqP + q0;
@@ -690,54 +718,48 @@ __device__ __forceinline__ void mfma_phase_img(const ApplyArgs& a, int b, int sl
   }
 }
 
-template <typename E>
+// backward, context = SHORT stream (Lq <= NL, Lc <= 32)
+template <typename E, int NL>
 __global__ __launch_bounds__(256) void cq_apply_bwd_cshort_mfma(ApplyArgs a) {
+  typedef Geo<NL> G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Qi = reinterpret_cast<bf16_t*>(smem);          // [128][IMG_LD]; dmid after c2q is done
-  bf16_t* midI = Qi + 128 * IMG_LD;
-  bf16_t* dQs = midI + 128 * IMG_LD;
-  bf16_t* Ci = dQs + 128 * IMG_LD;                       // [32][IMG_LD]
-  bf16_t* X1i = Ci + 32 * IMG_LD;
-  bf16_t* X2i = X1i + 32 * IMG_LD;
-  bf16_t* P1i = X2i + 32 * IMG_LD;                       // [128][PLD]
-  bf16_t* P2i = P1i + 128 * PLD;
+  bf16_t* Qi = reinterpret_cast<bf16_t*>(smem);          // [NL][IMG]; dmid after c2q is done
+  bf16_t* midI = Qi + NL * G::IMG;
+  bf16_t* Ci = midI + NL * G::IMG;                       // [32][IMG]
+  bf16_t* X1i = Ci + 32 * G::IMG;
+  bf16_t* X2i = X1i + 32 * G::IMG;
+  bf16_t* P1i = X2i + 32 * G::IMG;                       // [NL][PLD]
+  bf16_t* P2i = P1i + NL * G::PLD;
   const int tid = threadIdx.x, lane = tid & 63, w = WAVE_ID();
   const int r16 = lane & 15, kq = lane >> 4;
   const int b = blockIdx.y, slice = blockIdx.x, D = a.D, Lc = a.Lc, Lq = a.Lq;
-  const bf16_t* Cb = a.C + (int64_t)b * Lc * D + slice * DS;
-  const bf16_t* Qb = a.Q + (int64_t)b * Lq * D + slice * DS;
-  const bf16_t* gb = a.g + (int64_t)b * Lc * 4 * D + slice * DS;
+  const bf16_t* Cb = a.C + (int64_t)b * Lc * D + slice * G::DSV;
+  const bf16_t* Qb = a.Q + (int64_t)b * Lq * D + slice * G::DSV;
+  const bf16_t* gb = a.g + (int64_t)b * Lc * 4 * D + slice * G::DSV;
   const int SP = (Lc + 7) / 8 * 8;                       // the probability rows' length (cqscore.hip: columns >= Lc are exactly 0)
-  stage_rows<128>(Qb, D, Lq, Qi, tid);
-  stage_ctx<E, 32>(Cb, gb, D, Lc, Ci, X1i, X2i, tid);
-  stage_probs<E>(a.A1 + (int64_t)b * Lq * SP, Lq, SP, P1i, tid);
-  stage_probs<E>(a.A2 + (int64_t)b * Lq * SP, Lq, SP, P2i, tid);
+  stage_rows<NL, NL>(Qb, D, Lq, Qi, tid);
+  stage_ctx<E, NL, 32>(Cb, gb, D, Lc, Ci, X1i, X2i, tid);
+  stage_probs<E, NL>(a.A1 + (int64_t)b * Lq * SP, Lq, SP, P1i, tid);
+  stage_probs<E, NL>(a.A2 + (int64_t)b * Lq * SP, Lq, SP, P2i, tid);
   __syncthreads();
-  prod_long_rows<E>(P2i, Ci, midI, w, lane);             // mid[q] = sum_c S_t[c,q] C[c]
-  prod_long_rows<E>(P1i, X1i, dQs, w, lane);             // dQ[q]  = sum_c S_[c,q] dc2q[c]
+  prod_long_rows<E, NL>(P2i, Ci, midI, w, lane);                                                     // mid[q] = sum_c S_t[c,q] C[c]
+  prod_long_rows<E, NL, true>(P1i, X1i, a.dQ + (int64_t)b * Lq * D + slice * G::DSV, w, lane, D, Lq);  // dQ[q] = sum_c S_[c,q] dc2q[c]
   __syncthreads();
-  f32x4 c2q[2][2], q2c[2][2], dcm[2][2];
-  zero22(c2q); zero22(q2c); zero22(dcm);
-  prod_short_rows<E>(P1i, Qi, c2q, w, lane);
-  prod_short_rows<E>(P1i, midI, q2c, w, lane);
-  // the staged dQ rows leave with 16-byte stores
-  bf16_t* dQb = a.dQ + (int64_t)b * Lq * D + slice * DS;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
-    if (row < Lq) *reinterpret_cast<bf16x8*>(dQb + (int64_t)row * D + ch) = *reinterpret_cast<const bf16x8*>(dQs + row * IMG_LD + ch);
-  }
+  f32x4 c2q[2][G::NN], q2c[2][G::NN], dcm[2][G::NN];
+  zero2n(c2q); zero2n(q2c); zero2n(dcm);
+  prod_short_rows<E, NL>(P1i, Qi, c2q, w, lane);
+  prod_short_rows<E, NL>(P1i, midI, q2c, w, lane);
   __syncthreads();                                       // every wave is done with Qi
   bf16_t* dmidI = Qi;
-  prod_long_rows<E>(P1i, X2i, dmidI, w, lane);           // dmid[q] = sum_c S_[c,q] dq2c[c]
+  prod_long_rows<E, NL>(P1i, X2i, dmidI, w, lane);       // dmid[q] = sum_c S_[c,q] dq2c[c]
   __syncthreads();
-  prod_short_rows<E>(P2i, dmidI, dcm, w, lane);          // dC through mid: sum_q S_t[c,q] dmid[q]
-  bf16_t* dCb = a.dC + (int64_t)b * Lc * D + slice * DS;
+  prod_short_rows<E, NL>(P2i, dmidI, dcm, w, lane);      // dC through mid: sum_q S_t[c,q] dmid[q]
+  bf16_t* dCb = a.dC + (int64_t)b * Lc * D + slice * G::DSV;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
-      const int c = mt * 16 + r16, d = (2 * w + nn) * 16 + kq * 4;       // this lane: row c, four channels from d
+    for (int nn = 0; nn < G::NN; ++nn) {
+      const int c = mt * 16 + r16, d = (G::NN * w + nn) * 16 + kq * 4;       // this lane: row c, four channels from d
       if (c < Lc) {
         typedef __attribute__((ext_vector_type(4))) bf16_t b4;
         const bf16_t* gr = gb + (int64_t)c * 4 * D + d;
@@ -749,18 +771,20 @@ __global__ __launch_bounds__(256) void cq_apply_bwd_cshort_mfma(ApplyArgs a) {
         st4<E>(dCb + (int64_t)c * D + d, o);
       }
     }
-  mfma_phase_img<E, false>(a, b, slice, nullptr, midI, dmidI, Ci, X1i, X2i, lane, w);
+  mfma_phase_img<E, NL, false>(a, b, slice, nullptr, midI, dmidI, Ci, X1i, X2i, lane, w);
 }
 
 // the 4-way concat of NR context rows from the images Ci (context), Xi (c2q), Yi (q2c): [C | c2q | C*c2q | C*q2c], 16-byte stores
-template <typename E, int NR>
+template <typename E, int NL, int NR>
 __device__ __forceinline__ void put_cat4(const bf16_t* Ci, const bf16_t* Xi, const bf16_t* Yi, bf16_t* ob, int D, int n, int tid) {
+  typedef Geo<NL> G;
+  constexpr int CPR = G::DSV / 8;
 #pragma unroll
-  for (int j = 0; j < NR / 16; ++j) {
-    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
-    if (row < n) {
-      const bf16x8 c8 = *reinterpret_cast<const bf16x8*>(Ci + row * IMG_LD + ch), x = *reinterpret_cast<const bf16x8*>(Xi + row * IMG_LD + ch);
-      const bf16x8 y = *reinterpret_cast<const bf16x8*>(Yi + row * IMG_LD + ch);
+  for (int j = 0; j < (NR * CPR + 255) / 256; ++j) {
+    const int i = tid + 256 * j, row = i / CPR, ch = (i % CPR) * 8;
+    if (row < n && row < NR) {
+      const bf16x8 c8 = *reinterpret_cast<const bf16x8*>(Ci + row * G::IMG + ch), x = *reinterpret_cast<const bf16x8*>(Xi + row * G::IMG + ch);
+      const bf16x8 y = *reinterpret_cast<const bf16x8*>(Yi + row * G::IMG + ch);
       bf16x8 cx, cy;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -777,119 +801,124 @@ __device__ __forceinline__ void put_cat4(const bf16_t* Ci, const bf16_t* Xi, con
   }
 }
 
-// forward on MFMA, context = SHORT stream (Lq <= 128, Lc <= 32): mid = P2.C (K = 32), c2q = P1^T.Q, q2c = P1^T.mid (K = 128)
-template <typename E>
+// forward on MFMA, context = SHORT stream (Lq <= NL, Lc <= 32): mid = P2.C (K = 32), c2q = P1^T.Q, q2c = P1^T.mid (K = NL)
+template <typename E, int NL>
 __global__ __launch_bounds__(256) void cq_apply_fwd_cshort_mfma(ApplyArgs a) {
+  typedef Geo<NL> G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Qi = reinterpret_cast<bf16_t*>(smem);          // [128][IMG_LD]
-  bf16_t* midI = Qi + 128 * IMG_LD;                      // [128][IMG_LD]
-  bf16_t* Ci = midI + 128 * IMG_LD;                      // [32][IMG_LD]
-  bf16_t* Xi = Ci + 32 * IMG_LD;
-  bf16_t* Yi = Xi + 32 * IMG_LD;
-  bf16_t* P1i = Yi + 32 * IMG_LD;                        // [128][PLD]
-  bf16_t* P2i = P1i + 128 * PLD;
+  bf16_t* Qi = reinterpret_cast<bf16_t*>(smem);          // [NL][IMG]
+  bf16_t* midI = Qi + NL * G::IMG;                       // [NL][IMG]
+  bf16_t* Ci = midI + NL * G::IMG;                       // [32][IMG]
+  bf16_t* Xi = Ci + 32 * G::IMG;
+  bf16_t* Yi = Xi + 32 * G::IMG;
+  bf16_t* P1i = Yi + 32 * G::IMG;                        // [NL][PLD]
+  bf16_t* P2i = P1i + NL * G::PLD;
   const int tid = threadIdx.x, lane = tid & 63, w = WAVE_ID();
   const int b = blockIdx.y, slice = blockIdx.x, D = a.D, Lc = a.Lc, Lq = a.Lq;
   const int SP = (Lc + 7) / 8 * 8;
-  stage_rows<128>(a.Q + (int64_t)b * Lq * D + slice * DS, D, Lq, Qi, tid);
-  stage_rows<32>(a.C + (int64_t)b * Lc * D + slice * DS, D, Lc, Ci, tid);
-  stage_probs<E>(a.A1 + (int64_t)b * Lq * SP, Lq, SP, P1i, tid);
-  stage_probs<E>(a.A2 + (int64_t)b * Lq * SP, Lq, SP, P2i, tid);
+  stage_rows<NL, NL>(a.Q + (int64_t)b * Lq * D + slice * G::DSV, D, Lq, Qi, tid);
+  stage_rows<NL, 32>(a.C + (int64_t)b * Lc * D + slice * G::DSV, D, Lc, Ci, tid);
+  stage_probs<E, NL>(a.A1 + (int64_t)b * Lq * SP, Lq, SP, P1i, tid);
+  stage_probs<E, NL>(a.A2 + (int64_t)b * Lq * SP, Lq, SP, P2i, tid);
   __syncthreads();
-  prod_long_rows<E>(P2i, Ci, midI, w, lane);
-  f32x4 c2q[2][2], q2c[2][2];
-  zero22(c2q); zero22(q2c);
-  prod_short_rows<E>(P1i, Qi, c2q, w, lane);
-  put_short_img<E>(c2q, Xi, w, lane);
+  prod_long_rows<E, NL>(P2i, Ci, midI, w, lane);
+  f32x4 c2q[2][G::NN], q2c[2][G::NN];
+  zero2n(c2q); zero2n(q2c);
+  prod_short_rows<E, NL>(P1i, Qi, c2q, w, lane);
+  put_short_img<E, NL>(c2q, Xi, w, lane);
   __syncthreads();
-  prod_short_rows<E>(P1i, midI, q2c, w, lane);
-  put_short_img<E>(q2c, Yi, w, lane);
+  prod_short_rows<E, NL>(P1i, midI, q2c, w, lane);
+  put_short_img<E, NL>(q2c, Yi, w, lane);
   __syncthreads();
-  put_cat4<E, 32>(Ci, Xi, Yi, a.out + (int64_t)b * Lc * 4 * D + slice * DS, D, Lc, tid);
+  put_cat4<E, NL, 32>(Ci, Xi, Yi, a.out + (int64_t)b * Lc * 4 * D + slice * G::DSV, D, Lc, tid);
 }
 
-// forward on MFMA, context = LONG stream (Lc <= 128, Lq <= 32): c2q = P1.Q, mid = P2^T.C, q2c = P1.mid
-template <typename E>
+// forward on MFMA, context = LONG stream (Lc <= NL, Lq <= 32): c2q = P1.Q, mid = P2^T.C, q2c = P1.mid
+template <typename E, int NL>
 __global__ __launch_bounds__(256) void cq_apply_fwd_clong_mfma(ApplyArgs a) {
+  typedef Geo<NL> G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Ci = reinterpret_cast<bf16_t*>(smem);          // [128][IMG_LD]
-  bf16_t* Xi = Ci + 128 * IMG_LD;
-  bf16_t* Yi = Xi + 128 * IMG_LD;
-  bf16_t* Qi = Yi + 128 * IMG_LD;                        // [32][IMG_LD]
-  bf16_t* midI = Qi + 32 * IMG_LD;
-  bf16_t* P1i = midI + 32 * IMG_LD;                      // [128][PLD]
-  bf16_t* P2i = P1i + 128 * PLD;
+  bf16_t* Ci = reinterpret_cast<bf16_t*>(smem);          // [NL][IMG]
+  bf16_t* Xi = Ci + NL * G::IMG;
+  bf16_t* Yi = Xi + NL * G::IMG;
+  bf16_t* Qi = Yi + NL * G::IMG;                         // [32][IMG]
+  bf16_t* midI = Qi + 32 * G::IMG;
+  bf16_t* P1i = midI + 32 * G::IMG;                      // [NL][PLD]
+  bf16_t* P2i = P1i + NL * G::PLD;
   const int tid = threadIdx.x, lane = tid & 63, w = WAVE_ID();
   const int b = blockIdx.y, slice = blockIdx.x, D = a.D, Lc = a.Lc, Lq = a.Lq;
   const int SP = (Lq + 7) / 8 * 8;
-  stage_rows<128>(a.C + (int64_t)b * Lc * D + slice * DS, D, Lc, Ci, tid);
-  stage_rows<32>(a.Q + (int64_t)b * Lq * D + slice * DS, D, Lq, Qi, tid);
-  stage_probs<E>(a.A1 + (int64_t)b * Lc * SP, Lc, SP, P1i, tid);
-  stage_probs<E>(a.A2 + (int64_t)b * Lc * SP, Lc, SP, P2i, tid);
+  stage_rows<NL, NL>(a.C + (int64_t)b * Lc * D + slice * G::DSV, D, Lc, Ci, tid);
+  stage_rows<NL, 32>(a.Q + (int64_t)b * Lq * D + slice * G::DSV, D, Lq, Qi, tid);
+  stage_probs<E, NL>(a.A1 + (int64_t)b * Lc * SP, Lc, SP, P1i, tid);
+  stage_probs<E, NL>(a.A2 + (int64_t)b * Lc * SP, Lc, SP, P2i, tid);
   __syncthreads();
-  f32x4 mid[2][2];
-  zero22(mid);
-  prod_short_rows<E>(P2i, Ci, mid, w, lane);
-  put_short_img<E>(mid, midI, w, lane);
-  prod_long_rows<E>(P1i, Qi, Xi, w, lane);
+  f32x4 mid[2][G::NN];
+  zero2n(mid);
+  prod_short_rows<E, NL>(P2i, Ci, mid, w, lane);
+  put_short_img<E, NL>(mid, midI, w, lane);
+  prod_long_rows<E, NL>(P1i, Qi, Xi, w, lane);
   __syncthreads();
-  prod_long_rows<E>(P1i, midI, Yi, w, lane);
+  prod_long_rows<E, NL>(P1i, midI, Yi, w, lane);
   __syncthreads();
-  put_cat4<E, 128>(Ci, Xi, Yi, a.out + (int64_t)b * Lc * 4 * D + slice * DS, D, Lc, tid);
+  put_cat4<E, NL, NL>(Ci, Xi, Yi, a.out + (int64_t)b * Lc * 4 * D + slice * G::DSV, D, Lc, tid);
 }
 
-// backward, context = LONG stream (Lc <= 128, Lq <= 32), same two product shapes wired the other way round:
-//   mid = S_t^T.C, dQ = S_^T.dc2q, dmid = S_^T.dq2c   (K = the 128 context rows)   -> 32-row images / global dQ
-//   c2q = S_.Q, q2c = S_.mid, dCm = S_t.dmid            (K = the 32 query rows)      -> three 128-row images over the dead
+// backward, context = LONG stream (Lc <= NL, Lq <= 32), same two product shapes wired the other way round:
+//   mid = S_t^T.C, dQ = S_^T.dc2q, dmid = S_^T.dq2c   (K = the context rows)       -> 32-row images / global dQ
+//   the dS_ / dS_t partial tiles from the images (mfma_phase_img), while Ci / X1i / X2i are still alive
+//   c2q = S_.Q, q2c = S_.mid, dCm = S_t.dmid            (K = the 32 query rows)      -> three long images over the dead
 //   Ci / X1i / X2i regions; a cooperative epilogue then forms dC = g1 + g3*c2q + g4*q2c + dCm with 16-byte accesses.
-template <typename E>
+template <typename E, int NL>
 __global__ __launch_bounds__(256) void cq_apply_bwd_clong_mfma(ApplyArgs a) {
+  typedef Geo<NL> G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Ci = reinterpret_cast<bf16_t*>(smem);          // [128][IMG_LD]; dCm after mid is done
-  bf16_t* X1i = Ci + 128 * IMG_LD;                       // ... c2q
-  bf16_t* X2i = X1i + 128 * IMG_LD;                      // ... q2c
-  bf16_t* Qi = X2i + 128 * IMG_LD;                       // [32][IMG_LD]
-  bf16_t* midI = Qi + 32 * IMG_LD;
-  bf16_t* dmidI = midI + 32 * IMG_LD;
-  bf16_t* P1i = dmidI + 32 * IMG_LD;                     // [128][PLD]: rows = context, columns = query
-  bf16_t* P2i = P1i + 128 * PLD;
+  bf16_t* Ci = reinterpret_cast<bf16_t*>(smem);          // [NL][IMG]; dCm after mid is done
+  bf16_t* X1i = Ci + NL * G::IMG;                        // ... c2q
+  bf16_t* X2i = X1i + NL * G::IMG;                       // ... q2c
+  bf16_t* Qi = X2i + NL * G::IMG;                        // [32][IMG]
+  bf16_t* midI = Qi + 32 * G::IMG;
+  bf16_t* dmidI = midI + 32 * G::IMG;
+  bf16_t* P1i = dmidI + 32 * G::IMG;                     // [NL][PLD]: rows = context, columns = query
+  bf16_t* P2i = P1i + NL * G::PLD;
   const int tid = threadIdx.x, lane = tid & 63, w = WAVE_ID();
   const int b = blockIdx.y, slice = blockIdx.x, D = a.D, Lc = a.Lc, Lq = a.Lq;
-  const bf16_t* Cb = a.C + (int64_t)b * Lc * D + slice * DS;
-  const bf16_t* Qb = a.Q + (int64_t)b * Lq * D + slice * DS;
-  const bf16_t* gb = a.g + (int64_t)b * Lc * 4 * D + slice * DS;
+  const bf16_t* Cb = a.C + (int64_t)b * Lc * D + slice * G::DSV;
+  const bf16_t* Qb = a.Q + (int64_t)b * Lq * D + slice * G::DSV;
+  const bf16_t* gb = a.g + (int64_t)b * Lc * 4 * D + slice * G::DSV;
   const int SP = (Lq + 7) / 8 * 8;
-  stage_ctx<E, 128>(Cb, gb, D, Lc, Ci, X1i, X2i, tid);
-  stage_rows<32>(Qb, D, Lq, Qi, tid);
-  stage_probs<E>(a.A1 + (int64_t)b * Lc * SP, Lc, SP, P1i, tid);
-  stage_probs<E>(a.A2 + (int64_t)b * Lc * SP, Lc, SP, P2i, tid);
+  stage_ctx<E, NL, NL>(Cb, gb, D, Lc, Ci, X1i, X2i, tid);
+  stage_rows<NL, 32>(Qb, D, Lq, Qi, tid);
+  stage_probs<E, NL>(a.A1 + (int64_t)b * Lc * SP, Lc, SP, P1i, tid);
+  stage_probs<E, NL>(a.A2 + (int64_t)b * Lc * SP, Lc, SP, P2i, tid);
   __syncthreads();
   {
-    f32x4 mid[2][2], dq[2][2], dmid[2][2];
-    zero22(mid); zero22(dq); zero22(dmid);
-    prod_short_rows<E>(P2i, Ci, mid, w, lane);
-    prod_short_rows<E>(P1i, X1i, dq, w, lane);
-    prod_short_rows<E>(P1i, X2i, dmid, w, lane);
-    put_short_img<E>(mid, midI, w, lane);
-    put_short_img<E>(dmid, dmidI, w, lane);
-    put_short_global<E>(dq, a.dQ + (int64_t)b * Lq * D + slice * DS, D, Lq, w, lane);
+    f32x4 mid[2][G::NN], dq[2][G::NN], dmid[2][G::NN];
+    zero2n(mid); zero2n(dq); zero2n(dmid);
+    prod_short_rows<E, NL>(P2i, Ci, mid, w, lane);
+    prod_short_rows<E, NL>(P1i, X1i, dq, w, lane);
+    prod_short_rows<E, NL>(P1i, X2i, dmid, w, lane);
+    put_short_img<E, NL>(mid, midI, w, lane);
+    put_short_img<E, NL>(dmid, dmidI, w, lane);
+    put_short_global<E, NL>(dq, a.dQ + (int64_t)b * Lq * D + slice * G::DSV, D, Lq, w, lane);
   }
   __syncthreads();                                       // mid / dmid complete
-  mfma_phase_img<E, true>(a, b, slice, Qi, midI, dmidI, Ci, X1i, X2i, lane, w);     // dS_ / dS_t partials, all operands in LDS
+  mfma_phase_img<E, NL, true>(a, b, slice, Qi, midI, dmidI, Ci, X1i, X2i, lane, w);     // dS_ / dS_t partials, all operands in LDS
   __syncthreads();                                       // Ci, X1i, X2i free
-  prod_long_rows<E>(P1i, Qi, X1i, w, lane);              // c2q
-  prod_long_rows<E>(P1i, midI, X2i, w, lane);            // q2c
-  prod_long_rows<E>(P2i, dmidI, Ci, w, lane);            // dC through mid
+  prod_long_rows<E, NL>(P1i, Qi, X1i, w, lane);          // c2q
+  prod_long_rows<E, NL>(P1i, midI, X2i, w, lane);        // q2c
+  prod_long_rows<E, NL>(P2i, dmidI, Ci, w, lane);        // dC through mid
   __syncthreads();
-  bf16_t* dCb = a.dC + (int64_t)b * Lc * D + slice * DS;
+  bf16_t* dCb = a.dC + (int64_t)b * Lc * D + slice * G::DSV;
+  constexpr int CPR = G::DSV / 8;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
+  for (int j = 0; j < NL * CPR / 256; ++j) {
+    const int i = tid + 256 * j, row = i / CPR, ch = (i % CPR) * 8;
     if (row < Lc) {
       const bf16_t* gr = gb + (int64_t)row * 4 * D + ch;
       const bf16x8 g1 = ldfrag(gr), g3 = ldfrag(gr + 2 * D), g4 = ldfrag(gr + 3 * D);
-      const bf16x8 x = *reinterpret_cast<const bf16x8*>(X1i + row * IMG_LD + ch), y = *reinterpret_cast<const bf16x8*>(X2i + row * IMG_LD + ch);
-      const bf16x8 z = *reinterpret_cast<const bf16x8*>(Ci + row * IMG_LD + ch);
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(X1i + row * G::IMG + ch), y = *reinterpret_cast<const bf16x8*>(X2i + row * G::IMG + ch);
+      const bf16x8 z = *reinterpret_cast<const bf16x8*>(Ci + row * G::IMG + ch);
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -1055,35 +1084,38 @@ __global__ __launch_bounds__(256) void cq_score_bwd_kernel(ScoreBwdArgs a) {
 // The same on MFMA (bf16, Ll <= 128, Ls <= 32): dS rounded to the element type as a [long][short] image,
 //   d(long)  = dS . short      (K = 32)  -> staged image, 16-byte stores
 //   d(short) = dS^T . long     (K = 128) -> registers, 2-byte stores (32 rows)
-template <typename E>
+template <typename E, int NL>
 __global__ __launch_bounds__(256) void cq_score_bwd_mfma(ScoreBwdArgs a) {
+  typedef Geo<NL> G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Li = reinterpret_cast<bf16_t*>(smem);          // [128][IMG_LD]
-  bf16_t* dLs = Li + 128 * IMG_LD;                       // [128][IMG_LD]
-  bf16_t* Si = dLs + 128 * IMG_LD;                       // [32][IMG_LD]
-  bf16_t* Pi = Si + 32 * IMG_LD;                         // [128][PLD]
+  bf16_t* Li = reinterpret_cast<bf16_t*>(smem);          // [NL][IMG]
+  bf16_t* Si = Li + NL * G::IMG;                         // [32][IMG]
+  bf16_t* Pi = Si + 32 * G::IMG;                         // [NL][PLD]
   const int tid = threadIdx.x, lane = tid & 63, w = WAVE_ID();
   const int b = blockIdx.y, slice = blockIdx.x, D = a.D, Ll = a.Ll, Ls = a.Ls;
   const int SP = (Ls + 7) / 8 * 8;
-  stage_rows<128>(a.lng + (int64_t)b * Ll * D + slice * DS, D, Ll, Li, tid);
-  stage_rows<32>(a.sht + (int64_t)b * Ls * D + slice * DS, D, Ls, Si, tid);
-  stage_probs<E>(a.dS + (int64_t)b * Ll * SP, Ll, SP, Pi, tid);
+  stage_rows<NL, NL>(a.lng + (int64_t)b * Ll * D + slice * G::DSV, D, Ll, Li, tid);
+  stage_rows<NL, 32>(a.sht + (int64_t)b * Ls * D + slice * G::DSV, D, Ls, Si, tid);
+  stage_probs<E, NL>(a.dS + (int64_t)b * Ll * SP, Ll, SP, Pi, tid);
   __syncthreads();
-  prod_long_rows<E>(Pi, Si, dLs, w, lane);
-  f32x4 ds[2][2];
-  zero22(ds);
-  prod_short_rows<E>(Pi, Li, ds, w, lane);
-  put_short_global<E>(ds, a.dsht + (int64_t)b * Ls * D + slice * DS, D, Ls, w, lane);
-  __syncthreads();
-  bf16_t* dLb = a.dlng + (int64_t)b * Ll * D + slice * DS;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int i = tid + 256 * j, row = i >> 4, ch = (i & 15) * 8;
-    if (row < Ll) *reinterpret_cast<bf16x8*>(dLb + (int64_t)row * D + ch) = *reinterpret_cast<const bf16x8*>(dLs + row * IMG_LD + ch);
-  }
+  prod_long_rows<E, NL, true>(Pi, Si, a.dlng + (int64_t)b * Ll * D + slice * G::DSV, w, lane, D, Ll);
+  f32x4 ds[2][G::NN];
+  zero2n(ds);
+  prod_short_rows<E, NL>(Pi, Li, ds, w, lane);
+  put_short_global<E, NL>(ds, a.dsht + (int64_t)b * Ls * D + slice * G::DSV, D, Ls, w, lane);
 }
 
 inline int sp_of(int n) { return n <= 8 ? 8 : (n <= 16 ? 16 : (n <= 24 ? 24 : 32)); }
+
+// host side of Geo<NL>: the MFMA kernels' long-image rows for a (context, query) length pair, 0 = not theirs
+inline int cq_mfma_nl(int Lc, int Lq) {
+  const int lo = Lc < Lq ? Lc : Lq, hi = Lc < Lq ? Lq : Lc;
+  if (lo > 32 || hi > 256) return 0;
+  return hi > 128 ? 256 : 128;
+}
+template <int NL> constexpr size_t cq_img_bytes(int nlong, int nshort) {      // nlong long images + nshort 32-row images + two P images
+  return (size_t)(nlong * NL + nshort * 32) * Geo<NL>::IMG * 2 + (size_t)2 * NL * Geo<NL>::PLD * 2;
+}
 
 int cq_mfma_on() {      // A/B: VMR_CQ_MFMA=0 keeps the register kernels
   static int on = -1;
@@ -1107,11 +1139,13 @@ int set_lds(const void* fn, size_t bytes, const char* what) {
 
 }  // namespace
 
-// the fused apply kernels take: bf16, D a multiple of 128, one stream <= 32 rows, the other <= 256
+// the fused apply kernels take: a 16-bit element type, D a multiple of 128, one stream <= 32 rows, the other <= 128 (256 on MFMA)
 extern "C" int vmr_cq_apply_supported(int Lc, int Lq, int D, int dtype) {
   if (!vmr_dtype_16(dtype) || D % DS != 0 || Lc < 1 || Lq < 1) return 0;
   const int shorter = Lc < Lq ? Lc : Lq, longer = Lc < Lq ? Lq : Lc;
-  return shorter <= 32 && longer <= 256;
+  // (more than 128 long rows: the MFMA kernels' 64-channel-slice form only -- the register backward kernels' LDS images
+  //  of the long stream stop fitting near 200 rows)
+  return shorter <= 32 && (longer <= 128 || (longer <= 256 && cq_mfma_on()));
 }
 
 #define CQ_DISPATCH_SP1(E, SPV, KERNEL, ...)                                                          \
@@ -1140,16 +1174,20 @@ extern "C" int vmr_cq_apply_fwd(const void* ctx, const void* qry, const float* S
   static int fwd_env = -1;      // VMR_CQ_MFMA_FWD: bit 0 = context-short forward, bit 1 = context-long forward on MFMA
   if (fwd_env < 0) { const char* e = getenv("VMR_CQ_MFMA_FWD"); fwd_env = e ? atoi(e) : 3; }
   const int shortc = Lq > Lc;
-  if (cq_mfma_on() && (fwd_env & (shortc ? 1 : 2)) && (shortc ? (Lq <= 128 && Lc <= 32) : (Lc <= 128 && Lq <= 32))) {
-    const size_t ldsm = (size_t)(shortc ? 2 * 128 + 3 * 32 : 3 * 128 + 2 * 32) * IMG_LD * 2 + (size_t)2 * 128 * PLD * 2;
-#define CQ_FWD_MFMA(KERNEL, E)                                                                \
+  const int NLv = cq_mfma_nl(Lc, Lq);
+  if (cq_mfma_on() && NLv && (fwd_env & (shortc ? 1 : 2))) {
+#define CQ_FWD_MFMA(KERNEL, E, NL)                                                            \
     do {                                                                                      \
-      auto fn = KERNEL<E>;                                                                    \
+      const size_t ldsm = shortc ? cq_img_bytes<NL>(2, 3) : cq_img_bytes<NL>(3, 2);           \
+      const dim3 gridm(D / Geo<NL>::DSV, B);                                                  \
+      auto fn = KERNEL<E, NL>;                                                                \
       if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_apply_fwd")) return rc;             \
-      hipLaunchKernelGGL(fn, grid, dim3(256), ldsm, (hipStream_t)stream, a);                  \
+      hipLaunchKernelGGL(fn, gridm, dim3(256), ldsm, (hipStream_t)stream, a);                 \
     } while (0)
-    if (shortc) { if (dtype == VMR_F16) CQ_FWD_MFMA(cq_apply_fwd_cshort_mfma, f16_t); else CQ_FWD_MFMA(cq_apply_fwd_cshort_mfma, bf16_t); }
-    else { if (dtype == VMR_F16) CQ_FWD_MFMA(cq_apply_fwd_clong_mfma, f16_t); else CQ_FWD_MFMA(cq_apply_fwd_clong_mfma, bf16_t); }
+#define CQ_FWD_MFMA_E(KERNEL, NL) do { if (dtype == VMR_F16) CQ_FWD_MFMA(KERNEL, f16_t, NL); else CQ_FWD_MFMA(KERNEL, bf16_t, NL); } while (0)
+    if (shortc) { if (NLv == 256) CQ_FWD_MFMA_E(cq_apply_fwd_cshort_mfma, 256); else CQ_FWD_MFMA_E(cq_apply_fwd_cshort_mfma, 128); }
+    else { if (NLv == 256) CQ_FWD_MFMA_E(cq_apply_fwd_clong_mfma, 256); else CQ_FWD_MFMA_E(cq_apply_fwd_clong_mfma, 128); }
+#undef CQ_FWD_MFMA_E
 #undef CQ_FWD_MFMA
     VMR_LAUNCH_CHECK();
     return 0;
@@ -1186,17 +1224,17 @@ extern "C" int vmr_cq_apply_bwd(const void* dcat4, const void* ctx, const void* 
   const size_t img = (size_t)2 * a.LqP * IMG_LD * 2;
   if (Lq <= Lc) {
     const int SP = sp_of(Lq);
-    if (cq_mfma_on() && Lc <= 128 && Lq <= 32) {
-      const size_t ldsm = (size_t)(3 * 128 + 3 * 32) * IMG_LD * 2 + (size_t)2 * 128 * PLD * 2;
-      if (dtype == VMR_F16) {
-        auto fn = cq_apply_bwd_clong_mfma<f16_t>;
-        if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_apply_bwd")) return rc;
-        hipLaunchKernelGGL(fn, grid, dim3(256), ldsm, (hipStream_t)stream, a);
-      } else {
-        auto fn = cq_apply_bwd_clong_mfma<bf16_t>;
-        if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_apply_bwd")) return rc;
-        hipLaunchKernelGGL(fn, grid, dim3(256), ldsm, (hipStream_t)stream, a);
-      }
+    if (cq_mfma_on() && cq_mfma_nl(Lc, Lq)) {
+#define CQ_BWD_MFMA(KERNEL, E, NL, NLONG, NSHORT)                                             \
+      do {                                                                                    \
+        const size_t ldsm = cq_img_bytes<NL>(NLONG, NSHORT);                                  \
+        const dim3 gridm(D / Geo<NL>::DSV, B);                                                \
+        auto fn = KERNEL<E, NL>;                                                              \
+        if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_apply_bwd")) return rc;           \
+        hipLaunchKernelGGL(fn, gridm, dim3(256), ldsm, (hipStream_t)stream, a);               \
+      } while (0)
+#define CQ_BWD_MFMA_E(KERNEL, NL, NLONG, NSHORT) do { if (dtype == VMR_F16) CQ_BWD_MFMA(KERNEL, f16_t, NL, NLONG, NSHORT); else CQ_BWD_MFMA(KERNEL, bf16_t, NL, NLONG, NSHORT); } while (0)
+      if (cq_mfma_nl(Lc, Lq) == 256) CQ_BWD_MFMA_E(cq_apply_bwd_clong_mfma, 256, 3, 3); else CQ_BWD_MFMA_E(cq_apply_bwd_clong_mfma, 128, 3, 3);
       VMR_LAUNCH_CHECK();
       return 0;
     }
@@ -1206,17 +1244,8 @@ extern "C" int vmr_cq_apply_bwd(const void* dcat4, const void* ctx, const void* 
                    hipLaunchKernelGGL(fn, grid, dim3(256), lds, (hipStream_t)stream, a);)
   } else {
     const int SP = sp_of(Lc);
-    if (cq_mfma_on() && Lq <= 128 && Lc <= 32) {
-      const size_t ldsm = (size_t)(3 * 128 + 3 * 32) * IMG_LD * 2 + (size_t)2 * 128 * PLD * 2;
-      if (dtype == VMR_F16) {
-        auto fn = cq_apply_bwd_cshort_mfma<f16_t>;
-        if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_apply_bwd")) return rc;
-        hipLaunchKernelGGL(fn, grid, dim3(256), ldsm, (hipStream_t)stream, a);
-      } else {
-        auto fn = cq_apply_bwd_cshort_mfma<bf16_t>;
-        if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_apply_bwd")) return rc;
-        hipLaunchKernelGGL(fn, grid, dim3(256), ldsm, (hipStream_t)stream, a);
-      }
+    if (cq_mfma_on() && cq_mfma_nl(Lc, Lq)) {
+      if (cq_mfma_nl(Lc, Lq) == 256) CQ_BWD_MFMA_E(cq_apply_bwd_cshort_mfma, 256, 2, 3); else CQ_BWD_MFMA_E(cq_apply_bwd_cshort_mfma, 128, 2, 3);
       VMR_LAUNCH_CHECK();
       return 0;
     }
@@ -1239,7 +1268,9 @@ extern "C" int vmr_cq_softmax_bwd_parts(float* parts, const float* S_lm, const f
   const size_t lds = ((size_t)4 * Ll * SP + SP + 1024) * 4;
   VMR_CHECK(lds <= 160 * 1024, "vmr_cq_softmax_bwd_parts: score tile %dx%d does not fit LDS", Ll, SP);
   if (int rc = set_lds((const void*)cq_softmax_bwd_parts_kernel, lds, "vmr_cq_softmax_bwd_parts")) return rc;
-  const int LcP = (Lc + 15) / 16 * 16, LqP = (Lq + 15) / 16 * 16, nparts = D / DS;
+  // (slices written by vmr_cq_apply_bwd: the MFMA kernels take 64-channel slices when the longer stream exceeds 128 rows)
+  const int LcP = (Lc + 15) / 16 * 16, LqP = (Lq + 15) / 16 * 16;
+  const int nparts = (cq_mfma_on() && cq_mfma_nl(Lc, Lq) == 256) ? D / 64 : D / DS;
   int nsum = nparts;
   if (nparts > 1 && ((uintptr_t)parts & 15) == 0) {   // (parts is scratch: the slice sum is left in slice 0)
     const int64_t per4 = (int64_t)2 * LcP * LqP / 4, tot4 = per4 * B;
@@ -1264,11 +1295,17 @@ extern "C" int vmr_cq_score_bwd(const void* lng, const void* sht, const float* d
   a.Ll = Ll; a.Ls = Ls; a.D = D;
   const dim3 grid(D / DS, B);
   const int SP = sp_of(Ls);
-  if (cq_mfma_on() && dtype == VMR_BF16 && Ll <= 128) {      // (fp16 keeps dS in fp32: a scaled gradient may not fit the element type)
-    const size_t ldsm = (size_t)(2 * 128 + 32) * IMG_LD * 2 + (size_t)128 * PLD * 2;
-    auto fn = cq_score_bwd_mfma<bf16_t>;
-    if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_score_bwd")) return rc;
-    hipLaunchKernelGGL(fn, grid, dim3(256), ldsm, (hipStream_t)stream, a);
+  if (cq_mfma_on() && dtype == VMR_BF16 && Ll <= 256) {      // (fp16 keeps dS in fp32: a scaled gradient may not fit the element type)
+#define CQ_SB_MFMA(NL)                                                                                          \
+    do {                                                                                                        \
+      const size_t ldsm = (size_t)(NL + 32) * Geo<NL>::IMG * 2 + (size_t)NL * Geo<NL>::PLD * 2;                 \
+      const dim3 gridm(D / Geo<NL>::DSV, B);                                                                    \
+      auto fn = cq_score_bwd_mfma<bf16_t, NL>;                                                                  \
+      if (int rc = set_lds((const void*)fn, ldsm, "vmr_cq_score_bwd")) return rc;                               \
+      hipLaunchKernelGGL(fn, gridm, dim3(256), ldsm, (hipStream_t)stream, a);                                   \
+    } while (0)
+    if (Ll > 128) CQ_SB_MFMA(256); else CQ_SB_MFMA(128);
+#undef CQ_SB_MFMA
     VMR_LAUNCH_CHECK();
     return 0;
   }

@@ -243,6 +243,11 @@ __global__ __launch_bounds__(256) void cq_pad_zero_kernel(bf16_t* __restrict__ A
 extern "C" int vmr_cq_score_supported(int Ll, int Ls, int D, int dtype) {
   return vmr_dtype_16(dtype) && Ll >= 1 && Ll <= 128 && Ls >= 1 && Ls <= 32 && D % 256 == 0 && D >= 256 && D <= 2048;
 }
+// the row-split form (32 long rows per workgroup + the column-normalisation pass) also takes 128 < Ll <= 256 (BaseFast's
+// T = 256): fp32 pair only, with the vmr_cq_score_ws_floats(B) workspace (eight row groups)
+extern "C" int vmr_cq_score_split_supported(int Ll, int Ls, int D, int dtype) {
+  return vmr_dtype_16(dtype) && Ll >= 1 && Ll <= 256 && Ls >= 1 && Ls <= 32 && D % 256 == 0 && D >= 256 && D <= 2048;
+}
 
 static int g_split = -1;   // VMR_CQ_SPLIT / vmr_debug_set_cq_split
 extern "C" int vmr_debug_set_cq_split(int mode) {
@@ -260,7 +265,11 @@ extern "C" int vmr_cq_score_fwd_ws(const void* lng, const void* sht, const float
   VMR_CHECK((Srow && Scol) || (Pt_lm && Pv_lm), "vmr_cq_score_fwd: no output requested");
   VMR_CHECK((!Srow) == (!Scol) && (!Pt_lm) == (!Pv_lm), "vmr_cq_score_fwd: outputs come in pairs");
   VMR_CHECK((((uintptr_t)Pt_lm | (uintptr_t)Pv_lm) & 15) == 0, "vmr_cq_score_fwd: fp32 outputs must be 16-byte aligned");
-  VMR_CHECK(vmr_cq_score_supported(Ll, Ls, D, dtype), "vmr_cq_score_fwd: unsupported shape Ll=%d Ls=%d D=%d", Ll, Ls, D);
+  const bool long_rows = Ll > 128;      // only the row-split form takes these
+  VMR_CHECK(long_rows ? (vmr_cq_score_split_supported(Ll, Ls, D, dtype) && colstats && !Srow && Pt_lm)
+                      : vmr_cq_score_supported(Ll, Ls, D, dtype),
+            "vmr_cq_score_fwd: unsupported shape Ll=%d Ls=%d D=%d%s", Ll, Ls, D,
+            long_rows ? " (more than 128 long rows: fp32 pair + workspace only)" : "");
   VMR_CHECK(orient == 0 || orient == 1, "vmr_cq_score_fwd: bad orientation");
   VMR_CHECK(!Srow || (ldP % 4 == 0 && ldP >= (orient == 0 ? Ls : Ll)), "vmr_cq_score_fwd: bad ldP");
   if (B == 0) return 0;
@@ -274,7 +283,7 @@ extern "C" int vmr_cq_score_fwd_ws(const void* lng, const void* sht, const float
     const char* e = getenv("VMR_CQ_SPLIT");
     g_split = e ? atoi(e) : 0;   // measured at cfg2: 10.5 us + 5.1 us (column normalisation) against 15.0 us in one launch
   }
-  const bool split = g_split && colstats && !Srow && Pt_lm && Ll > 32;
+  const bool split = (g_split || long_rows) && colstats && !Srow && Pt_lm && Ll > 32;
   if (smem > 64 * 1024) {
     static thread_local bool done = false;
     if (!done) {

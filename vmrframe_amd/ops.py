@@ -2008,6 +2008,9 @@ def cq_block_supported(Lc, Lq, D, dtype):
     """Both halves of the fused CQAttention core take this shape (score kernel: long stream <= 128 rows)."""
     Ll, Ls = max(Lc, Lq), min(Lc, Lq)
     code = L.F32 if dtype == torch.float32 else L.BF16
+    if Ll > 128:      # (BaseFast's T = 256: the score kernel's row-split form + the 64-channel-slice apply kernels)
+        return bool(FUSED_CQ_APPLY and FUSED_CQ_SCORE and L.lib().vmr_cq_score_split_supported(Ll, Ls, D, code) and
+                    L.lib().vmr_cq_apply_supported(Lc, Lq, D, code))
     return (FUSED_CQ_APPLY and cq_score_supported(Ll, Ls, D, dtype) and
             bool(L.lib().vmr_cq_apply_supported(Lc, Lq, D, code)))
 
