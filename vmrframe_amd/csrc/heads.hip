@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void match_loss_final_kernel(const float* __re
   {   // sum of the per-workgroup partials (nparts <= 256: one per thread)
     float n_ = threadIdx.x < nparts ? stats[2 * threadIdx.x] : 0.f;
     float d_ = threadIdx.x < nparts ? stats[2 * threadIdx.x + 1] : 0.f;
-    n_ = wave_sum(n_);
-    d_ = wave_sum(d_);
+    n_ = wave_sum_dpp(n_);
+    d_ = wave_sum_dpp(d_);
     if ((threadIdx.x & 63) == 0) { tot[0][threadIdx.x >> 6] = n_; tot[1][threadIdx.x >> 6] = d_; }
   }
   float g[HC_MAX * HC_MAX];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void match_loss_final_kernel(const float* __re
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < HC_MAX * HC_MAX; ++i) {
-    const float s = wave_sum(g[i]);
+    const float s = wave_sum_dpp(g[i]);      // (16 + 2 wave reductions: as ds_bpermute butterflies they were most of this kernel)
     if (lane == 0) red[wid][i] = s;
   }
   __syncthreads();

@@ -89,13 +89,13 @@ __global__ __launch_bounds__(256) void weighted_pool_bwd_kernel(const T* __restr
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += xv[e] * gv[e];
     }
-    s = wave_sum(s);
+    s = wave_sum_dpp(s);
     if (lane == 0) ds[l] = s;
   }
   __syncthreads();
   float t = 0.f;
   for (int l = tid; l < L; l += 256) t += al[l] * ds[l];
-  t = wave_sum(t);
+  t = wave_sum_dpp(t);
   if (lane == 0) red[wid] = t;
   __syncthreads();
   t = red[0] + red[1] + red[2] + red[3];
