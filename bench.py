@@ -348,7 +348,11 @@ def main():
     import vmrframe_amd as V
     from vmrframe_amd import dp, ops
     from vmrframe_amd.optim import FlatAdamW
-    if world > 1:
+    # rehearsal hook for a 1-GPU box: VMR_DP_FORCE_COLLECTIVES=1 --force-split initialises a ONE-rank RCCL group and the
+    # reducers issue every collective although each is an identity: RCCL itself then runs this code's call pattern
+    # (async all-reduce / reduce-scatter / all-gather between the replays of the piecewise graphs)
+    rehearse = world == 1 and os.environ.get("VMR_DP_FORCE_COLLECTIVES", "0") == "1"
+    if world > 1 or rehearse:
         dp.init_process_group_from_env(os.environ.get("VMR_DIST_BACKEND", "nccl"))
 
     if args.workload == "ban":
@@ -527,7 +531,7 @@ def main():
                "final_loss": round(final_loss, 4), "hipgraph": not args.no_graph,
                "step_form": ("sharded-optimizer " if args.shard_optimizer else "") +
                             ("piecewise graphs (multi-rank form)" if split and not args.no_graph else "one graph"),
-               "dist": None if world == 1 else {"backend": dist.get_backend(), "world_observed": dist.get_world_size(),
+               "dist": None if (world == 1 and not dist.is_initialized()) else {"backend": dist.get_backend(), "world_observed": dist.get_world_size(),
                                                 "reduce_dtype": args.reduce_dtype,
                                                 "overlap": ("stage-cut backward; per stage: reduce-scatter of the matrix region + "
                                                             "all-reduce of the fp32 region; AdamW on the local slices; all-gather "
@@ -580,7 +584,7 @@ def main():
             if args.cpu_baseline_full:     # BASELINE.md's 1.42 clips/s (the reference itself, 8 Xeon cores) is THIS batch size
                 out["cpu_baseline_full"] = cpu_baseline(a, B=a["B"], n=1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -328,3 +328,27 @@ def test_two_ranks_sharded_optimizer_equals_all_reduce(dev, tmp_path):
         assert torch.equal(got[0]["w"][it], got[1]["w"][it])           # the same mirrors on both ranks
     assert torch.equal(got[0]["wg"], got[1]["wg"])                     # ... also after the captured steps (lock-step)
     assert torch.isfinite(got[0]["logits"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--shard-optimizer"], ["--reduce-dtype", "bf16"]])
+def test_rccl_runs_the_reducers_call_pattern_at_world_size_one(dev, extra):
+    """No multi-GPU box exists in this pipeline, so RCCL itself had never executed this code.  A ONE-rank RCCL group with
+    VMR_DP_FORCE_COLLECTIVES=1 makes the reducers issue every collective although each is an identity: async all-reduce
+    (ncclAvg) of the stage ranges between the replays of the piecewise hipGraphs, reduce-scatter + scalar all-reduce +
+    all-gather for the sharded optimizer, the bf16 staging buffer.  The run must finish, report the nccl backend and a
+    finite loss (bench.py asserts it), at the real cfg2 sizes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VMR_DP_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-split", "--steps", "4", "--warmup", "3",
+                        "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["dist"] is not None and out["dist"]["backend"] == "nccl" and out["dist"]["world_observed"] == 1
+    assert out["step_form"].endswith("piecewise graphs (multi-rank form)") and np.isfinite(out["final_loss"])
+

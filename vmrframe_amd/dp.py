@@ -90,6 +90,10 @@ class GradReducer:
     def __init__(self, model: torch.nn.Module, optimizer, reduce_dtype: torch.dtype = torch.float32):
         self.model, self.opt, self.reduce_dtype = model, optimizer, reduce_dtype
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # rehearsal hook (VMR_DP_FORCE_COLLECTIVES=1 with an initialised 1-rank group): issue every collective although
+        # it is an identity -- the only way to put RCCL itself through this call pattern on a one-GPU box
+        import os
+        self.collect = self.world > 1 or (dist.is_initialized() and os.environ.get("VMR_DP_FORCE_COLLECTIVES", "0") == "1")
         # RCCL averages in the collective itself (ncclAvg): no extra divide pass over the arena; gloo (CPU tests and
         # the one-GPU rehearsal) only sums
         self.avg = dist.is_initialized() and dist.get_backend() == "nccl"
@@ -114,7 +118,7 @@ class GradReducer:
         """Every gradient of stage i is final: send its arena range (callable from a captured-graph trainer too:
         it only enqueues a collective, on RCCL's stream, ordered after the current stream)."""
         rg = self.ranges()
-        if self.world == 1 or rg is None or i >= len(rg) or i in self.reduced:
+        if not self.collect or rg is None or i >= len(rg) or i in self.reduced:
             return
         self.reduced.add(i)
         lo, hi = rg[i]
@@ -135,7 +139,7 @@ class GradReducer:
 
     def finish(self):
         """Call after backward(): reduce whatever stage has not been sent yet, wait, average."""
-        if self.world == 1:
+        if not self.collect:
             return
         rg = self.ranges()
         if rg is None:                 # first step: the arena is not built yet -- one coalesced buffer
@@ -218,7 +222,7 @@ class ShardedReducer(GradReducer):
 
     def stage_done(self, i: int):
         sp = self.split()
-        if self.world == 1 or sp is None or i >= len(sp) or i in self.reduced:
+        if not self.collect or sp is None or i >= len(sp) or i in self.reduced:
             return
         self.reduced.add(i)
         lo, mid, hi = sp[i]
@@ -239,7 +243,7 @@ class ShardedReducer(GradReducer):
         self.launch_log.append(i)
 
     def finish(self):
-        if self.world == 1:
+        if not self.collect:
             return
         if self.split() is None:
             return super().finish()         # first step, no arena yet: one coalesced all-reduce
@@ -256,13 +260,13 @@ class ShardedReducer(GradReducer):
 
     def sum_scalar(self, t: torch.Tensor):
         """partial sums of squares -> their sum over the ranks (the clip norm of the averaged gradient)"""
-        if self.world > 1:
+        if self.collect:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
     def gather(self, flat: torch.Tensor):
         """All-gather every stage's matrix region of `flat` (the 16-bit mirror arena, or the fp32 masters): each rank
         contributes its own slice."""
-        if self.world == 1:
+        if not self.collect:
             return
         hs = []
         for (lo, mid, _), (a, b) in zip(self.split(), self.my_slices()):

@@ -99,6 +99,7 @@ class GraphedTrainStep:
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        self._quiesce_process_group()
         assert self.opt.arena is not None
         self.model.drop_step = self.opt.step_t      # int32[1] on the device, advanced inside the optimizer graph
         self.model._cache.clear()                   # every weight cast must be recorded in the graph
@@ -138,6 +139,20 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.g_opt, stream=s, pool=g0.pool(), **mode):
             self.opt.step()
         return self
+
+    @staticmethod
+    def _quiesce_process_group():
+        """Let the process group's watchdog retire the warm-up's collectives before a capture begins.  Its thread polls
+        the events of every outstanding work object (hipEventQuery, every ~100 ms); the captures below run in
+        thread-local error mode, which is meant to leave other threads' queries alone -- and yet one rehearsal run in
+        about eight (RCCL, one rank, the sharded step's extra captures) died inside the watchdog's
+        finishedGPUExecutionInternal with a HIP error raised from that query.  After a device synchronize every work
+        object is complete; a few poll periods later the watchdog's list is empty and it issues no query at all while we
+        capture (no collective is enqueued during a capture: they all sit between the replays)."""
+        import time
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            time.sleep(0.5)
 
     def load_batch(self, batch: Dict[str, torch.Tensor]):
         for k, v in batch.items():
