@@ -424,14 +424,14 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         print(f"[bench] warm-up done, loss {float(loss.item()):.4f}", file=sys.stderr, flush=True)
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
     dt = time.perf_counter() - t0
     final_loss = float(loss.item())
@@ -469,7 +469,7 @@ def main():
     ops.CQ_HOOK = None
     ops.CQ_APPLY_HOOK = None
     timed_steps_for_hook = 2
-    if world > 1:
+    if world > 1 or rehearse:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())

@@ -49,7 +49,8 @@ def broadcast_parameters(model: torch.nn.Module, src: int = 0, optimizer=None):
     """Every rank starts from rank `src`'s weights.  With a flat arena (optimizer given and built) that is ONE
     broadcast of the fp32 arena plus the few parameters outside it, followed by a refresh of the compute-dtype
     mirrors; before the arena exists, parameters are coalesced into one flat buffer per dtype."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    import os
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and os.environ.get("VMR_DP_FORCE_COLLECTIVES", "0") != "1"):
         return
     arena = getattr(optimizer, "arena", None)
     inside = set()
